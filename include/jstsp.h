@@ -1,0 +1,158 @@
+/*
+ * jstsp.h — C ABI of libjstsp_mi355x.so: the MI355X (gfx950) implementation of the
+ * sparse channel-estimation solver path of vlaxose/jstsp19.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one MATLAB
+ * function of the reference (cited per function as path:line under /root/reference) and
+ * is what a MEX gateway (mex/), a ctypes binding (jstsp19_amd/_lib.py) or any other FFI
+ * binds.  Plain pointers and sizes only.
+ *
+ * Conventions (all entry points)
+ *  - Arrays are COLUMN-MAJOR (MATLAB order, basic_system_functions/vec.m:1-2), complex
+ *    values INTERLEAVED {re, im} (jstsp_c32 == float[2]).
+ *  - `batch` independent problems are stacked along a trailing (slowest) dimension.
+ *    batch == 1 with 2-D inputs is exactly the un-batched MATLAB call.
+ *  - `memspace` says where EVERY array argument of that call lives:
+ *      JSTSP_HOST   — host memory; the library copies in/out (PCIe included in the call);
+ *      JSTSP_DEVICE — memory of the context's GPU (hipMalloc / a torch CUDA tensor); the
+ *                     call is asynchronous on the context's stream, nothing is copied.
+ *    Per-problem scalar arrays (tau_Y, tau_S, rho ...) are always HOST doubles.
+ *  - Return value: 0 = ok; < 0 = bad argument (JSTSP_E_*); > 0 = hipError_t of a failed
+ *    HIP call.  jstsp_last_error() gives a thread-local message.  No exception crosses
+ *    the boundary.  The library never keeps a caller pointer after the call returns
+ *    (JSTSP_HOST) / after the stream work completes (JSTSP_DEVICE).
+ *  - A context owns one HIP stream and a grow-only device workspace; it is not
+ *    thread-safe — use one context per thread / per parfor worker process.
+ */
+#ifndef JSTSP_H
+#define JSTSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jstsp_ctx jstsp_ctx;
+typedef struct { float re, im; } jstsp_c32;
+
+enum { JSTSP_HOST = 0, JSTSP_DEVICE = 1 };
+
+enum {
+    JSTSP_OK = 0,
+    JSTSP_E_NULL = -1,      /* required pointer is NULL                      */
+    JSTSP_E_SHAPE = -2,     /* non-positive / inconsistent dimensions        */
+    JSTSP_E_UNSUPPORTED = -3, /* shape outside what the kernels implement    */
+    JSTSP_E_ARG = -4,       /* bad enum / flag value                         */
+    JSTSP_E_NOMEM = -5      /* workspace allocation failed                   */
+};
+
+/* type argument of proposed_algorithm: 'approximate' vs anything else ('std')
+ * (basic_system_functions/proposed_algorithm.m:23-30,45-54). */
+enum { JSTSP_TYPE_APPROXIMATE = 0, JSTSP_TYPE_STD = 1 };
+
+/* ---- context ---------------------------------------------------------------------- */
+int  jstsp_create(int device_id, jstsp_ctx **out);
+int  jstsp_destroy(jstsp_ctx *ctx);
+/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+int  jstsp_set_stream(jstsp_ctx *ctx, void *hip_stream);
+int  jstsp_synchronize(jstsp_ctx *ctx);
+const char *jstsp_last_error(void);
+const char *jstsp_version(void);
+/* Device bytes currently held by the context's workspace. */
+size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
+
+/* ---- kernel-level entry points (the north-star correlation / synthesis) ------------ */
+
+/* out = A' * K * B'   (Gr x G2)   — `K2'*k` of proposed_algorithm.m:47 in structured form,
+ * `A'*r` of OMP.m:17 when the dictionary is kron(B.', A).
+ * K: N x M x batch.  A: N x Gr, B: G2 x M; strideA/strideB = elements between consecutive
+ * problems' A / B (0 = one dictionary shared by the whole batch). */
+int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                        const jstsp_c32 *K, const jstsp_c32 *A, long long strideA,
+                        const jstsp_c32 *B, long long strideB,
+                        jstsp_c32 *out, int memspace);
+
+/* out = A * S * B   (N x M)   — `K2*s` / `A*S*B` of proposed_algorithm.m:38,58. */
+int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                         const jstsp_c32 *S, const jstsp_c32 *A, long long strideA,
+                         const jstsp_c32 *B, long long strideB,
+                         jstsp_c32 *out, int memspace);
+
+/* ---- solvers ------------------------------------------------------------------------ */
+
+/* [S, Y, convergence_error] = proposed_algorithm(subY, Omega, A, B, Imax, tau_Y, tau_S, rho, type)
+ *   basic_system_functions/proposed_algorithm.m:1-73
+ * [S, Y, convergence_error] = proposed_algorithm_angles(subY, Omega, indx_S, A, B, Imax, ...)
+ *   basic_system_functions/proposed_algorithm_angles.m:1-85   (when indx_S != NULL)
+ *
+ * subY  : N x M x batch complex.       Omega : N x M x batch float (0/1 sampling mask).
+ * A     : N x Gr (strideA as above).   B     : G2 x M (strideB as above).
+ * tau_Y, tau_S, rho : host double[batch].
+ * indx_S: NULL, or Gr*G2 x batch int32, 1-BASED column-major linear indices into S in
+ *         descending-magnitude order (plot_errorVSsnr.m:143); same memspace as the arrays.
+ * S_out : Gr x G2 x batch.   Y_out : N x M x batch (may be NULL).
+ * ce_out: NULL (spectral norms are then not computed), or Imax x 3 x batch DOUBLE,
+ *         column-major (ce[i + Imax*c + 3*Imax*t]); same memspace as the arrays. */
+int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                                 const jstsp_c32 *subY, const float *Omega,
+                                 const jstsp_c32 *A, long long strideA,
+                                 const jstsp_c32 *B, long long strideB,
+                                 int Imax, const double *tau_Y, const double *tau_S,
+                                 const double *rho, int type, const int32_t *indx_S,
+                                 jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out,
+                                 int memspace);
+
+/* X = svt(Y, tau)   benchmark_algorithms/svt.m:1-15.   Y, X: Mr x Mt x batch; tau host double[batch]. */
+int jstsp_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Y,
+                  const double *tau, jstsp_c32 *X, int memspace);
+
+/* [x_hat, indexSet, v, targetMatrix] = OMP(A, v, m, snr)   benchmark_algorithms/OMP.m:1-32
+ * Dense dictionary A: measures x size_d (strideA 0 = shared); v: measures x batch.
+ * x_hat: size_d x batch; index_out: m x batch int32 (1-based); target_out: measures x m x batch
+ * (may be NULL).  `snr` is unused by the reference and has no parameter here. */
+int jstsp_omp_c32(jstsp_ctx *ctx, int measures, int size_d, int batch,
+                  const jstsp_c32 *A, long long strideA, const jstsp_c32 *v, int m,
+                  jstsp_c32 *x_hat, int32_t *index_out, jstsp_c32 *target_out, int memspace);
+
+/* OMP on the Kronecker dictionary Phi = kron(Bf.', Af) given by its factors (never formed):
+ * Af: N x Gr, Bf: G2 x M, y: N*M x batch, atoms indexed g + Gr*h (1-based in index_out). */
+int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                       const jstsp_c32 *Af, long long strideA, const jstsp_c32 *Bf,
+                       long long strideB, const jstsp_c32 *y, int m,
+                       jstsp_c32 *x_hat, int32_t *index_out, int memspace);
+
+/* [S, convergence_error] = sparse_admm(Htrue, OH, Dr, Dt, Imax)   benchmark_algorithms/sparse_admm.m:1-36
+ * Htrue, OH: Mr x Mt x batch; Dr: Mr x Gr, Dt: Mt x Gt (shared by the batch; Gr*Gt == Mr*Mt
+ * as the reference requires, :16).  S_out: Mr x Mt x batch; ce_out: NULL or Imax x batch double. */
+int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int Gt, int batch,
+                          const jstsp_c32 *Htrue, const jstsp_c32 *OH,
+                          const jstsp_c32 *Dr, const jstsp_c32 *Dt, int Imax,
+                          jstsp_c32 *S_out, double *ce_out, int memspace);
+
+/* X = mc_svt(OH, Omega, Imax, tau, rho)   benchmark_algorithms/mc_svt.m:1-12 */
+int jstsp_mc_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *OH,
+                     const float *Omega, int Imax, const double *tau, const double *rho,
+                     jstsp_c32 *X_out, int memspace);
+
+/* [X, convergence_error] = mc_admm(Htrue, OH, Omega, Imax, tau, rho)   benchmark_algorithms/mc_admm.m:1-34 */
+int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Htrue,
+                      const jstsp_c32 *OH, const float *Omega, int Imax, const double *tau,
+                      const double *rho, jstsp_c32 *X_out, double *ce_out, int memspace);
+
+/* nmse[t] = min(1, norm(S - Zbar)^2 / norm(Zbar)^2) with spectral norms
+ *   plot_errorVSsnr.m:138-141.   S, Zbar: R x C x batch; nmse: batch doubles (same memspace). */
+int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S,
+                            const jstsp_c32 *Zbar, double *nmse, int memspace);
+
+/* Per-kernel timing of the last proposed_algorithm call made with profiling enabled:
+ * jstsp_set_profiling(ctx, 1) brackets every launch of the dominant kernel with HIP
+ * events on the context's stream; jstsp_get_profile() returns launches and total ms. */
+int jstsp_set_profiling(jstsp_ctx *ctx, int enable);
+int jstsp_get_profile(jstsp_ctx *ctx, const char *kernel, int *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JSTSP_H */

@@ -1,0 +1,149 @@
+"""ctypes binding of libjstsp_mi355x.so (the C ABI declared in include/jstsp.h).
+
+There is NO CPU fallback: importing this module without the built library, or creating a
+context without an MI355X, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libjstsp_mi355x.so")
+
+HOST, DEVICE = 0, 1
+TYPE_APPROXIMATE, TYPE_STD = 0, 1
+
+c_void_p, c_int, c_ll, c_dp, c_ip = C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/jstsp.h one to one
+SIGNATURES = {
+    "jstsp_create": (c_int, [c_int, C.POINTER(c_void_p)]),
+    "jstsp_destroy": (c_int, [c_void_p]),
+    "jstsp_set_stream": (c_int, [c_void_p, c_void_p]),
+    "jstsp_synchronize": (c_int, [c_void_p]),
+    "jstsp_last_error": (C.c_char_p, []),
+    "jstsp_version": (C.c_char_p, []),
+    "jstsp_workspace_bytes": (C.c_size_t, [c_void_p]),
+    "jstsp_correlate_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll,
+                                    c_void_p, c_ll, c_void_p, c_int]),
+    "jstsp_synthesize_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll,
+                                     c_void_p, c_ll, c_void_p, c_int]),
+    "jstsp_proposed_algorithm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                             c_void_p, c_ll, c_void_p, c_ll, c_int, c_dp, c_dp, c_dp, c_int,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "jstsp_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_dp, c_void_p, c_int]),
+    "jstsp_omp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p,
+                              c_void_p, c_void_p, c_int]),
+    "jstsp_omp_kron_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_ll,
+                                   c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "jstsp_sparse_admm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "jstsp_mc_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_dp, c_dp,
+                                 c_void_p, c_int]),
+    "jstsp_mc_admm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_dp,
+                                  c_dp, c_void_p, c_void_p, c_int]),
+    "jstsp_nmse_spectral_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),
+    "jstsp_set_profiling": (c_int, [c_void_p, c_int]),
+    "jstsp_get_profile": (c_int, [c_void_p, C.c_char_p, c_ip, c_dp]),
+}
+
+
+class JstspError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype of include/jstsp.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JstspError(
+            "%s is missing: build it with `python -m jstsp19_amd.build` (hipcc, gfx950). "
+            "jstsp19_amd has no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so.7 /
+    # libhsa-runtime64; if ours (from /opt/rocm) were loaded first, torch would later find
+    # "No HIP GPUs".  Importing torch first makes the loader resolve this library's
+    # libamdhip64.so.7 dependency to the copy that is already mapped.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().jstsp_last_error().decode("utf-8", "replace")
+        raise JstspError("%s failed with code %d: %s" % (what or "jstsp call", rc, msg))
+
+
+class Context:
+    """One jstsp_ctx: a HIP stream + grow-only device workspace on one GPU."""
+
+    def __init__(self, device=0):
+        lib = load()
+        h = c_void_p()
+        check(lib.jstsp_create(int(device), C.byref(h)), "jstsp_create")
+        self._h = h
+        self.device = int(device)
+        self._lib = lib
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise JstspError("context already destroyed")
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        check(self._lib.jstsp_set_stream(self.handle, c_void_p(stream_ptr)), "jstsp_set_stream")
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        check(self._lib.jstsp_synchronize(self.handle), "jstsp_synchronize")
+
+    def workspace_bytes(self):
+        return int(self._lib.jstsp_workspace_bytes(self.handle))
+
+    def set_profiling(self, on):
+        check(self._lib.jstsp_set_profiling(self.handle, int(bool(on))), "jstsp_set_profiling")
+
+    def get_profile(self, kernel):
+        n, ms = c_int(0), C.c_double(0.0)
+        check(self._lib.jstsp_get_profile(self.handle, kernel.encode(), C.byref(n), C.byref(ms)),
+              "jstsp_get_profile")
+        return n.value, ms.value
+
+    def close(self):
+        if self._h is not None:
+            self._lib.jstsp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

@@ -1,0 +1,65 @@
+"""Build libjstsp_mi355x.so (hipcc, gfx950 only) in-tree under jstsp19_amd/csrc/.
+
+Cross-compiles without a GPU.  Objects are rebuilt only when a source or header is newer.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libjstsp_mi355x.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc"]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "jstsp.h"))
+    return hs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(CSRC, src[:-4] + ".o")
+    path = os.path.join(CSRC, src)
+    if _stale(obj, [path] + _headers()):
+        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(verbose=False, jobs=4):
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(verbose=True)

@@ -1,0 +1,328 @@
+// Kernel-level entry points (correlate / synthesize), svt, the matrix-completion baselines
+// mc_svt / mc_admm and the spectral-norm NMSE of the drivers.
+#include "solver_common.h"
+#include <algorithm>
+
+namespace jstsp {
+
+__global__ __launch_bounds__(256) void diff_kernel(long long n, const float2 *a, const float2 *b, float2 *o)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        o[i] = make_float2(a[i].x - b[i].x, a[i].y - b[i].y);
+}
+
+// nmse = min(1, num/den)   (plot_errorVSsnr.m:138-141; NaN stays NaN: `NaN > 1` is false)
+__global__ void ratio_cap_kernel(int batch, const float *num, const float *den, double *out, int cap,
+                                 long long ostride, long long ooff)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < batch) {
+        double e = (double)num[t] / (double)den[t];
+        if (cap && e > 1.0) e = 1.0;
+        out[(long long)t * ostride + ooff] = e;
+    }
+}
+
+// mc_svt.m:9   Y = Y + rho (OH - Omega .* X)
+__global__ __launch_bounds__(256) void mc_svt_update_kernel(long long nm, float2 *Y, const float2 *OH,
+                                                            const float *Omega, const float2 *X,
+                                                            const TrialParams *prm)
+{
+    const int t = blockIdx.y;
+    const float rho = prm[t].rho;
+    const long long base = (long long)t * nm, stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nm; i += stride) {
+        const float om = Omega[base + i];
+        const float2 x = X[base + i], oh = OH[base + i];
+        float2 y = Y[base + i];
+        y.x += rho * (oh.x - om * x.x);
+        y.y += rho * (oh.y - om * x.y);
+        Y[base + i] = y;
+    }
+}
+
+// mc_admm.m:24-26   Y = (OH + Z + rho X) ./ (Omega + rho);  Z = Z + rho (X - Y);  Zn = Y - Z/rho (next svt arg)
+__global__ __launch_bounds__(256) void mc_admm_update_kernel(long long nm, float2 *Y, float2 *Z,
+                                                             const float2 *OH, const float *invD,
+                                                             const float2 *X, const TrialParams *prm,
+                                                             float2 *Zn)
+{
+    const int t = blockIdx.y;
+    const float rho = prm[t].rho, ir = prm[t].irho;
+    const long long base = (long long)t * nm, stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nm; i += stride) {
+        const float id = invD[base + i];
+        const float2 x = X[base + i], oh = OH[base + i];
+        float2 z = Z[base + i];
+        const float2 y = make_float2((oh.x + z.x + rho * x.x) * id, (oh.y + z.y + rho * x.y) * id);
+        z.x += rho * (x.x - y.x);
+        z.y += rho * (x.y - y.y);
+        Y[base + i] = y;
+        Z[base + i] = z;
+        Zn[base + i] = make_float2(y.x - ir * z.x, y.y - ir * z.y);
+    }
+}
+
+static dim3 grid2(long long n, int batch)
+{
+    long long blocks = std::max<long long>(1, std::min<long long>((n + 255) / 256, (4096 + batch - 1) / batch));
+    return dim3((unsigned)blocks, (unsigned)batch);
+}
+
+static int check_common(jstsp_ctx *ctx, int memspace)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
+    JSTSP_HIP(hipSetDevice(ctx->device));
+    return 0;
+}
+
+static int upload_tau_rho(jstsp_ctx *ctx, int batch, const double *tau, const double *rho, TrialParams *prm)
+{
+    std::vector<TrialParams> hp(batch);
+    for (int t = 0; t < batch; ++t) {
+        const double r = rho ? rho[t] : 1.0;
+        hp[t].rho = (float)r;
+        hp[t].irho = (float)(1.0 / r);
+        hp[t].tauY_rho = (float)(tau[t] / r);
+        hp[t].tauS_rho = 0.f;
+        hp[t].c_coef = (float)(r / (r + 1.0));
+    }
+    return upload(ctx, prm, hp.data(), batch * sizeof(TrialParams));
+}
+
+}  // namespace jstsp
+
+using namespace jstsp;
+
+extern "C" {
+
+int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *K_,
+                        const jstsp_c32 *A_, long long strideA, const jstsp_c32 *B_, long long strideB,
+                        jstsp_c32 *out, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_REQUIRE(K_ && A_ && B_ && out, JSTSP_E_NULL, "correlate: NULL array argument");
+    JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0, JSTSP_E_SHAPE, "correlate: bad shape");
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
+    const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
+    const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
+    size_t need = rnd256(batch * ng * sizeof(float2)) + rnd256(batch * g * sizeof(float2));
+    if (memspace == JSTSP_HOST)
+        need += rnd256(batch * nm * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *K, *A, *B;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(K_), batch * nm, memspace, &K));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(B_), szB, memspace, &B));
+    float2 *Tc = ctx->arena.get<float2>(batch * ng);
+    float2 *O = ctx->arena.get<float2>(batch * g);
+    JSTSP_REQUIRE(Tc && O, JSTSP_E_NOMEM, "correlate: workspace exhausted");
+    // A^H (K B^H): the cheaper association (N*M*G2 + Gr*N*G2 MACs)
+    JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{K, (long long)nm, N}, Mat{B, strideB, G2}, Tc,
+                   (long long)ng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
+    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Mat{A, strideA, N}, Mat{Tc, (long long)ng, N}, O,
+                   (long long)g, Gr));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(out), O, batch * g, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *S_,
+                         const jstsp_c32 *A_, long long strideA, const jstsp_c32 *B_, long long strideB,
+                         jstsp_c32 *out, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_REQUIRE(S_ && A_ && B_ && out, JSTSP_E_NULL, "synthesize: NULL array argument");
+    JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0, JSTSP_E_SHAPE, "synthesize: bad shape");
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
+    const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
+    const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
+    size_t need = rnd256(batch * ng * sizeof(float2)) + rnd256(batch * nm * sizeof(float2));
+    if (memspace == JSTSP_HOST)
+        need += rnd256(batch * g * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *S, *A, *B;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(S_), batch * g, memspace, &S));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(B_), szB, memspace, &B));
+    float2 *W = ctx->arena.get<float2>(batch * ng);
+    float2 *O = ctx->arena.get<float2>(batch * nm);
+    JSTSP_REQUIRE(W && O, JSTSP_E_NOMEM, "synthesize: workspace exhausted");
+    JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Mat{A, strideA, N}, Mat{S, (long long)g, Gr}, W,
+                   (long long)ng, N));
+    JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{W, (long long)ng, N}, Mat{B, strideB, G2}, O,
+                   (long long)nm, N, 1.f, nullptr, 0, 0, 0.f, GEMM_SYNTH));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(out), O, batch * nm, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int jstsp_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Y_, const double *tau,
+                  jstsp_c32 *X_, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_REQUIRE(Y_ && tau && X_, JSTSP_E_NULL, "svt: NULL argument");
+    JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0, JSTSP_E_SHAPE, "svt: bad shape");
+    JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "svt: min(Mr, Mt) = %d > 128",
+                  std::min(Mr, Mt));
+    const size_t nm = (size_t)Mr * Mt;
+    size_t need = GramWS::bytes(Mr, Mt, batch, true) + rnd256(batch * sizeof(TrialParams)) +
+                  rnd256(batch * nm * sizeof(float2));
+    if (memspace == JSTSP_HOST) need += rnd256(batch * nm * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *Y;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Y_), batch * nm, memspace, &Y));
+    TrialParams *prm = ctx->arena.get<TrialParams>(batch);
+    float2 *X = ctx->arena.get<float2>(batch * nm);
+    JSTSP_REQUIRE(prm && X, JSTSP_E_NOMEM, "svt: workspace exhausted");
+    GramWS w;
+    JSTSP_TRY(w.alloc(ctx->arena, Mr, Mt, batch, true));
+    JSTSP_TRY(upload_tau_rho(ctx, batch, tau, nullptr, prm));
+    JSTSP_TRY(svt_batched(ctx, w, Y, prm, nullptr, X));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(X_), X, batch * nm, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S_,
+                            const jstsp_c32 *Zbar_, double *nmse, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_REQUIRE(S_ && Zbar_ && nmse, JSTSP_E_NULL, "nmse: NULL argument");
+    JSTSP_REQUIRE(R > 0 && C > 0 && batch > 0, JSTSP_E_SHAPE, "nmse: bad shape");
+    JSTSP_REQUIRE(std::min(R, C) <= 128, JSTSP_E_UNSUPPORTED, "nmse: min(R, C) = %d > 128", std::min(R, C));
+    const size_t n = (size_t)R * C;
+    size_t need = GramWS::bytes(R, C, batch, false) + rnd256(batch * n * sizeof(float2)) +
+                  2 * rnd256(batch * sizeof(float)) + rnd256(batch * sizeof(double));
+    if (memspace == JSTSP_HOST) need += 2 * rnd256(batch * n * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *S, *Zb;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(S_), batch * n, memspace, &S));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Zbar_), batch * n, memspace, &Zb));
+    float2 *D = ctx->arena.get<float2>(batch * n);
+    float *num = ctx->arena.get<float>(batch), *den = ctx->arena.get<float>(batch);
+    double *o = ctx->arena.get<double>(batch);
+    JSTSP_REQUIRE(D && num && den && o, JSTSP_E_NOMEM, "nmse: workspace exhausted");
+    GramWS w;
+    JSTSP_TRY(w.alloc(ctx->arena, R, C, batch, false));
+    const long long tot = (long long)batch * n;
+    hipLaunchKernelGGL(diff_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0,
+                       ctx->stream, tot, S, Zb, D);
+    JSTSP_TRY(sigma_max_sq(ctx, w, D, num));
+    JSTSP_TRY(sigma_max_sq(ctx, w, Zb, den));
+    hipLaunchKernelGGL(ratio_cap_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream, batch, num, den,
+                       o, 1, 1ll, 0ll);
+    JSTSP_HIP(hipGetLastError());
+    JSTSP_TRY(stage_out(ctx, nmse, o, (size_t)batch, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int jstsp_mc_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *OH_, const float *Omega_,
+                     int Imax, const double *tau, const double *rho, jstsp_c32 *X_out, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_REQUIRE(OH_ && Omega_ && tau && rho && X_out, JSTSP_E_NULL, "mc_svt: NULL argument");
+    JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0 && Imax >= 0, JSTSP_E_SHAPE, "mc_svt: bad shape");
+    JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "mc_svt: min(Mr, Mt) = %d > 128",
+                  std::min(Mr, Mt));
+    const size_t nm = (size_t)Mr * Mt;
+    size_t need = GramWS::bytes(Mr, Mt, batch, true) + rnd256(batch * sizeof(TrialParams)) +
+                  2 * rnd256(batch * nm * sizeof(float2));
+    if (memspace == JSTSP_HOST) need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *OH;
+    const float *Omega;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(OH_), batch * nm, memspace, &OH));
+    JSTSP_TRY(stage_in(ctx, Omega_, batch * nm, memspace, &Omega));
+    TrialParams *prm = ctx->arena.get<TrialParams>(batch);
+    float2 *Y = ctx->arena.get<float2>(batch * nm), *X = ctx->arena.get<float2>(batch * nm);
+    JSTSP_REQUIRE(prm && Y && X, JSTSP_E_NOMEM, "mc_svt: workspace exhausted");
+    GramWS w;
+    JSTSP_TRY(w.alloc(ctx->arena, Mr, Mt, batch, true));
+    JSTSP_TRY(upload_tau_rho(ctx, batch, tau, rho, prm));
+    JSTSP_HIP(hipMemsetAsync(Y, 0, batch * nm * sizeof(float2), ctx->stream));     // mc_svt.m:5
+    JSTSP_HIP(hipMemsetAsync(X, 0, batch * nm * sizeof(float2), ctx->stream));
+    for (int it = 0; it < Imax; ++it) {                                              // :7
+        JSTSP_TRY(svt_batched(ctx, w, Y, prm, nullptr, X));                          // :8
+        hipLaunchKernelGGL(mc_svt_update_kernel, grid2((long long)nm, batch), dim3(256), 0, ctx->stream,
+                           (long long)nm, Y, OH, Omega, X, prm);                     // :9
+    }
+    JSTSP_HIP(hipGetLastError());
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(X_out), X, batch * nm, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Htrue_,
+                      const jstsp_c32 *OH_, const float *Omega_, int Imax, const double *tau,
+                      const double *rho, jstsp_c32 *X_out, double *ce_out, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_REQUIRE(OH_ && Omega_ && tau && rho && X_out, JSTSP_E_NULL, "mc_admm: NULL argument");
+    JSTSP_REQUIRE(!ce_out || Htrue_, JSTSP_E_NULL, "mc_admm: convergence_error needs Htrue");
+    JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0 && Imax >= 0, JSTSP_E_SHAPE, "mc_admm: bad shape");
+    JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "mc_admm: min(Mr, Mt) = %d > 128",
+                  std::min(Mr, Mt));
+    const size_t nm = (size_t)Mr * Mt;
+    const bool want_ce = ce_out != nullptr;
+    size_t need = GramWS::bytes(Mr, Mt, batch, true) + rnd256(batch * sizeof(TrialParams)) +
+                  5 * rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
+                  2 * rnd256(batch * sizeof(float)) + rnd256((size_t)batch * std::max(Imax, 1) * sizeof(double));
+    if (want_ce) need += GramWS::bytes(Mr, Mt, batch, false);
+    if (memspace == JSTSP_HOST) need += 2 * rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *OH, *Htrue = nullptr;
+    const float *Omega;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(OH_), batch * nm, memspace, &OH));
+    JSTSP_TRY(stage_in(ctx, Omega_, batch * nm, memspace, &Omega));
+    if (want_ce) JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Htrue_), batch * nm, memspace, &Htrue));
+    TrialParams *prm = ctx->arena.get<TrialParams>(batch);
+    float2 *X = ctx->arena.get<float2>(batch * nm), *Y = ctx->arena.get<float2>(batch * nm),
+           *Z = ctx->arena.get<float2>(batch * nm), *Zn = ctx->arena.get<float2>(batch * nm),
+           *D = ctx->arena.get<float2>(batch * nm);
+    float *invD = ctx->arena.get<float>(batch * nm);
+    float *num = ctx->arena.get<float>(batch), *den = ctx->arena.get<float>(batch);
+    double *ce = ctx->arena.get<double>((size_t)batch * std::max(Imax, 1));
+    JSTSP_REQUIRE(prm && X && Y && Z && Zn && D && invD && num && den && ce, JSTSP_E_NOMEM,
+                  "mc_admm: workspace exhausted");
+    GramWS w, wn;
+    JSTSP_TRY(w.alloc(ctx->arena, Mr, Mt, batch, true));
+    if (want_ce) JSTSP_TRY(wn.alloc(ctx->arena, Mr, Mt, batch, false));
+    JSTSP_TRY(upload_tau_rho(ctx, batch, tau, rho, prm));
+    hipStream_t st = ctx->stream;
+    JSTSP_HIP(hipMemsetAsync(X, 0, batch * nm * sizeof(float2), st));                // mc_admm.m:6-8
+    JSTSP_HIP(hipMemsetAsync(Y, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(Z, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(Zn, 0, batch * nm * sizeof(float2), st));
+    JSTSP_TRY(launch_inv_d(ctx, (long long)nm, batch, Omega, 1.f, prm, invD));        // :11-17  A = diag(Omega) + rho I
+    if (want_ce) JSTSP_TRY(sigma_max_sq(ctx, wn, Htrue, den));
+    const long long tot = (long long)batch * nm;
+    for (int it = 0; it < Imax; ++it) {                                               // :20
+        JSTSP_TRY(svt_batched(ctx, w, Zn, prm, nullptr, X));                          // :22  X = svt(Y - Z/rho, tau/rho)
+        hipLaunchKernelGGL(mc_admm_update_kernel, grid2((long long)nm, batch), dim3(256), 0, st, (long long)nm,
+                           Y, Z, OH, invD, X, prm, Zn);                               // :24-26
+        if (want_ce) {                                                                // :28
+            hipLaunchKernelGGL(diff_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)),
+                               dim3(256), 0, st, tot, X, Htrue, D);
+            JSTSP_TRY(sigma_max_sq(ctx, wn, D, num));
+            hipLaunchKernelGGL(ratio_cap_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, num, den,
+                               ce, 0, (long long)Imax, (long long)it);
+        }
+    }
+    JSTSP_HIP(hipGetLastError());
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(X_out), X, batch * nm, memspace));
+    if (want_ce && Imax > 0) JSTSP_TRY(stage_out(ctx, ce_out, ce, (size_t)batch * Imax, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,143 @@
+// Internal declarations shared by the translation units of libjstsp_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/jstsp.h"
+
+namespace jstsp {
+
+void set_error(const char *fmt, ...);
+
+#define JSTSP_HIP(call)                                                                  \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            jstsp::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                             __FILE__, __LINE__);                                        \
+            return (int)e_;                                                              \
+        }                                                                                \
+    } while (0)
+
+#define JSTSP_TRY(expr)                                                                  \
+    do {                                                                                 \
+        int rc_ = (expr);                                                                \
+        if (rc_ != 0) return rc_;                                                        \
+    } while (0)
+
+#define JSTSP_REQUIRE(cond, code, ...)                                                   \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            jstsp::set_error(__VA_ARGS__);                                               \
+            return (code);                                                               \
+        }                                                                                \
+    } while (0)
+
+// Per-problem scalars of the ADMM solvers, resident on the device.
+struct TrialParams {
+    float rho, irho;        // rho, 1/rho
+    float tauY_rho;         // tau_Y / rho   (svt threshold, proposed_algorithm.m:35)
+    float tauS_rho;         // tau_S / rho   (soft threshold, :56)
+    float c_coef;           // rho/(rho+1)   (:61)
+    float pad[3];
+};
+
+// Grow-only device arena: one hipMalloc'd slab, bump allocation, reset per call.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    int reserve(size_t bytes);           // ensure capacity (may reallocate; invalidates pointers)
+    void reset() { off = 0; }
+    template <class T> T *get(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        if (off + bytes > cap) return nullptr;
+        T *p = reinterpret_cast<T *>(base + off);
+        off += bytes;
+        return p;
+    }
+    void release();
+};
+
+struct ProfileSlot {
+    int launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0;
+};
+
+}  // namespace jstsp
+
+struct jstsp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    jstsp::Arena arena;
+    bool profiling = false;
+    std::map<std::string, jstsp::ProfileSlot> prof;
+    std::vector<hipEvent_t> event_pool;
+    int num_cus = 256;
+    // pinned staging buffer for small host->device parameter blocks (stream-ordered uploads)
+    void *pinned = nullptr;
+    size_t pinned_cap = 0, pinned_off = 0;
+    hipEvent_t pinned_done = nullptr;
+    bool pinned_pending = false;
+};
+
+namespace jstsp {
+
+// ---- generic batched complex GEMM on the fp32 MFMA (cgemm.hip) ------------------------
+// C[t] (m x n, column-major, ld = ldc) = alpha * opA(A[t]) * opB(B[t]) + beta * D[t]
+// with element addressing  a(i,kk) = A[t*sAt + i*sAi + kk*sAk]  (conjugated if conjA)
+//                          b(kk,j) = B[t*sBt + kk*sBk + j*sBj]  (conjugated if conjB).
+// splitk > 1: the k range is cut in `splitk` chunks, chunk s written to C + s*sCsplit
+// (the consumer sums; alpha applied, beta/D ignored).
+struct GemmDesc {
+    const float2 *A; long long sAt, sAi, sAk; int conjA;
+    const float2 *B; long long sBt, sBk, sBj; int conjB;
+    float2 *C; long long sCt; int ldc;
+    const float2 *D; long long sDt; int ldd;
+    float alpha, beta;
+    int m, n, k, batch;
+    int splitk; long long sCsplit;
+};
+enum { GEMM_MISC = 0, GEMM_CORRELATE = 1, GEMM_SYNTH = 2, GEMM_GRAM = 3 };
+int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag = GEMM_MISC);
+
+// ---- batched Hermitian eigen-solver (eig.hip) -------------------------------------------
+// G[t] = sum_{s<nsplit} Gpart[t*sGt + s*sGs + i + n*j]   (n x n Hermitian PSD Gram, n <= 128)
+// mode EIG_SVT_Q : Q[t] = U diag(min(1, tau_t/sigma_i)) U^H with sigma = sqrt(lambda)
+//                  (so that svt(Z, tau) = Z - Q Z);  tau_t = prm[t].tauY_rho or tau[t]
+// mode EIG_LMAX  : lam_out[t] = largest eigenvalue
+enum { EIG_SVT_Q = 0, EIG_LMAX = 1 };
+int launch_eig(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt,
+               int nsplit, long long sGs, const TrialParams *prm, const float *tau,
+               float2 *Q, float *lam_out, float2 *Vg);
+bool eig_needs_global_v(int n);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)
+
+// ---- fused element-wise / reduction kernels (admm.hip) -----------------------------------
+int launch_form_z(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, const float2 *V1,
+                  const TrialParams *prm, float2 *Z);
+int launch_update_x(jstsp_ctx *ctx, long long nm, int batch, float2 *X, float2 *V1,
+                    const float2 *V2, const float2 *C, const float2 *Xs, const float2 *Y,
+                    const float2 *subY, const float *invD, const TrialParams *prm, float2 *K);
+int launch_update_c(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, const float2 *Xs,
+                    float2 *V2, float2 *C, const TrialParams *prm);
+int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const float2 *RRes,
+                  float2 *V, float2 *S, const int32_t *rank, int cnt, const TrialParams *prm,
+                  double *ce3, int Imax, int it);
+int launch_soft(jstsp_ctx *ctx, int g, int batch, const float2 *V, float2 *S, const int32_t *rank,
+                int cnt, const TrialParams *prm);
+int launch_inv_d(jstsp_ctx *ctx, long long nm, int batch, const float *Omega, float scale2rho,
+                 const TrialParams *prm, float *invD);
+int launch_rank_from_index(jstsp_ctx *ctx, int g, int batch, const int32_t *indx, int32_t *rank);
+int launch_ce_ratio(jstsp_ctx *ctx, int batch, const float *lamV1, const float *lamV2,
+                    const float *lamX, double *ce, int Imax, int it);
+
+// ---- profiling helpers ---------------------------------------------------------------------
+void prof_begin(jstsp_ctx *ctx, const char *name);
+void prof_end(jstsp_ctx *ctx, const char *name);
+
+}  // namespace jstsp

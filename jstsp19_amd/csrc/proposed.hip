@@ -1,0 +1,213 @@
+// jstsp_proposed_algorithm_c32 — the batched ADMM of
+//   basic_system_functions/proposed_algorithm.m:1-73          (indx_S == NULL)
+//   basic_system_functions/proposed_algorithm_angles.m:1-85   (indx_S != NULL)
+// in structured form: the dense Kronecker operators K1, K2, R, K3 of the
+// reference (:14-25, angles :37-43) are never formed —
+//   K2*s = vec(A S B),  K2'*k = vec(A^H K B^H),  R*v = vec((A^H A) V (B B^H)),
+//   iK1*b = b ./ (Omega + 2 rho),  K3*s = Omega_S .* S.
+// All problems of the batch advance together; every step below is one kernel launch over
+// the whole batch on the context's stream.
+#include "solver_common.h"
+#include <cmath>
+#include <algorithm>
+
+namespace jstsp {
+
+struct ProposedWS {
+    // state, N x M per problem
+    float2 *X, *V1, *V2, *C, *Xs, *Y, *ZK;
+    float *invD;
+    // Gr x G2 per problem
+    float2 *V, *RV, *Res, *RRes, *S, *P1;
+    // N x G2 per problem
+    float2 *Tc, *W;
+    float2 *GA, *GB;
+    TrialParams *prm;
+    int32_t *rank;
+    double *ce;
+    float *lam;            // 3 * batch
+    GramWS gz, gn;         // SVT of Z; spectral norms of V1, V2, X
+};
+
+static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, int nB, bool angles,
+                             bool want_ce, int Imax)
+{
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
+    size_t b = 0;
+    b += 7 * rnd256(batch * nm * sizeof(float2));
+    b += rnd256(batch * nm * sizeof(float));
+    b += 6 * rnd256(batch * g * sizeof(float2));
+    b += 2 * rnd256(batch * ng * sizeof(float2));
+    b += rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + rnd256((size_t)nB * G2 * G2 * sizeof(float2));
+    b += rnd256(batch * sizeof(TrialParams));
+    if (angles) b += rnd256(batch * g * sizeof(int32_t));
+    b += rnd256((size_t)batch * 3 * Imax * sizeof(double));
+    b += rnd256(3 * (size_t)batch * sizeof(float));
+    b += GramWS::bytes(N, M, batch, true);
+    if (want_ce) b += GramWS::bytes(N, M, batch, false);
+    return b;
+}
+
+static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2, int batch, int nA, int nB,
+                          bool angles, bool want_ce, int Imax)
+{
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
+    w.X = a.get<float2>(batch * nm); w.V1 = a.get<float2>(batch * nm); w.V2 = a.get<float2>(batch * nm);
+    w.C = a.get<float2>(batch * nm); w.Xs = a.get<float2>(batch * nm); w.Y = a.get<float2>(batch * nm);
+    w.ZK = a.get<float2>(batch * nm);
+    w.invD = a.get<float>(batch * nm);
+    w.V = a.get<float2>(batch * g); w.RV = a.get<float2>(batch * g); w.Res = a.get<float2>(batch * g);
+    w.RRes = a.get<float2>(batch * g); w.S = a.get<float2>(batch * g); w.P1 = a.get<float2>(batch * g);
+    w.Tc = a.get<float2>(batch * ng); w.W = a.get<float2>(batch * ng);
+    w.GA = a.get<float2>((size_t)nA * Gr * Gr); w.GB = a.get<float2>((size_t)nB * G2 * G2);
+    w.prm = a.get<TrialParams>(batch);
+    w.rank = angles ? a.get<int32_t>(batch * g) : nullptr;
+    w.ce = a.get<double>((size_t)batch * 3 * Imax);
+    w.lam = a.get<float>(3 * (size_t)batch);
+    JSTSP_REQUIRE(w.X && w.V1 && w.V2 && w.C && w.Xs && w.Y && w.ZK && w.invD && w.V && w.RV && w.Res &&
+                      w.RRes && w.S && w.P1 && w.Tc && w.W && w.GA && w.GB && w.prm && w.ce && w.lam &&
+                      (!angles || w.rank),
+                  JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
+    JSTSP_TRY(w.gz.alloc(a, N, M, batch, true));
+    if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, batch, false));
+    return 0;
+}
+
+}  // namespace jstsp
+
+using namespace jstsp;
+
+extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                                            const jstsp_c32 *subY_, const float *Omega_,
+                                            const jstsp_c32 *A_, long long strideA, const jstsp_c32 *B_,
+                                            long long strideB, int Imax, const double *tau_Y,
+                                            const double *tau_S, const double *rho, int type,
+                                            const int32_t *indx_S_, jstsp_c32 *S_out, jstsp_c32 *Y_out,
+                                            double *ce_out, int memspace)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_REQUIRE(subY_ && Omega_ && A_ && B_ && tau_Y && tau_S && rho && S_out, JSTSP_E_NULL,
+                  "proposed_algorithm: NULL array argument");
+    JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0 && Imax >= 0, JSTSP_E_SHAPE,
+                  "proposed_algorithm: bad shape N=%d M=%d Gr=%d G2=%d batch=%d Imax=%d", N, M, Gr, G2, batch,
+                  Imax);
+    JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d",
+                  memspace);
+    JSTSP_REQUIRE(type == JSTSP_TYPE_APPROXIMATE || type == JSTSP_TYPE_STD, JSTSP_E_ARG, "bad type %d", type);
+    JSTSP_REQUIRE(std::min(N, M) <= 128, JSTSP_E_UNSUPPORTED,
+                  "proposed_algorithm: min(N, M) = %d > 128 (order of the SVT's Gram eigenproblem)",
+                  std::min(N, M));
+    JSTSP_REQUIRE(strideA == 0 || strideA >= (long long)N * Gr, JSTSP_E_SHAPE, "strideA too small");
+    JSTSP_REQUIRE(strideB == 0 || strideB >= (long long)G2 * M, JSTSP_E_SHAPE, "strideB too small");
+    JSTSP_REQUIRE(type == JSTSP_TYPE_APPROXIMATE, JSTSP_E_UNSUPPORTED,
+                  "proposed_algorithm: only type 'approximate' (Algorithm 2) is implemented; "
+                  "'std' (LU least squares, proposed_algorithm.m:29,53) is not");
+    JSTSP_HIP(hipSetDevice(ctx->device));
+
+    const bool angles = indx_S_ != nullptr;
+    const bool want_ce = ce_out != nullptr;
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
+    const int nA = strideA ? batch : 1, nB = strideB ? batch : 1;
+    const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
+    const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
+
+    size_t need = proposed_bytes(N, M, Gr, G2, batch, nA, nB, angles, want_ce, std::max(Imax, 1));
+    if (memspace == JSTSP_HOST) {
+        need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
+                rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
+        if (angles) need += rnd256(batch * g * sizeof(int32_t));
+    }
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+
+    const float2 *subY, *A, *B;
+    const float *Omega;
+    const int32_t *indx_S = nullptr;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(subY_), batch * nm, memspace, &subY));
+    JSTSP_TRY(stage_in(ctx, Omega_, batch * nm, memspace, &Omega));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(B_), szB, memspace, &B));
+    if (angles) JSTSP_TRY(stage_in(ctx, indx_S_, batch * g, memspace, &indx_S));
+    if (memspace == JSTSP_DEVICE)
+        JSTSP_REQUIRE(((uintptr_t)subY % 16 == 0) && ((uintptr_t)Omega % 8 == 0), JSTSP_E_ARG,
+                      "device arrays must be 16-byte aligned");
+
+    ProposedWS w;
+    JSTSP_TRY(proposed_alloc(ctx->arena, w, N, M, Gr, G2, batch, nA, nB, angles, want_ce, std::max(Imax, 1)));
+
+    // ---- per-problem scalars ------------------------------------------------------------------
+    {
+        std::vector<TrialParams> hp(batch);
+        for (int t = 0; t < batch; ++t) {
+            const double r = rho[t];
+            hp[t].rho = (float)r;
+            hp[t].irho = (float)(1.0 / r);
+            hp[t].tauY_rho = (float)(tau_Y[t] / r);
+            hp[t].tauS_rho = (float)(tau_S[t] / r);
+            hp[t].c_coef = (float)(r / (r + 1.0));
+        }
+        JSTSP_TRY(upload(ctx, w.prm, hp.data(), batch * sizeof(TrialParams)));
+    }
+
+    // ---- setup: zero state (:8-12), iK1 (:14-20), Grams of the dictionary factors (:25) --------
+    hipStream_t st = ctx->stream;
+    JSTSP_HIP(hipMemsetAsync(w.X, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.V1, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.V2, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.C, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.Xs, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.Y, 0, batch * nm * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.V, 0, batch * g * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.S, 0, batch * g * sizeof(float2), st));
+    JSTSP_TRY(launch_inv_d(ctx, (long long)nm, batch, Omega, 2.f, w.prm, w.invD));
+    if (angles) JSTSP_TRY(launch_rank_from_index(ctx, (int)g, batch, indx_S, w.rank));
+
+    const Mat Am{A, strideA, N}, Bm{B, strideB, G2};
+    const Mat GAm{w.GA, strideA ? (long long)Gr * Gr : 0, Gr}, GBm{w.GB, strideB ? (long long)G2 * G2 : 0, G2};
+    // G_A = A^H A (Gr x Gr), G_B = B B^H (G2 x G2):  R = K2'*K2 = G_B^T (x) G_A
+    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
+    JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
+
+    const long long snm = (long long)nm, sg = (long long)g, sng = (long long)ng;
+    for (int it = 0; it < Imax; ++it) {
+        // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho)                                          (:35)
+        JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.ZK));
+        JSTSP_TRY(svt_batched(ctx, w.gz, w.ZK, w.prm, nullptr, w.Y));
+        // -- sub 2 + k of sub 3 + V1 dual update                                            (:38-43,:64)
+        JSTSP_TRY(launch_update_x(ctx, snm, batch, w.X, w.V1, w.V2, w.C, w.Xs, w.Y, subY, w.invD, w.prm, w.ZK));
+        // -- sub 3: res = K2'*k - R*v                                                        (:47)
+        //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
+        JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{w.ZK, snm, N}, Bm, w.Tc, sng, N, 1.f, nullptr, 0, 0,
+                       0.f, GEMM_CORRELATE));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.V, sg, Gr}, w.P1, sg, Gr));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RV, sg, Gr));
+        JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
+                       -1.f));
+        //    R*res for alpha = res'*res / (res'*R*res)                                        (:48)
+        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.Res, sg, Gr}, w.P1, sg, Gr));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RRes, sg, Gr));
+        //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                                (:49-56, angles :36,:68)
+        const long long cnt_ll = std::min<long long>(10 + 5ll * (it + 1), (long long)g);
+        JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
+                                Imax, it));
+        // -- Xs = A S B                                                                      (:58)
+        JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N, 1.f, nullptr, 0, 0,
+                       0.f, GEMM_SYNTH));
+        // -- sub 4 + V2 dual update                                                          (:61,:65)
+        JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
+        // -- convergence_error(i,1:2) = norm(V1)^2/norm(X)^2, norm(V2)^2/norm(X)^2           (:67,:69)
+        if (want_ce) {
+            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.V1, w.lam));
+            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.V2, w.lam + batch));
+            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.X, w.lam + 2 * batch));
+            JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam, w.lam + batch, w.lam + 2 * batch, w.ce, Imax, it));
+        }
+    }
+
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), w.S, batch * g, memspace));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), w.Y, batch * nm, memspace));
+    if (want_ce && Imax > 0) JSTSP_TRY(stage_out(ctx, ce_out, w.ce, (size_t)batch * 3 * Imax, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(st));
+    return 0;
+}

@@ -1,0 +1,330 @@
+// Context, workspace arena, error reporting, event-based kernel timing, and the host-side
+// helpers (GEMM shorthands, batched SVT / spectral norm) of libjstsp_mi355x.so.
+#include "solver_common.h"
+#include <cstring>
+#include <algorithm>
+
+namespace jstsp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int Arena::reserve(size_t bytes)
+{
+    if (bytes <= cap) return 0;
+    if (base) {
+        JSTSP_HIP(hipDeviceSynchronize());
+        JSTSP_HIP(hipFree(base));
+        base = nullptr;
+        cap = 0;
+    }
+    // a little headroom so that nearby shapes do not reallocate
+    size_t want = bytes + (bytes >> 4) + (1u << 20);
+    hipError_t e = hipMalloc((void **)&base, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes;
+        e = hipMalloc((void **)&base, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        base = nullptr;
+        set_error("workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        return JSTSP_E_NOMEM;
+    }
+    cap = want;
+    return 0;
+}
+
+void Arena::release()
+{
+    if (base) (void)hipFree(base);
+    base = nullptr;
+    cap = off = 0;
+}
+
+// ---- event timing of tagged kernels ----------------------------------------------------------
+static hipEvent_t take_event(jstsp_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(jstsp_ctx *ctx, const char *name)
+{
+    if (!ctx->profiling) return;
+    ProfileSlot &s = ctx->prof[name];
+    hipEvent_t a = take_event(ctx), b = take_event(ctx);
+    (void)hipEventRecord(a, ctx->stream);
+    s.pending.emplace_back(a, b);
+}
+
+void prof_end(jstsp_ctx *ctx, const char *name)
+{
+    if (!ctx->profiling) return;
+    ProfileSlot &s = ctx->prof[name];
+    (void)hipEventRecord(s.pending.back().second, ctx->stream);
+    s.launches++;
+}
+
+static void prof_collect(jstsp_ctx *ctx)
+{
+    for (auto &kv : ctx->prof) {
+        for (auto &pr : kv.second.pending) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(pr.second);
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.total_ms += ms;
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// ---- GEMM shorthand ---------------------------------------------------------------------------
+int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C,
+         long long sCt, int ldc, float alpha, const float2 *D, long long sDt, int ldd, float beta, int tag,
+         int splitk, long long sCsplit)
+{
+    GemmDesc d;
+    d.A = A.p; d.sAt = A.st;
+    if (opA == 'N') { d.sAi = 1; d.sAk = A.ld; d.conjA = 0; }       // a(i,kk) = A[i + ld*kk]
+    else            { d.sAi = A.ld; d.sAk = 1; d.conjA = 1; }       // a(i,kk) = conj(A[kk + ld*i])
+    d.B = B.p; d.sBt = B.st;
+    if (opB == 'N') { d.sBk = 1; d.sBj = B.ld; d.conjB = 0; }       // b(kk,j) = B[kk + ld*j]
+    else            { d.sBk = B.ld; d.sBj = 1; d.conjB = 1; }       // b(kk,j) = conj(B[j + ld*kk])
+    d.C = C; d.sCt = sCt; d.ldc = ldc;
+    d.D = D; d.sDt = sDt; d.ldd = ldd;
+    d.alpha = alpha; d.beta = beta;
+    d.m = m; d.n = n; d.k = k; d.batch = batch;
+    d.splitk = splitk < 1 ? 1 : splitk; d.sCsplit = sCsplit;
+    return launch_cgemm(ctx, d, tag);
+}
+
+// ---- Gram-form SVT ------------------------------------------------------------------------------
+static int pick_nsplit(int n, int kc, int batch)
+{
+    const int tiles = ((n + 63) / 64) * ((n + 63) / 64);
+    long long want = (1024 + (long long)batch * tiles - 1) / ((long long)batch * tiles);
+    const int kmax = std::max(1, kc / 256);
+    want = std::max<long long>(1, std::min<long long>(want, kmax));
+    return (int)std::min<long long>(want, 32);
+}
+
+size_t GramWS::bytes(int rows, int cols, int batch, bool need_q)
+{
+    const int n = std::min(rows, cols), kc = std::max(rows, cols);
+    const int ns = pick_nsplit(n, kc, batch);
+    size_t b = rnd256((size_t)batch * ns * n * n * sizeof(float2));
+    if (need_q) {
+        b += rnd256((size_t)batch * n * n * sizeof(float2));
+        if (eig_needs_global_v(n)) {
+            const int ne = (n + 1) & ~1;
+            b += rnd256((size_t)batch * ne * ne * sizeof(float2));
+        }
+    }
+    return b;
+}
+
+int GramWS::alloc(Arena &a, int rows_, int cols_, int batch_, bool need_q)
+{
+    rows = rows_; cols = cols_; batch = batch_;
+    n = std::min(rows, cols);
+    left = rows <= cols;
+    nsplit = pick_nsplit(n, std::max(rows, cols), batch);
+    Gpart = a.get<float2>((size_t)batch * nsplit * n * n);
+    JSTSP_REQUIRE(Gpart, JSTSP_E_NOMEM, "workspace exhausted (Gram partials)");
+    Q = nullptr; Vg = nullptr;
+    if (need_q) {
+        Q = a.get<float2>((size_t)batch * n * n);
+        JSTSP_REQUIRE(Q, JSTSP_E_NOMEM, "workspace exhausted (SVT projector)");
+        if (eig_needs_global_v(n)) {
+            const int ne = (n + 1) & ~1;
+            Vg = a.get<float2>((size_t)batch * ne * ne);
+            JSTSP_REQUIRE(Vg, JSTSP_E_NOMEM, "workspace exhausted (eigenvectors)");
+        }
+    }
+    return 0;
+}
+
+int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt)
+{
+    const Mat Zm{Z, sZt, w.rows};
+    const long long sG = (long long)w.n * w.n;
+    if (w.left)     // G = Z Z^H, contraction over the columns
+        return gemm(ctx, 'N', 'C', w.n, w.n, w.cols, w.batch, Zm, Zm, w.Gpart, sG * w.nsplit, w.n, 1.f,
+                    nullptr, 0, 0, 0.f, GEMM_GRAM, w.nsplit, sG);
+    // G = Z^H Z, contraction over the rows
+    return gemm(ctx, 'C', 'N', w.n, w.n, w.rows, w.batch, Zm, Zm, w.Gpart, sG * w.nsplit, w.n, 1.f, nullptr,
+                0, 0, 0.f, GEMM_GRAM, w.nsplit, sG);
+}
+
+int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm,
+                const float *tau, float2 *Y)
+{
+    const long long sZ = (long long)w.rows * w.cols;
+    const long long sG = (long long)w.n * w.n;
+    JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
+    JSTSP_TRY(launch_eig(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau, w.Q,
+                         nullptr, w.Vg));
+    const Mat Zm{Z, sZ, w.rows}, Qm{w.Q, sG, w.n};
+    if (w.left)     // Y = Z - Q Z
+        return gemm(ctx, 'N', 'N', w.rows, w.cols, w.n, w.batch, Qm, Zm, Y, sZ, w.rows, -1.f, Z, sZ, w.rows,
+                    1.f);
+    // Y = Z - Z Q
+    return gemm(ctx, 'N', 'N', w.rows, w.cols, w.n, w.batch, Zm, Qm, Y, sZ, w.rows, -1.f, Z, sZ, w.rows, 1.f);
+}
+
+int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam)
+{
+    const long long sZ = (long long)w.rows * w.cols;
+    const long long sG = (long long)w.n * w.n;
+    JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
+    return launch_eig(ctx, EIG_LMAX, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, nullptr, nullptr,
+                      nullptr, lam, nullptr);
+}
+
+int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    // Stream-ordered upload of a small parameter block through a pinned staging buffer owned by
+    // the context, so the caller's source may die immediately and earlier in-flight work on
+    // the stream is not disturbed.  The buffer is recycled once its last copy has completed.
+    if (ctx->pinned_off + bytes > ctx->pinned_cap) {
+        if (ctx->pinned_pending) {
+            JSTSP_HIP(hipEventSynchronize(ctx->pinned_done));
+            ctx->pinned_pending = false;
+        }
+        ctx->pinned_off = 0;
+        if (bytes > ctx->pinned_cap) {
+            if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+            ctx->pinned = nullptr;
+            const size_t cap = std::max(bytes, (size_t)1 << 20);
+            JSTSP_HIP(hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+            ctx->pinned_cap = cap;
+        }
+    }
+    char *stage = (char *)ctx->pinned + ctx->pinned_off;
+    memcpy(stage, src, bytes);
+    ctx->pinned_off += (bytes + 63) & ~size_t(63);
+    JSTSP_HIP(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->pinned_done) JSTSP_HIP(hipEventCreateWithFlags(&ctx->pinned_done, hipEventDisableTiming));
+    JSTSP_HIP(hipEventRecord(ctx->pinned_done, ctx->stream));
+    ctx->pinned_pending = true;
+    return 0;
+}
+
+}  // namespace jstsp
+
+using namespace jstsp;
+
+extern "C" {
+
+const char *jstsp_last_error(void) { return g_err; }
+const char *jstsp_version(void) { return "jstsp-mi355x 0.1 (gfx950)"; }
+
+int jstsp_create(int device_id, jstsp_ctx **out)
+{
+    JSTSP_REQUIRE(out, JSTSP_E_NULL, "jstsp_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("jstsp_create: no HIP device available (%s) — this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return e != hipSuccess ? (int)e : (int)hipErrorNoDevice;
+    }
+    JSTSP_REQUIRE(device_id >= 0 && device_id < ndev, JSTSP_E_ARG, "jstsp_create: device %d of %d", device_id,
+                  ndev);
+    JSTSP_HIP(hipSetDevice(device_id));
+    jstsp_ctx *c = new (std::nothrow) jstsp_ctx();
+    JSTSP_REQUIRE(c, JSTSP_E_NOMEM, "jstsp_create: out of host memory");
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete c;
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+        return (int)se;
+    }
+    c->own_stream = true;
+    *out = c;
+    return 0;
+}
+
+int jstsp_destroy(jstsp_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    prof_collect(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->pinned_done) (void)hipEventDestroy(ctx->pinned_done);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->arena.release();
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int jstsp_set_stream(jstsp_ctx *ctx, void *hip_stream)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        JSTSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return 0;
+}
+
+int jstsp_synchronize(jstsp_ctx *ctx)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+size_t jstsp_workspace_bytes(const jstsp_ctx *ctx) { return ctx ? ctx->arena.cap : 0; }
+
+int jstsp_set_profiling(jstsp_ctx *ctx, int enable)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    ctx->profiling = enable != 0;
+    if (enable) for (auto &kv : ctx->prof) { kv.second.launches = 0; kv.second.total_ms = 0; }
+    return 0;
+}
+
+int jstsp_get_profile(jstsp_ctx *ctx, const char *kernel, int *launches, double *total_ms)
+{
+    JSTSP_REQUIRE(ctx && kernel, JSTSP_E_NULL, "ctx/kernel is NULL");
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    prof_collect(ctx);
+    auto it = ctx->prof.find(kernel);
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.total_ms;
+    return 0;
+}
+
+}  // extern "C"

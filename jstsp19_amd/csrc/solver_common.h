@@ -1,0 +1,62 @@
+// Host-side helpers shared by the solver drivers: GEMM call shorthands, batched SVT,
+// spectral norms, host<->device staging.
+#pragma once
+#include "common.h"
+
+namespace jstsp {
+
+// Column-major matrix view of a batched operand: element (r, c) of problem t at
+// p[t*st + r + ld*c]; st == 0 => one matrix shared by the whole batch.
+struct Mat {
+    const float2 *p; long long st; int ld;
+};
+
+// C = alpha * op(A) * op(B) + beta * D, all column-major; opX in {'N','C'} ('C' = conj. transpose)
+int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C,
+         long long sCt, int ldc, float alpha = 1.f, const float2 *D = nullptr, long long sDt = 0,
+         int ldd = 0, float beta = 0.f, int tag = GEMM_MISC, int splitk = 1, long long sCsplit = 0);
+
+// Workspace of the Gram-form SVT / spectral norm of rows x cols matrices.
+struct GramWS {
+    int rows = 0, cols = 0, n = 0, nsplit = 1, batch = 0;
+    bool left = true;          // true: G = Z Z^H (rows <= cols); false: G = Z^H Z
+    float2 *Gpart = nullptr;   // batch * nsplit * n*n
+    float2 *Q = nullptr;       // batch * n*n
+    float2 *Vg = nullptr;      // eigenvectors in HBM when they do not fit in LDS
+    static size_t bytes(int rows, int cols, int batch, bool need_q);
+    int alloc(Arena &a, int rows, int cols, int batch, bool need_q);
+};
+
+// G partials of Z (split-K over the long dimension).
+int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt);
+// Y = svt(Z, tau_t): tau from prm[t].tauY_rho, or tau[t] when tau != nullptr.  Y may alias nothing.
+int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm,
+                const float *tau, float2 *Y);
+// lam[t] = sigma_max(Z_t)^2
+int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam);
+
+// Host -> device scalar block.
+int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+// Staging of an array argument according to memspace: returns a device pointer (the caller's
+// pointer for JSTSP_DEVICE, an arena copy for JSTSP_HOST).
+template <class T> int stage_in(jstsp_ctx *ctx, const T *src, size_t n, int memspace, const T **out)
+{
+    if (memspace == JSTSP_DEVICE) { *out = src; return 0; }
+    T *d = ctx->arena.get<T>(n);
+    JSTSP_REQUIRE(d, JSTSP_E_NOMEM, "workspace exhausted while staging an input");
+    JSTSP_HIP(hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    *out = d;
+    return 0;
+}
+template <class T> int stage_out(jstsp_ctx *ctx, T *dst, const T *dev, size_t n, int memspace)
+{
+    if (!dst) return 0;
+    JSTSP_HIP(hipMemcpyAsync(dst, dev, n * sizeof(T),
+                             memspace == JSTSP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                             ctx->stream));
+    return 0;
+}
+inline size_t rnd256(size_t b) { return (b + 255) & ~size_t(255); }
+
+}  // namespace jstsp

@@ -1,0 +1,153 @@
+"""Generate the committed golden fixtures under tests/golden/ (TEST INFRASTRUCTURE).
+
+The reference is MATLAB and cannot run here (no matlab/octave in the image),
+and it ships no test vectors of its own, so these fixtures are produced by the oracle's
+LITERAL restatement (dense kron / lu / full svd in the reference's operation order) on
+seeded numpy inputs.  They pin the structured oracle, the HIP path and any later refactor
+to the same numbers.  Run:  python -m oracle.make_golden
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+from . import solvers as S
+from . import system_model as sm
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+PARAMS_SMALL = dict(Nt=2, Nr=8, Mr_e=8, Gr=8, Gt=2, clusters=2, rays=3, L=3, Mr=3, T=5)
+# reference-native parameters, plot_errorVSsnr.m:8-25
+PARAMS_REF = dict(Nt=4, Nr=32, Mr_e=32, Gr=32, Gt=4, clusters=2, rays=3, L=4, Mr=4, T=35)
+
+
+def trial(params, snr_db, seed):
+    p = dict(params)
+    p["noise_var"] = 10 ** (-snr_db / 10)          # plot_errorVSsnr.m:49
+    rng = np.random.default_rng(seed)
+    d = sm.draw_trial(rng, p)
+    return p, d, sm.training_inputs_errorVSsnr(p, d)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f KiB)" % (path, os.path.getsize(path) / 1024))
+
+
+def gen_proposed(name, params, snr_db, seed, Imax, literal=True, types=("approximate",)):
+    p, d, inp = trial(params, snr_db, seed)
+    out = dict(subY=inp["subY"], Omega=inp["Omega"], A=inp["A"], B=inp["B"], Zbar=inp["Zbar"],
+               indx_S=inp["indx_S"], tau_Y=inp["tau_Y"], tau_Z=inp["tau_Z"], rho=inp["rho"], Imax=Imax,
+               snr_db=snr_db, seed=seed, literal=literal)
+    fn = S.proposed_algorithm_literal if literal else S.proposed_algorithm
+    for ty in types:
+        t0 = time.time()
+        Sx, Y, ce = fn(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax, inp["tau_Y"], inp["tau_Z"],
+                       inp["rho"], ty)
+        out["S_" + ty], out["Y_" + ty], out["ce_" + ty] = Sx, Y, ce
+        out["nmse_" + ty] = S.nmse_capped(Sx, inp["Zbar"])
+        print("  %s %s: nmse %.6f (%.1fs)" % (name, ty, out["nmse_" + ty], time.time() - t0))
+    t0 = time.time()
+    Sa, Ya, cea = fn(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax, inp["tau_Y"], inp["tau_Z"],
+                     inp["rho"], "approximate", indx_S=inp["indx_S"])
+    out["S_angles"], out["Y_angles"], out["ce_angles"] = Sa, Ya, cea
+    out["nmse_angles"] = S.nmse_capped(Sa, inp["Zbar"])
+    print("  %s angles: nmse %.6f (%.1fs)" % (name, out["nmse_angles"], time.time() - t0))
+    save(name, **out)
+
+
+def gen_svt():
+    rng = np.random.default_rng(11)
+    out = {}
+    for k, (r, c) in enumerate([(6, 9), (9, 6), (32, 140), (16, 16)]):
+        lowrank = (rng.standard_normal((r, 3)) + 1j * rng.standard_normal((r, 3))) @ \
+                  (rng.standard_normal((3, c)) + 1j * rng.standard_normal((3, c)))
+        Y = lowrank + 0.1 * (rng.standard_normal((r, c)) + 1j * rng.standard_normal((r, c)))
+        tau = float(0.3 * np.linalg.svd(Y, compute_uv=False)[1])
+        out["Y%d" % k], out["tau%d" % k], out["X%d" % k] = Y, tau, S.svt(Y, tau)
+    out["n"] = 4
+    save("svt", **out)
+
+
+def gen_omp():
+    rng = np.random.default_rng(12)
+    out = {}
+    # (a) closed-form KAT: unitary DFT dictionary, noiseless k-sparse vector => exact recovery
+    n, k = 32, 5
+    F = np.exp(-2j * np.pi * np.outer(np.arange(n), np.arange(n)) / n) / np.sqrt(n)
+    x = np.zeros(n, complex)
+    sup = np.sort(rng.choice(n, k, replace=False))
+    x[sup] = (rng.standard_normal(k) + 1j * rng.standard_normal(k)) + 2 * np.sign(rng.standard_normal(k))
+    v = F @ x
+    xh, idx, _, T = S.omp_literal(F, v, k)
+    out.update(A0=F, v0=v, m0=k, x0=xh, idx0=idx, T0=T, xtrue0=x)
+    # (b) random over-complete dictionary with noise, m larger than the sparsity
+    meas, size_d, m = 24, 40, 8
+    A = (rng.standard_normal((meas, size_d)) + 1j * rng.standard_normal((meas, size_d))) / np.sqrt(2 * meas)
+    x = np.zeros(size_d, complex)
+    x[rng.choice(size_d, 4, replace=False)] = rng.standard_normal(4) + 1j * rng.standard_normal(4)
+    v = A @ x + 0.01 * (rng.standard_normal(meas) + 1j * rng.standard_normal(meas))
+    xh, idx, _, T = S.omp_literal(A, v, m)
+    out.update(A1=A, v1=v, m1=m, x1=xh, idx1=idx, T1=T)
+    # (c) Kronecker dictionary (conventional-HBF baseline, plot_errorVSdelays.m:77 style)
+    p, d, inp = trial(PARAMS_SMALL, 5.0, 5)
+    Af, Bf = inp["A"], inp["B"]
+    y = S.vec(Af @ inp["Zbar"] @ Bf) + 0.01 * (rng.standard_normal(Af.shape[0] * Bf.shape[1])
+                                              + 1j * rng.standard_normal(Af.shape[0] * Bf.shape[1]))
+    Phi = np.kron(Bf.T, Af)
+    xh, idx, _, T = S.omp_literal(Phi, y, 6)
+    out.update(Af2=Af, Bf2=Bf, y2=y, m2=6, x2=xh, idx2=idx)
+    save("omp", **out)
+
+
+def gen_sparse_admm():
+    rng = np.random.default_rng(13)
+    Mr, Mt = 8, 6
+    Dr = np.exp(-2j * np.pi * np.outer(np.arange(Mr), np.arange(Mr)) / Mr) / np.sqrt(Mr)
+    Dt = np.exp(-2j * np.pi * np.outer(np.arange(Mt), np.arange(Mt)) / Mt) / np.sqrt(Mt)
+    Sp = np.zeros((Mr, Mt), complex)
+    Sp[rng.integers(0, Mr, 4), rng.integers(0, Mt, 4)] = rng.standard_normal(4) + 1j * rng.standard_normal(4)
+    H = Dr @ Sp @ Dt.conj().T
+    OH = H + 0.05 * (rng.standard_normal((Mr, Mt)) + 1j * rng.standard_normal((Mr, Mt)))
+    Sx, ce = S.sparse_admm_literal(H, OH, Dr, Dt, 40)
+    # non-unitary dictionaries (still Gr*Gt == Mr*Mt): exercises the eigen-solve
+    Dr2 = Dr + 0.2 * (rng.standard_normal((Mr, Mr)) + 1j * rng.standard_normal((Mr, Mr))) / np.sqrt(Mr)
+    Dt2 = Dt + 0.2 * (rng.standard_normal((Mt, Mt)) + 1j * rng.standard_normal((Mt, Mt))) / np.sqrt(Mt)
+    Sx2, ce2 = S.sparse_admm_literal(H, OH, Dr2, Dt2, 40)
+    save("sparse_admm", Htrue=H, OH=OH, Dr=Dr, Dt=Dt, Imax=40, S=Sx, ce=ce, Dr2=Dr2, Dt2=Dt2, S2=Sx2, ce2=ce2)
+
+
+def gen_mc():
+    rng = np.random.default_rng(14)
+    Mr, Mt = 10, 14
+    H = (rng.standard_normal((Mr, 2)) + 1j * rng.standard_normal((Mr, 2))) @ \
+        (rng.standard_normal((2, Mt)) + 1j * rng.standard_normal((2, Mt)))
+    Omega = (rng.random((Mr, Mt)) < 0.6).astype(float)
+    OH = Omega * (H + 0.01 * (rng.standard_normal((Mr, Mt)) + 1j * rng.standard_normal((Mr, Mt))))
+    tau, rho, Imax = 0.5, 0.1, 60
+    X1 = S.mc_svt(OH, Omega, Imax, tau, rho)
+    X2, ce2 = S.mc_admm_literal(H, OH, Omega, Imax, tau, rho)
+    save("mc", Htrue=H, OH=OH, Omega=Omega, tau=tau, rho=rho, Imax=Imax, X_svt=X1, X_admm=X2, ce_admm=ce2)
+
+
+def main():
+    t0 = time.time()
+    gen_proposed("proposed_small", PARAMS_SMALL, 5.0, 1, 30, literal=True, types=("approximate", "std"))
+    gen_proposed("proposed_small_lowsnr", PARAMS_SMALL, -10.0, 2, 30, literal=True, types=("approximate",))
+    gen_svt()
+    gen_omp()
+    gen_sparse_admm()
+    gen_mc()
+    if "--fast" not in sys.argv:
+        # reference-native shape (N=32, M=140, Gr=32, G2=16): dense K1 is 4480^2, K2 4480x512
+        gen_proposed("proposed_refnative", PARAMS_REF, 5.0, 3, 100, literal=True, types=("approximate",))
+    print("done in %.1fs" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""HIP path vs the float64 oracle / golden fixtures — proposed_algorithm(_angles).
+
+Tolerances (fp32 device arithmetic vs float64 reference restatement):
+  S, Y   : max|d| / max|ref| <= 2e-4
+  NMSE   : |d| <= 1e-6 (BASELINE.json north_star) at the reference-native shape and above
+  ce     : relative 2e-3 on convergence_error columns 1-2 (ratios of fp32 lambda_max), 1e-3 on column 3
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_S = 2e-4
+
+
+def _check(out, g, key, nmse_tol=1e-6, check_ce=True):
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    S, Y, ce = out
+    assert rel_err(S, g["S_" + key]) < TOL_S
+    assert rel_err(Y, g["Y_" + key]) < TOL_S
+    nm = O.nmse_capped(np.asarray(S, dtype=np.complex128), g["Zbar"])
+    assert abs(nm - float(g["nmse_" + key])) < nmse_tol
+    if check_ce:
+        ref = g["ce_" + key]
+        assert ce.shape == ref.shape
+        assert np.isinf(ce[0, 2]) and np.isinf(ref[0, 2])          # 0-divide at i = 1 (proposed_algorithm.m:51)
+        np.testing.assert_allclose(ce[1:, 2], ref[1:, 2], rtol=1e-3)
+        np.testing.assert_allclose(ce[:, :2], ref[:, :2], rtol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["proposed_small", "proposed_small_lowsnr", "proposed_refnative"])
+def test_proposed_host_path_matches_golden(name):
+    import jstsp19_amd as J
+    g = load_golden(name)
+    out = J.proposed_algorithm(g["subY"], g["Omega"], g["A"], g["B"], int(g["Imax"]), float(g["tau_Y"]),
+                               float(g["tau_Z"]), float(g["rho"]), "approximate")
+    _check(out, g, "approximate", nmse_tol=1e-6 if name == "proposed_refnative" else 2e-6)
+
+
+@pytest.mark.parametrize("name", ["proposed_small", "proposed_refnative"])
+def test_proposed_angles_matches_golden(name):
+    import jstsp19_amd as J
+    g = load_golden(name)
+    out = J.proposed_algorithm_angles(g["subY"], g["Omega"], g["indx_S"], g["A"], g["B"], int(g["Imax"]),
+                                      float(g["tau_Y"]), float(g["tau_Z"]), float(g["rho"]), "approximate", 100)
+    _check(out, g, "angles", nmse_tol=1e-6 if name == "proposed_refnative" else 2e-6)
+
+
+def test_first_iteration_invariants():
+    """Y_1 = 0 (svt of the zero matrix, svt.m:8-12) and ce(1,3) = Inf (proposed_algorithm.m:51)."""
+    import jstsp19_amd as J
+    g = load_golden("proposed_small")
+    S, Y, ce = J.proposed_algorithm(g["subY"], g["Omega"], g["A"], g["B"], 1, float(g["tau_Y"]),
+                                    float(g["tau_Z"]), float(g["rho"]), "approximate")
+    assert np.all(Y == 0)
+    assert np.isinf(ce[0, 2])
+    assert np.all(np.isfinite(S))
+
+
+def test_batched_device_path_per_trial_and_shared_dictionaries():
+    """batch > 1 on device-resident tensors: per-trial B, and one A shared by the batch.
+    Each problem must equal its own un-batched solve (same kernels => tight tolerance) and
+    the oracle."""
+    import torch
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    from oracle import system_model as sm
+    from oracle.make_golden import PARAMS_REF
+    dev = torch.device("cuda:0")
+    trials = []
+    for t in range(5):
+        p = dict(PARAMS_REF)
+        p["noise_var"] = 10 ** (-(3.0 * t - 5) / 10)
+        rng = np.random.default_rng(100 + t)
+        trials.append(sm.training_inputs_errorVSsnr(p, sm.draw_trial(rng, p)))
+    stack = lambda k, dt: np.stack([tr[k] for tr in trials]).astype(dt)
+    subY, Om, B = stack("subY", np.complex64), stack("Omega", np.float32), stack("B", np.complex64)
+    A = trials[0]["A"].astype(np.complex64)                 # ZC combiner x DFT: identical for every trial
+    tY = np.array([tr["tau_Y"] for tr in trials]); tZ = np.array([tr["tau_Z"] for tr in trials])
+    rho = np.array([tr["rho"] for tr in trials])
+    cm = lambda a: J.colmajor(torch.from_numpy(a).to(dev))
+    S, Y, ce = J.proposed_algorithm(cm(subY), cm(Om), cm(A), cm(B), 100, tY, tZ, rho, "approximate")
+    torch.cuda.synchronize()
+    S = S.cpu().numpy(); Y = Y.cpu().numpy(); ce = ce.cpu().numpy()
+    assert S.shape == (5, 32, 16) and Y.shape == (5, 32, 140) and ce.shape == (5, 100, 3)
+    for t, tr in enumerate(trials):
+        So, Yo, ceo = O.proposed_algorithm(tr["subY"], tr["Omega"], tr["A"], tr["B"], 100, tr["tau_Y"],
+                                           tr["tau_Z"], tr["rho"], "approximate")
+        assert rel_err(S[t], So) < TOL_S
+        assert rel_err(Y[t], Yo) < TOL_S
+        assert abs(O.nmse_capped(S[t].astype(complex), tr["Zbar"]) - O.nmse_capped(So, tr["Zbar"])) < 1e-6
+        np.testing.assert_allclose(ce[t, :, :2], ceo[:, :2], rtol=2e-3)
+        S1, Y1, _ = J.proposed_algorithm(tr["subY"], tr["Omega"], tr["A"], tr["B"], 100, tr["tau_Y"],
+                                         tr["tau_Z"], tr["rho"], "approximate", want_ce=False)
+        assert rel_err(S[t], S1) < 1e-5
+
+
+def test_ragged_shapes_not_multiples_of_the_tile():
+    """N, M, Gr, G2 that are not multiples of 32/64/16 (edge tiles, odd N*M => scalar path)."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(7)
+    N, M, Gr, G2 = 7, 13, 5, 9
+    A = (rng.standard_normal((N, Gr)) + 1j * rng.standard_normal((N, Gr))) / np.sqrt(N)
+    B = (rng.standard_normal((G2, M)) + 1j * rng.standard_normal((G2, M))) / np.sqrt(G2)
+    S0 = np.zeros((Gr, G2), complex); S0[1, 2] = 3 + 1j; S0[4, 7] = -2j
+    Om = (rng.random((N, M)) < 0.5).astype(float)
+    subY = Om * (A @ S0 @ B + 0.05 * (rng.standard_normal((N, M)) + 1j * rng.standard_normal((N, M))))
+    args = (subY, Om, A, B, 25, 0.01, 0.02, 0.3, "approximate")
+    So, Yo, ceo = O.proposed_algorithm(*args)
+    S, Y, ce = J.proposed_algorithm(*args)
+    assert rel_err(S, So) < TOL_S and rel_err(Y, Yo) < TOL_S
+    np.testing.assert_allclose(ce[1:, 2], ceo[1:, 2], rtol=1e-3)
+    np.testing.assert_allclose(ce[:, :2], ceo[:, :2], rtol=2e-3)
+
+
+def test_bad_arguments_are_rejected_not_crashed():
+    import jstsp19_amd as J
+    g = load_golden("proposed_small")
+    with pytest.raises(ValueError):
+        J.proposed_algorithm(g["subY"], g["Omega"][:, :-1], g["A"], g["B"], 5, 1.0, 1.0, 1.0)
+    with pytest.raises(ValueError):
+        J.proposed_algorithm(g["subY"], g["Omega"], g["A"][:-1], g["B"], 5, 1.0, 1.0, 1.0)
