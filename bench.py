@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — channel-estimates/sec of the batched proposed_algorithm on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic Monte-Carlo trials:
+`batch` independent proposed_algorithm solves (Imax = 100, 'approximate', all three outputs
+S, Y, convergence_error) at BASELINE.json configs[1]:
+    Nt = Nr = 64, Nrf (Mr) = 8, K (T) = 64, L = 8  =>  N = 64, M = T*Nt = 4096, Gr = 64, G2 = L*Gt = 512
+(symbol binding per SURVEY.md §8), 256 trials per GPU, inputs generated on the device
+(jstsp19_amd.system_model, per-trial pilots => per-trial B) and resident in HBM before the
+timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Trials shard embarrassingly over ranks (weak scaling: `batch` trials per GPU, global trial
+ids keyed into the RNG so inputs do not depend on N); the only collective is one RCCL
+all-reduce of the NMSE sum (plus the timing MAX).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+IMAX = 100
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="Monte-Carlo trials per GPU per step")
+    ap.add_argument("--snr-db", type=float, default=5.0)
+    ap.add_argument("--no-ce", action="store_true", help="skip convergence_error (2-output call)")
+    ap.add_argument("--cpu-trials", type=int, default=2, help="trials timed on the host oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="reference-native shape (plumbing check)")
+    return ap.parse_args()
+
+
+def make_inputs(p, trial_ids, device, chunk=16):
+    """Build the batch's solver inputs chunk by chunk directly into column-major buffers."""
+    from jstsp19_amd.solvers import empty_colmajor
+    from jstsp19_amd.system_model import build_inputs, draw_trials
+    T = len(trial_ids)
+    N, M, Gr, G2 = p.solver_shape
+    subY = empty_colmajor(T, N, M, torch.complex64, device)
+    Omega = empty_colmajor(T, N, M, torch.float32, device)
+    B = empty_colmajor(T, G2, M, torch.complex64, device)
+    Zbar = torch.empty((T, Gr, G2), dtype=torch.complex128, device=device)
+    tY, tZ, rho = [], [], []
+    A = None
+    for i in range(0, T, chunk):
+        ids = trial_ids[i:i + chunk]
+        o = build_inputs(p, draw_trials(p, ids, device=device))
+        subY[i:i + len(ids)] = o["subY"]
+        Omega[i:i + len(ids)] = o["Omega"]
+        B[i:i + len(ids)] = o["B"]
+        Zbar[i:i + len(ids)] = o["Zbar"]
+        tY.append(o["tau_Y"]); tZ.append(o["tau_Z"]); rho.append(o["rho"])
+        A = o["A"]
+        del o
+    torch.cuda.empty_cache()
+    return dict(subY=subY, Omega=Omega, A=A, B=B, Zbar=Zbar, tau_Y=torch.cat(tY).numpy(),
+                tau_Z=torch.cat(tZ).numpy(), rho=torch.cat(rho).numpy())
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import SweepParams
+
+    if a.small:   # plot_errorVSsnr.m:8-25
+        p = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4, snr_db=a.snr_db)
+        workload = "proposed_algorithm approximate Imax=100, reference-native Nr=32 Nt=4 L=4 T=35 (N=32 M=140 Gr=32 G2=16)"
+    else:         # BASELINE.json configs[1]
+        p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=a.snr_db)
+        workload = "proposed_algorithm approximate Imax=100, Nt=Nr=64 Nrf=8 K=64 L=8 (N=64 M=4096 Gr=64 G2=512)"
+    N, M, Gr, G2 = p.solver_shape
+    want_ce = not a.no_ce
+
+    ids = list(range(rank * a.batch, (rank + 1) * a.batch))
+    inp = make_inputs(p, ids, device)
+    ctx = J.default_context(local)
+
+    def step():
+        return J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], IMAX, inp["tau_Y"],
+                                    inp["tau_Z"], inp["rho"], "approximate", want_ce=want_ce)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    S, Y, ce = out
+    # NMSE per trial (plot_errorVSsnr.m:138-141), one all-reduce of the sum (:170 takes the mean)
+    nmse = J.nmse_spectral(S, J.colmajor(inp["Zbar"].to(torch.complex64)))
+    acc = torch.stack([nmse.sum(), torch.tensor(float(a.batch), dtype=torch.float64, device=device)])
+    if dist is not None:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    mean_nmse = float(acc[0] / acc[1])
+
+    # ---- roofline of the dominant kernel: one extra untimed step with HIP events on the launch stream
+    ctx.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    n_l, ms = ctx.get_profile("correlate")
+    n_s, ms_s = ctx.get_profile("synthesize")
+    ctx.set_profiling(False)
+    flops_per_launch = 8.0 * N * M * G2 * a.batch              # K * B^H, 8 real flops per complex MAC
+    roofline = None
+    if n_l:
+        avg_ms = ms / n_l
+        ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "cgemm_kernel<128, CORRELATE> (K*B^H of A^H K B^H)",
+                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
+                    "flops_per_launch": flops_per_launch,
+                    "synthesize_avg_launch_ms": round(ms_s / n_s, 4) if n_s else None}
+
+    # ---- CPU baseline + parity on a bounded sample (rank 0, single-GPU runs only) -------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.cpu_trials > 0:
+        from oracle import solvers as O
+        nt = min(a.cpu_trials, a.batch)
+        h = {k: inp[k][:nt].cpu().numpy() for k in ("subY", "Omega", "B", "Zbar")}
+        A_h = inp["A"].cpu().numpy().astype(np.complex128)
+        S_h = S[:nt].cpu().numpy().astype(np.complex128)
+        t0 = time.perf_counter()
+        dn = []
+        for t in range(nt):
+            So, Yo, ceo = O.proposed_algorithm(h["subY"][t].astype(np.complex128), h["Omega"][t].astype(np.float64),
+                                               A_h, h["B"][t].astype(np.complex128), IMAX, float(inp["tau_Y"][t]),
+                                               float(inp["tau_Z"][t]), float(inp["rho"][t]), "approximate",
+                                               want_ce=want_ce)
+            dn.append((O.nmse_capped(S_h[t], h["Zbar"][t]), O.nmse_capped(So, h["Zbar"][t]),
+                       float(np.max(np.abs(S_h[t] - So)) / np.max(np.abs(So)))))
+        cdt = time.perf_counter() - t0
+        cpu = {"value": round(nt / cdt, 4), "unit": "channel-estimates/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": "%d of the %d trials of this workload, float64 numpy/OpenBLAS structured restatement "
+                         "(oracle.solvers.proposed_algorithm, Imax=100, ce=%s)" % (nt, a.batch, want_ce)}
+        parity = {"trials": nt, "max_abs_dNMSE": float(max(abs(x[0] - x[1]) for x in dn)),
+                  "max_rel_dS": float(max(x[2] for x in dn)), "nmse_gpu": [x[0] for x in dn],
+                  "nmse_oracle": [x[1] for x in dn]}
+
+    if rank == 0:
+        total = a.batch * world * a.steps
+        line = {
+            "metric": "channel-estimates/sec (batched MC) at Nt=Nr=64,K=64; NMSE vs ref",
+            "value": round(total / dt, 3), "unit": "channel-estimates/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "c32", "data": "synthetic",
+            "config": {"workload": workload, "trials_per_gpu_per_step": a.batch, "Imax": IMAX,
+                       "outputs": "S,Y,convergence_error" if want_ce else "S,Y", "snr_db": a.snr_db,
+                       "pilots": "per-trial (B per trial)", "parallelism": "trials sharded, dp%d" % world},
+            "mean_nmse": mean_nmse, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -251,7 +251,7 @@ int jstsp_mc_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 
     JSTSP_HIP(hipMemsetAsync(Y, 0, batch * nm * sizeof(float2), ctx->stream));     // mc_svt.m:5
     JSTSP_HIP(hipMemsetAsync(X, 0, batch * nm * sizeof(float2), ctx->stream));
     for (int it = 0; it < Imax; ++it) {                                              // :7
-        JSTSP_TRY(svt_batched(ctx, w, Y, prm, nullptr, X));                          // :8
+        JSTSP_TRY(svt_batched(ctx, w, Y, prm, nullptr, X, true));                    // :8
         hipLaunchKernelGGL(mc_svt_update_kernel, grid2((long long)nm, batch), dim3(256), 0, ctx->stream,
                            (long long)nm, Y, OH, Omega, X, prm);                     // :9
     }
@@ -307,7 +307,7 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
     if (want_ce) JSTSP_TRY(sigma_max_sq(ctx, wn, Htrue, den));
     const long long tot = (long long)batch * nm;
     for (int it = 0; it < Imax; ++it) {                                               // :20
-        JSTSP_TRY(svt_batched(ctx, w, Zn, prm, nullptr, X));                          // :22  X = svt(Y - Z/rho, tau/rho)
+        JSTSP_TRY(svt_batched(ctx, w, Zn, prm, nullptr, X, true));                    // :22  X = svt(Y - Z/rho, tau/rho)
         hipLaunchKernelGGL(mc_admm_update_kernel, grid2((long long)nm, batch), dim3(256), 0, st, (long long)nm,
                            Y, Z, OH, invD, X, prm, Zn);                               // :24-26
         if (want_ce) {                                                                // :28

@@ -115,7 +115,14 @@ enum { EIG_SVT_Q = 0, EIG_LMAX = 1 };
 int launch_eig(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt,
                int nsplit, long long sGs, const TrialParams *prm, const float *tau,
                float2 *Q, float *lam_out, float2 *Vg);
-bool eig_needs_global_v(int n);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)
+bool eig_needs_global_v(int n);
+// Fast paths (eig2.hip): warm-started block Jacobi for n <= 64; tridiagonalisation + Sturm for lambda_max.
+int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
+                    long long sGs, const TrialParams *prm, const float *tau, float2 *Q, float *lam_out,
+                    float2 *Uwarm, int warm);
+int eig_fast_ne(int n);           // padded order (32 or 64) of the warm-start basis
+int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
+                float *lam_out);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)
 
 // ---- fused element-wise / reduction kernels (admm.hip) -----------------------------------
 int launch_form_z(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, const float2 *V1,

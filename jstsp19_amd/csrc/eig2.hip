@@ -1,0 +1,487 @@
+// Fast paths of the batched Hermitian eigen-solver for Gram matrices of order n <= 64
+// (the SVT of benchmark_algorithms/svt.m:5-10 and the spectral norms of
+// proposed_algorithm.m:67,69 at the BASELINE shapes).  One workgroup per matrix, everything in LDS.
+//
+//  * jacobi2_kernel<NE>: parallel-order two-sided Jacobi where each thread owns whole 2x2
+//    blocks (pair a, pair b) of G and applies J_a^H . J_b to them in registers — one LDS
+//    read + one write per element per round and two barriers per round (the general kernel
+//    in eig.hip makes separate column and row passes).  WARM START: the eigenvector basis of
+//    the previous ADMM iteration is kept per problem; G' = U^H G U (two 64^3 complex GEMMs
+//    on the fp32 MFMA, operands straight from LDS) is already nearly diagonal because the
+//    ADMM iterates move slowly, so 2-3 sweeps replace 7-8.  Q = U diag(q) U^H is a third
+//    in-LDS MFMA GEMM.
+//  * lmax_kernel<NE>: lambda_max only — Householder tridiagonalisation (zhetd2-style) in LDS,
+//    then 256-way multisection on the Sturm sequence of the real tridiagonal matrix.
+#include "common.h"
+
+namespace jstsp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// C[i + ldc*j] = sum_k a(i,k) b(k,j) for an NE x NE x NE complex product with all operands in
+// LDS.  a(i,k) = A[i*sAi + k*sAk] (conj if CA), b(k,j) = B[k*sBk + j*sBj] (conj if CB).
+// Each wave computes 32 x 32 blocks; MFMA fed (A-op = b, B-op = a) so lanes hold consecutive i.
+// If Cg != nullptr the result goes to global memory (ld = ldg) instead of LDS.
+template <int NE, bool CA, bool CB>
+__device__ __forceinline__ void lds_cgemm(const float2 *A, int sAi, int sAk, const float2 *B, int sBk,
+                                          int sBj, float2 *C, int ldc, float2 *Cg, int ldg, int nvalid)
+{
+    constexpr int NBLK = (NE / 32) * (NE / 32);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int blk = wave; blk < NBLK; blk += 4) {
+        const int i0 = (blk % (NE / 32)) * 32, j0 = (blk / (NE / 32)) * 32;
+        f32x16 re, im;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { re[r] = 0.f; im[r] = 0.f; }
+#pragma unroll 4
+        for (int kp = 0; kp < NE / 2; ++kp) {
+            const int k = 2 * kp + lhi;
+            float2 av = A[(i0 + l31) * sAi + k * sAk];
+            float2 bv = B[k * sBk + (j0 + l31) * sBj];
+            if (CA) av.y = -av.y;
+            if (CB) bv.y = -bv.y;
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, re, 0, 0, 0);
+            re = __builtin_amdgcn_mfma_f32_32x32x2f32(-bv.y, av.y, re, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.y, im, 0, 0, 0);
+            im = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.x, im, 0, 0, 0);
+        }
+        const int i = i0 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            if (Cg) {
+                if (i < nvalid && j < nvalid) Cg[i + (size_t)ldg * j] = make_float2(re[r], im[r]);
+            } else {
+                C[i + ldc * j] = make_float2(re[r], im[r]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void rr_pair2(int n, int s, int k, int &p, int &q)
+{
+    int a, b;
+    if (k == 0) { a = n - 1; b = s; }
+    else {
+        a = s + k; if (a >= n - 1) a -= n - 1;
+        b = s - k; if (b < 0) b += n - 1;
+    }
+    p = min(a, b);
+    q = max(a, b);
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cmulcf(float2 a, float2 b)   // conj(a) * b
+{
+    return make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
+}
+
+template <int NE>
+__global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const float2 *Gpart, long long sGt,
+                                                       int nsplit, long long sGs, const TrialParams *prm,
+                                                       const float *tau, float2 *Q, float *lam_out,
+                                                       float2 *Uwarm, int warm)
+{
+    constexpr int LD = NE + 1;
+    constexpr int H = NE / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2 *G = reinterpret_cast<float2 *>(smem_raw);       // [NE][LD] column-major
+    float2 *U = G + NE * LD;
+    float2 *T = U + NE * LD;
+    float *rot = reinterpret_cast<float *>(T + NE * LD);    // [H][4]: c, wx, wy, (p | q<<16)
+    float *red = rot + 4 * H;                               // [8]
+    float *qv = red + 8;                                    // [NE]
+    const int t = blockIdx.x, tid = threadIdx.x;
+    float2 *Uw = Uwarm ? Uwarm + (size_t)t * NE * NE : nullptr;
+
+    // ---- load G (sum of split-K partials, zero padded), U (previous basis or identity) ------
+    for (int e = tid; e < NE * NE; e += 256) {
+        const int i = e % NE, j = e / NE;
+        float2 g = make_float2(0.f, 0.f);
+        if (i < n && j < n) {
+            const float2 *src = Gpart + (long long)t * sGt + i + (long long)n * j;
+            for (int s = 0; s < nsplit; ++s) {
+                const float2 v = src[(long long)s * sGs];
+                g.x += v.x; g.y += v.y;
+            }
+        }
+        G[i + LD * j] = g;
+        U[i + LD * j] = (warm && Uw) ? Uw[e] : make_float2(i == j ? 1.f : 0.f, 0.f);
+    }
+    __syncthreads();
+    if (warm && Uw) {
+        // G' = U^H (G U)
+        lds_cgemm<NE, false, false>(G, 1, LD, U, 1, LD, T, LD, nullptr, 0, NE);
+        __syncthreads();
+        lds_cgemm<NE, true, false>(U, LD, 1, T, 1, LD, G, LD, nullptr, 0, NE);
+        __syncthreads();
+    }
+    // Hermitian-symmetrise (MFMA products are Hermitian only up to rounding)
+    for (int e = tid; e < NE * NE; e += 256) {
+        const int i = e % NE, j = e / NE;
+        if (i < j) {
+            const float2 u = G[i + LD * j], l = G[j + LD * i];
+            const float2 a = make_float2(0.5f * (u.x + l.x), 0.5f * (u.y - l.y));
+            G[i + LD * j] = a;
+            G[j + LD * i] = make_float2(a.x, -a.y);
+        } else if (i == j) {
+            G[i + LD * i].y = 0.f;
+        }
+    }
+    __syncthreads();
+    {
+        float m = 0.f;
+        for (int i = tid; i < NE; i += 256) m = fmaxf(m, fabsf(G[i + LD * i].x));
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = m;
+        __syncthreads();
+        if (tid == 0) red[1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        __syncthreads();
+    }
+    const float dmax = red[1];
+
+    constexpr int NBLKS = H * H;                       // 2x2 blocks of G per round
+    constexpr int BPT = (NBLKS + 255) / 256;           // blocks per thread
+    const int MAX_SWEEPS = 14;
+    for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
+        if (tid == 0) red[0] = 0.f;
+        float worst = 0.f;
+        for (int s = 0; s < NE - 1; ++s) {
+            // -- rotation of each of the H disjoint pairs of this round
+            if (tid < H) {
+                int p, q;
+                rr_pair2(NE, s, tid, p, q);
+                const float a = G[p + LD * p].x, dd = G[q + LD * q].x;
+                const float2 bq = G[p + LD * q];
+                const float ab = sqrtf(bq.x * bq.x + bq.y * bq.y);
+                float c = 1.f, wx = 0.f, wy = 0.f;
+                const float scale = sqrtf(fabsf(a) * fabsf(dd));
+                if (ab > 0.f && ab > 1e-8f * scale) {
+                    worst = fmaxf(worst, ab / fmaxf(scale, 1e-3f * dmax));
+                    const float zeta = (dd - a) / (2.f * ab);
+                    const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
+                    c = 1.f / sqrtf(1.f + tt * tt);
+                    const float sn = tt * c;
+                    wx = sn * bq.x / ab;
+                    wy = sn * bq.y / ab;
+                }
+                rot[4 * tid + 0] = c; rot[4 * tid + 1] = wx; rot[4 * tid + 2] = wy;
+                rot[4 * tid + 3] = __int_as_float(p | (q << 16));
+            }
+            __syncthreads();
+            // -- G <- J^H G J on 2x2 blocks (pair a rows, pair b columns); U <- U J on 2 x 2 blocks
+#pragma unroll
+            for (int it = 0; it < BPT; ++it) {
+                const int blk = tid + 256 * it;
+                if (NBLKS % 256 != 0 && blk >= NBLKS) break;
+                const int a = blk % H, b = blk / H;
+                const float4 ra = *reinterpret_cast<const float4 *>(&rot[4 * a]);
+                const float4 rb = *reinterpret_cast<const float4 *>(&rot[4 * b]);
+                const int pa = __float_as_int(ra.w) & 0xffff, qa = __float_as_int(ra.w) >> 16;
+                const int pb = __float_as_int(rb.w) & 0xffff, qb = __float_as_int(rb.w) >> 16;
+                const float ca = ra.x, cb = rb.x;
+                const float2 wa = make_float2(ra.y, ra.z), wb = make_float2(rb.y, rb.z);
+                const bool ida = (ra.y == 0.f && ra.z == 0.f), idb = (rb.y == 0.f && rb.z == 0.f);
+                // ---- G block
+                if (!(ida && idb)) {
+                    float2 gpp = G[pa + LD * pb], gpq = G[pa + LD * qb];
+                    float2 gqp = G[qa + LD * pb], gqq = G[qa + LD * qb];
+                    // right: [x_p, x_q] -> [c x_p - conj(w) x_q, w x_p + c x_q]   (columns pb, qb)
+                    float2 t0 = cmulcf(wb, gpq), t1 = cmulf(wb, gpp);
+                    float2 n_pp = make_float2(cb * gpp.x - t0.x, cb * gpp.y - t0.y);
+                    float2 n_pq = make_float2(t1.x + cb * gpq.x, t1.y + cb * gpq.y);
+                    t0 = cmulcf(wb, gqq); t1 = cmulf(wb, gqp);
+                    float2 n_qp = make_float2(cb * gqp.x - t0.x, cb * gqp.y - t0.y);
+                    float2 n_qq = make_float2(t1.x + cb * gqq.x, t1.y + cb * gqq.y);
+                    // left: [y_p; y_q] -> [c y_p - w y_q; conj(w) y_p + c y_q]     (rows pa, qa)
+                    t0 = cmulf(wa, n_qp); t1 = cmulcf(wa, n_pp);
+                    gpp = make_float2(ca * n_pp.x - t0.x, ca * n_pp.y - t0.y);
+                    gqp = make_float2(t1.x + ca * n_qp.x, t1.y + ca * n_qp.y);
+                    t0 = cmulf(wa, n_qq); t1 = cmulcf(wa, n_pq);
+                    gpq = make_float2(ca * n_pq.x - t0.x, ca * n_pq.y - t0.y);
+                    gqq = make_float2(t1.x + ca * n_qq.x, t1.y + ca * n_qq.y);
+                    if (a == b) {       // the annihilated block: exact zeros off the diagonal, real diagonal
+                        gpq = make_float2(0.f, 0.f); gqp = make_float2(0.f, 0.f);
+                        gpp.y = 0.f; gqq.y = 0.f;
+                    }
+                    G[pa + LD * pb] = gpp; G[pa + LD * qb] = gpq;
+                    G[qa + LD * pb] = gqp; G[qa + LD * qb] = gqq;
+                }
+                // ---- U block: rows 2a, 2a+1; columns pb, qb
+                if (!idb) {
+                    const int r0 = 2 * a, r1 = 2 * a + 1;
+                    const float2 u0p = U[r0 + LD * pb], u0q = U[r0 + LD * qb];
+                    const float2 u1p = U[r1 + LD * pb], u1q = U[r1 + LD * qb];
+                    float2 t0 = cmulcf(wb, u0q), t1 = cmulf(wb, u0p);
+                    U[r0 + LD * pb] = make_float2(cb * u0p.x - t0.x, cb * u0p.y - t0.y);
+                    U[r0 + LD * qb] = make_float2(t1.x + cb * u0q.x, t1.y + cb * u0q.y);
+                    t0 = cmulcf(wb, u1q); t1 = cmulf(wb, u1p);
+                    U[r1 + LD * pb] = make_float2(cb * u1p.x - t0.x, cb * u1p.y - t0.y);
+                    U[r1 + LD * qb] = make_float2(t1.x + cb * u1q.x, t1.y + cb * u1q.y);
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < H) atomicMax(reinterpret_cast<int *>(&red[0]), __float_as_int(worst));
+        __syncthreads();
+        const float w = red[0];
+        __syncthreads();
+        if (w < 3e-7f) break;
+    }
+
+    if (mode == EIG_LMAX) {
+        float m = -1e30f;
+        for (int i = tid; i < n; i += 256) m = fmaxf(m, G[i + LD * i].x);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) red[4 + (tid >> 6)] = m;
+        __syncthreads();
+        if (tid == 0) lam_out[t] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        return;
+    }
+    // ---- Q = U diag(q) U^H, q_i = min(1, tau/sigma_i); keep U for the next warm start ----------
+    const float tv = tau ? tau[t] : prm[t].tauY_rho;
+    for (int i = tid; i < NE; i += 256) {
+        const float sig = sqrtf(fmaxf(G[i + LD * i].x, 0.f));
+        qv[i] = (sig > 0.f) ? fminf(1.f, tv / sig) : 1.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < NE * NE; e += 256) {
+        const int i = e % NE, k = e / NE;
+        const float2 u = U[i + LD * k];
+        T[i + LD * k] = make_float2(u.x * qv[k], u.y * qv[k]);
+        if (Uw) Uw[e] = u;
+    }
+    __syncthreads();
+    // Q[i][j] = sum_k T[i][k] conj(U[j][k])
+    lds_cgemm<NE, false, true>(T, 1, LD, U, LD, 1, nullptr, 0, Q + (size_t)t * n * n, n, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lambda_max by Householder tridiagonalisation + Sturm multisection.
+template <int NE>
+__global__ __launch_bounds__(256) void lmax_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
+                                                    long long sGs, float *lam_out)
+{
+    constexpr int LD = NE + 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float2 *G = reinterpret_cast<float2 *>(smem_raw);       // [n][LD]
+    float2 *v = G + NE * LD;                                // [NE]
+    float2 *p = v + NE;                                     // [NE]
+    float *d = reinterpret_cast<float *>(p + NE);           // [NE] diagonal
+    float *e2 = d + NE;                                     // [NE] squared off-diagonal
+    float *sc = e2 + NE;                                    // [16] scalars
+    int *cnt = reinterpret_cast<int *>(sc + 16);            // [256]
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e % n, j = e / n;
+        const float2 *src = Gpart + (long long)t * sGt + e;
+        float2 g = make_float2(0.f, 0.f);
+        for (int s = 0; s < nsplit; ++s) {
+            const float2 x = src[(long long)s * sGs];
+            g.x += x.x; g.y += x.y;
+        }
+        G[i + LD * j] = g;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {       // symmetrise
+        const int i = e % n, j = e / n;
+        if (i < j) {
+            const float2 u = G[i + LD * j], l = G[j + LD * i];
+            const float2 a = make_float2(0.5f * (u.x + l.x), 0.5f * (u.y - l.y));
+            G[i + LD * j] = a;
+            G[j + LD * i] = make_float2(a.x, -a.y);
+        } else if (i == j) G[i + LD * i].y = 0.f;
+    }
+    __syncthreads();
+
+    for (int k = 0; k + 1 < n; ++k) {
+        const int m0 = k + 1;                      // active block rows/cols m0 .. n-1
+        // (1) reflector for column k below the diagonal (wave 0)
+        if (tid < 64) {
+            float ss = 0.f;
+            for (int i = m0 + 1 + lane; i < n; i += 64) {
+                const float2 x = G[i + LD * k];
+                ss += x.x * x.x + x.y * x.y;
+            }
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            const float2 alpha = G[m0 + LD * k];
+            float beta, taur, taui;
+            float2 scal;
+            if (ss == 0.f && alpha.y == 0.f) {      // nothing to annihilate: H = I
+                beta = alpha.x; taur = 0.f; taui = 0.f; scal = make_float2(0.f, 0.f);
+            } else {
+                const float nrm = sqrtf(alpha.x * alpha.x + alpha.y * alpha.y + ss);
+                beta = (alpha.x >= 0.f) ? -nrm : nrm;
+                taur = (beta - alpha.x) / beta;
+                taui = -alpha.y / beta;
+                const float dr = alpha.x - beta, di = alpha.y, den = dr * dr + di * di;
+                scal = make_float2(dr / den, -di / den);          // 1/(alpha - beta)
+            }
+            for (int i = m0 + lane; i < n; i += 64) {
+                float2 x = G[i + LD * k];
+                v[i] = (i == m0) ? make_float2(1.f, 0.f) : cmulf(x, scal);
+            }
+            if (lane == 0) {
+                d[k] = G[k + LD * k].x;
+                e2[k] = beta * beta;
+                sc[0] = taur; sc[1] = taui;
+            }
+        }
+        __syncthreads();
+        const float2 tauc = make_float2(sc[0], sc[1]);
+        const int m = n - m0;
+        if (tauc.x != 0.f || tauc.y != 0.f) {
+            // (2) p = tau * A v  (A = G[m0:, m0:]); 4 lanes per row, shuffle-reduced
+            for (int base = 0; base < m; base += 64) {
+                const int i = m0 + base + (tid >> 2), c = tid & 3;
+                float2 acc = make_float2(0.f, 0.f);
+                if (i < n)
+                    for (int j = m0 + c; j < n; j += 4) {
+                        const float2 g = G[i + LD * j], vj = v[j];
+                        acc.x += g.x * vj.x - g.y * vj.y;
+                        acc.y += g.x * vj.y + g.y * vj.x;
+                    }
+                acc.x += __shfl_xor(acc.x, 1); acc.y += __shfl_xor(acc.y, 1);
+                acc.x += __shfl_xor(acc.x, 2); acc.y += __shfl_xor(acc.y, 2);
+                if (c == 0 && i < n) p[i] = cmulf(tauc, acc);
+            }
+            __syncthreads();
+            // (3) w = p - (tau/2)(p^H v) v   (wave 0)
+            if (tid < 64) {
+                float2 dot = make_float2(0.f, 0.f);
+                for (int i = m0 + lane; i < n; i += 64) {
+                    const float2 c = cmulcf(p[i], v[i]);
+                    dot.x += c.x; dot.y += c.y;
+                }
+                for (int o = 32; o > 0; o >>= 1) { dot.x += __shfl_xor(dot.x, o); dot.y += __shfl_xor(dot.y, o); }
+                const float2 f = cmulf(make_float2(0.5f * tauc.x, 0.5f * tauc.y), dot);
+                for (int i = m0 + lane; i < n; i += 64) {
+                    const float2 fv = cmulf(f, v[i]);
+                    p[i] = make_float2(p[i].x - fv.x, p[i].y - fv.y);
+                }
+            }
+            __syncthreads();
+            // (4) A <- A - v w^H - w v^H
+            for (int e = tid; e < m * m; e += 256) {
+                const int i = m0 + e % m, j = m0 + e / m;
+                const float2 vi = v[i], wi = p[i], vj = v[j], wj = p[j];
+                float2 g = G[i + LD * j];
+                // v_i conj(w_j) + w_i conj(v_j)
+                g.x -= (vi.x * wj.x + vi.y * wj.y) + (wi.x * vj.x + wi.y * vj.y);
+                g.y -= (vi.y * wj.x - vi.x * wj.y) + (wi.y * vj.x - wi.x * vj.y);
+                G[i + LD * j] = g;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { d[n - 1] = G[(n - 1) + LD * (n - 1)].x; e2[n - 1] = 0.f; }
+    __syncthreads();
+
+    // ---- Gershgorin bounds, then multisection for the largest eigenvalue ------------------------
+    if (tid < 64) {
+        float lo = 1e30f, hi = -1e30f;
+        for (int i = lane; i < n; i += 64) {
+            const float r = (i > 0 ? sqrtf(e2[i - 1]) : 0.f) + (i + 1 < n ? sqrtf(e2[i]) : 0.f);
+            lo = fminf(lo, d[i] - r);
+            hi = fmaxf(hi, d[i] + r);
+        }
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) { sc[2] = lo; sc[3] = hi; }
+    }
+    __syncthreads();
+    float lo = sc[2], hi = sc[3];
+    const float span0 = fmaxf(hi - lo, 1e-30f);
+    hi += 1e-6f * span0 + 1e-30f;
+    for (int round = 0; round < 5; ++round) {
+        // candidate x_j = lo + (j+1) (hi-lo)/257 ; count(x) = #eigenvalues < x ; lambda_max in (x_j, x_{j+1}]
+        const float step = (hi - lo) / 257.f;
+        const float x = lo + (tid + 1) * step;
+        int c = 0;
+        float q = 1.f;
+        for (int i = 0; i < n; ++i) {
+            q = d[i] - x - (i > 0 ? e2[i - 1] / q : 0.f);
+            if (fabsf(q) < 1e-30f) q = -1e-30f;
+            c += (q < 0.f);
+        }
+        cnt[tid] = c;
+        __syncthreads();
+        // largest j with count(x_j) < n  => lambda_max > ... ; find first j with count == n
+        if (tid == 0) {
+            int first = 256;
+            for (int j = 0; j < 256; ++j) if (cnt[j] >= n) { first = j; break; }
+            sc[4] = lo + first * step;                    // count < n at this point (or lo)
+            sc[5] = (first < 256) ? lo + (first + 1) * step : hi;
+        }
+        __syncthreads();
+        lo = sc[4]; hi = sc[5];
+        __syncthreads();
+    }
+    if (tid == 0) lam_out[t] = 0.5f * (lo + hi);
+}
+
+template <int NE> static size_t jacobi2_smem()
+{
+    return (size_t)3 * NE * (NE + 1) * sizeof(float2) + (size_t)(4 * (NE / 2) + 8 + NE) * sizeof(float);
+}
+template <int NE> static size_t lmax_smem()
+{
+    return (size_t)NE * (NE + 1) * sizeof(float2) + (size_t)2 * NE * sizeof(float2) +
+           (size_t)(2 * NE + 16) * sizeof(float) + 256 * sizeof(int);
+}
+
+template <int NE>
+static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt,
+                            int nsplit, long long sGs, const TrialParams *prm, const float *tau, float2 *Q,
+                            float *lam_out, float2 *Uwarm, int warm)
+{
+    const size_t sh = jacobi2_smem<NE>();
+    JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi2_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sh));
+    hipLaunchKernelGGL((jacobi2_kernel<NE>), dim3(batch), dim3(256), sh, ctx->stream, mode, n, Gpart, sGt, nsplit,
+                       sGs, prm, tau, Q, lam_out, Uwarm, warm);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// SVT projector with warm start; n <= 64.  Uwarm: batch * NE*NE float2 (NE = 32 or 64), or nullptr.
+int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
+                    long long sGs, const TrialParams *prm, const float *tau, float2 *Q, float *lam_out,
+                    float2 *Uwarm, int warm)
+{
+    JSTSP_REQUIRE(n >= 1 && n <= 64, JSTSP_E_UNSUPPORTED, "launch_eig_fast: n = %d > 64", n);
+    if (n <= 32)
+        return launch_jacobi2_t<32>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
+    return launch_jacobi2_t<64>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
+}
+
+int eig_fast_ne(int n) { return n <= 32 ? 32 : 64; }
+
+template <int NE>
+static int launch_lmax_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
+                         long long sGs, float *lam_out)
+{
+    const size_t sh = lmax_smem<NE>();
+    JSTSP_HIP(hipFuncSetAttribute((const void *)lmax_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sh));
+    hipLaunchKernelGGL((lmax_kernel<NE>), dim3(batch), dim3(256), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs,
+                       lam_out);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// lam_out[t] = lambda_max of the n x n Hermitian matrix sum_s Gpart[t][s]; n <= 128.
+int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
+                float *lam_out)
+{
+    JSTSP_REQUIRE(n >= 1 && n <= 128, JSTSP_E_UNSUPPORTED, "launch_lmax: n = %d outside [1,128]", n);
+    if (n <= 32) return launch_lmax_t<32>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+    if (n <= 64) return launch_lmax_t<64>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+    return launch_lmax_t<128>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+}
+
+}  // namespace jstsp

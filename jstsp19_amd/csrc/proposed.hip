@@ -172,7 +172,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     for (int it = 0; it < Imax; ++it) {
         // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho)                                          (:35)
         JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.ZK));
-        JSTSP_TRY(svt_batched(ctx, w.gz, w.ZK, w.prm, nullptr, w.Y));
+        JSTSP_TRY(svt_batched(ctx, w.gz, w.ZK, w.prm, nullptr, w.Y, true));
         // -- sub 2 + k of sub 3 + V1 dual update                                            (:38-43,:64)
         JSTSP_TRY(launch_update_x(ctx, snm, batch, w.X, w.V1, w.V2, w.C, w.Xs, w.Y, subY, w.invD, w.prm, w.ZK));
         // -- sub 3: res = K2'*k - R*v                                                        (:47)

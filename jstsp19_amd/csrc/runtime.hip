@@ -131,7 +131,8 @@ size_t GramWS::bytes(int rows, int cols, int batch, bool need_q)
     size_t b = rnd256((size_t)batch * ns * n * n * sizeof(float2));
     if (need_q) {
         b += rnd256((size_t)batch * n * n * sizeof(float2));
-        if (eig_needs_global_v(n)) {
+        if (n <= 64) b += rnd256((size_t)batch * eig_fast_ne(n) * eig_fast_ne(n) * sizeof(float2));
+        else if (eig_needs_global_v(n)) {
             const int ne = (n + 1) & ~1;
             b += rnd256((size_t)batch * ne * ne * sizeof(float2));
         }
@@ -147,11 +148,14 @@ int GramWS::alloc(Arena &a, int rows_, int cols_, int batch_, bool need_q)
     nsplit = pick_nsplit(n, std::max(rows, cols), batch);
     Gpart = a.get<float2>((size_t)batch * nsplit * n * n);
     JSTSP_REQUIRE(Gpart, JSTSP_E_NOMEM, "workspace exhausted (Gram partials)");
-    Q = nullptr; Vg = nullptr;
+    Q = nullptr; Vg = nullptr; Uwarm = nullptr; warm = 0;
     if (need_q) {
         Q = a.get<float2>((size_t)batch * n * n);
         JSTSP_REQUIRE(Q, JSTSP_E_NOMEM, "workspace exhausted (SVT projector)");
-        if (eig_needs_global_v(n)) {
+        if (n <= 64) {
+            Uwarm = a.get<float2>((size_t)batch * eig_fast_ne(n) * eig_fast_ne(n));
+            JSTSP_REQUIRE(Uwarm, JSTSP_E_NOMEM, "workspace exhausted (warm-start basis)");
+        } else if (eig_needs_global_v(n)) {
             const int ne = (n + 1) & ~1;
             Vg = a.get<float2>((size_t)batch * ne * ne);
             JSTSP_REQUIRE(Vg, JSTSP_E_NOMEM, "workspace exhausted (eigenvectors)");
@@ -173,13 +177,19 @@ int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZ
 }
 
 int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm,
-                const float *tau, float2 *Y)
+                const float *tau, float2 *Y, bool sequence)
 {
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
     JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
-    JSTSP_TRY(launch_eig(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau, w.Q,
-                         nullptr, w.Vg));
+    if (w.n <= 64) {
+        JSTSP_TRY(launch_eig_fast(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau,
+                                  w.Q, nullptr, w.Uwarm, sequence ? w.warm : 0));
+        w.warm = sequence ? 1 : 0;
+    } else {
+        JSTSP_TRY(launch_eig(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau, w.Q,
+                             nullptr, w.Vg));
+    }
     const Mat Zm{Z, sZ, w.rows}, Qm{w.Q, sG, w.n};
     if (w.left)     // Y = Z - Q Z
         return gemm(ctx, 'N', 'N', w.rows, w.cols, w.n, w.batch, Qm, Zm, Y, sZ, w.rows, -1.f, Z, sZ, w.rows,
@@ -193,8 +203,7 @@ int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam)
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
     JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
-    return launch_eig(ctx, EIG_LMAX, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, nullptr, nullptr,
-                      nullptr, lam, nullptr);
+    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam);
 }
 
 int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes)

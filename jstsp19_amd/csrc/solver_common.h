@@ -23,6 +23,8 @@ struct GramWS {
     float2 *Gpart = nullptr;   // batch * nsplit * n*n
     float2 *Q = nullptr;       // batch * n*n
     float2 *Vg = nullptr;      // eigenvectors in HBM when they do not fit in LDS
+    float2 *Uwarm = nullptr;   // n <= 64: eigenvector basis of the previous call (warm start)
+    mutable int warm = 0;      // 1 once Uwarm holds a basis
     static size_t bytes(int rows, int cols, int batch, bool need_q);
     int alloc(Arena &a, int rows, int cols, int batch, bool need_q);
 };
@@ -30,8 +32,10 @@ struct GramWS {
 // G partials of Z (split-K over the long dimension).
 int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt);
 // Y = svt(Z, tau_t): tau from prm[t].tauY_rho, or tau[t] when tau != nullptr.  Y may alias nothing.
+// `sequence` = true: successive calls see slowly varying inputs (an ADMM loop), so the
+// eigenvector basis of the previous call warm-starts the Jacobi sweeps.
 int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm,
-                const float *tau, float2 *Y);
+                const float *tau, float2 *Y, bool sequence = false);
 // lam[t] = sigma_max(Z_t)^2
 int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam);
 

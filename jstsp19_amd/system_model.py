@@ -1,0 +1,170 @@
+"""Batched, device-resident construction of the solver inputs (the caller side of the hot path).
+
+What plot_errorVSsnr.m:57-136 does per trial on the host — channel, pilots, noise, the
+random-spatial-sampling measurement, the dictionary factors A, B and the hyper-parameters —
+done here for a whole batch of Monte-Carlo trials with torch tensor ops on the GPU, so that
+the solver's inputs are born in HBM.  Not the timed hot path; torch is
+used as plumbing.  Every function cites the reference lines it follows (paths relative to
+/root/reference) and reproduces their quirks (tap-1 steering reuse, cumulative cluster sum,
+Hermitian Toeplitz pilots, sigma_6 in rho).
+
+Random numbers come from a counter-style scheme keyed by (seed, sweep index, global trial
+index), so a trial's inputs do not depend on how trials are sharded over GPUs.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+__all__ = ["SweepParams", "draw_trials", "build_inputs", "zc_beamformer", "dft_dictionary"]
+
+
+class SweepParams:
+    """Parameters of one sweep point — names follow plot_errorVSsnr.m:8-25."""
+
+    def __init__(self, Nt, Nr, L, T, Mr, Mr_e=None, Gr=None, Gt=None, clusters=2, rays=3, snr_db=5.0):
+        self.Nt, self.Nr, self.L, self.T, self.Mr = Nt, Nr, L, T, Mr
+        self.Mr_e = Nr if Mr_e is None else Mr_e
+        self.Gr = Nr if Gr is None else Gr
+        self.Gt = Nt if Gt is None else Gt
+        self.clusters, self.rays = clusters, rays
+        self.snr_db = float(snr_db)
+
+    @property
+    def T_prop(self):                       # plot_errorVSsnr.m:23
+        return self.T * self.Nt
+
+    @property
+    def noise_var(self):                    # :49
+        return 10.0 ** (-self.snr_db / 10.0)
+
+    @property
+    def solver_shape(self):
+        """(N, M, Gr, G2) of the proposed_algorithm call."""
+        return self.Mr_e, self.T_prop, self.Gr, self.L * self.Gt
+
+
+def _trial_seed(seed, sweep_idx, trial_idx):
+    # splitmix-style mixing of (seed, sweep, trial) into one 63-bit generator seed
+    x = (seed * 0x9E3779B97F4A7C15 + sweep_idx * 0xBF58476D1CE4E5B9 + trial_idx * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    x ^= x >> 31
+    return x & (2 ** 63 - 1)
+
+
+def draw_trials(p: SweepParams, trial_ids, seed=20190913, sweep_idx=0, device="cuda"):
+    """Draw the random numbers of the given global trial indices (one generator per trial).
+
+    Returns a dict of batched tensors: gains (T,L,Np) complex128, u_r/u_t (T,L,Np) float64,
+    noise (T,Nr,T_prop) complex128 (unit-variance real and imaginary parts),
+    qam_idx (T,Nt,T_prop) int64 in 0..3, omega_rows (T,T_prop,Mr) int64.
+    """
+    Np = p.clusters * p.rays
+    out = {k: [] for k in ("gains", "u_r", "u_t", "noise", "qam_idx", "omega_rows")}
+    g = torch.Generator(device=device)
+    for tid in trial_ids:
+        g.manual_seed(_trial_seed(seed, sweep_idx, int(tid)))
+        gr = torch.randn((2, p.L, Np), generator=g, device=device, dtype=torch.float64)
+        out["gains"].append(torch.complex(gr[0], gr[1]) / math.sqrt(2.0))        # wideband_mmwave_channel.m:19
+        out["u_r"].append(torch.rand((p.L, Np), generator=g, device=device, dtype=torch.float64))   # :20
+        out["u_t"].append(torch.rand((p.L, Np), generator=g, device=device, dtype=torch.float64))   # :22
+        nz = torch.randn((2, p.Nr, p.T_prop), generator=g, device=device, dtype=torch.float64)
+        out["noise"].append(torch.complex(nz[0], nz[1]))                         # plot_errorVSsnr.m:60
+        out["qam_idx"].append(torch.randint(0, 4, (p.Nt, p.T_prop), generator=g, device=device))    # qam4mod.m:8
+        # proposed_hbf.m:37-40: randperm(Lr_e)(1:Lr) per column = the Lr smallest of Lr_e uniforms
+        keys = torch.rand((p.T_prop, p.Mr_e), generator=g, device=device)
+        out["omega_rows"].append(keys.argsort(dim=1)[:, :p.Mr])
+    return {k: torch.stack(v) for k, v in out.items()}
+
+
+def dft_dictionary(Mn, G, device, dtype=torch.complex128):
+    """wideband_mmwave_channel.m:9-10 — 1/sqrt(M) exp(-j (0:M-1)' 2 pi (0:G-1)/G)."""
+    n = torch.arange(Mn, device=device, dtype=torch.float64)[:, None]
+    gg = torch.arange(G, device=device, dtype=torch.float64)[None, :]
+    ph = -2.0 * math.pi * n * gg / G
+    return (torch.complex(torch.cos(ph), torch.sin(ph)) / math.sqrt(Mn)).to(dtype)
+
+
+def zc_beamformer(N, device, dtype=torch.complex128):
+    """createBeamformer.m:15-16 ('ZC') — 1/sqrt(N) exp(-j 11 (0:N-1)' pi (1:N)/N)."""
+    n = torch.arange(N, device=device, dtype=torch.float64)[:, None]
+    m = torch.arange(1, N + 1, device=device, dtype=torch.float64)[None, :]
+    ph = -11.0 * n * math.pi * m / N
+    return (torch.complex(torch.cos(ph), torch.sin(ph)) / math.sqrt(N)).to(dtype)
+
+
+def _steer(phi, Mn):
+    """wideband_mmwave_channel.m:42-52 — exp(-j pi sin(0 - phi) (0:M-1)'), un-normalised."""
+    n = torch.arange(Mn, device=phi.device, dtype=torch.float64)
+    ph = -math.pi * torch.sin(-phi)[..., None] * n           # (..., Mn)
+    return torch.complex(torch.cos(ph), torch.sin(ph))
+
+
+def _laplacian(u):
+    """wideband_mmwave_channel.m:56-62."""
+    beta = 1.0 / (1.0 - math.exp(-math.sqrt(2.0) * math.pi / 50.0))
+    return beta * (math.exp(-math.sqrt(2.0) / 50.0 * math.pi) - torch.cosh(u))
+
+
+def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64):
+    """plot_errorVSsnr.m:57-136 for a batch of trials.
+
+    Returns a dict of device tensors, matrices column-major per problem as the C ABI wants:
+      subY (T,N,M), Omega (T,N,M) float32, A (N,Gr) [shared: ZC x DFT is trial-independent],
+      B (T,G2,M), Zbar (T,Gr,G2) complex128, H (T,Nr,Nt,L) complex128,
+      tau_Y, tau_Z, rho (T,) float64 on the host side of the C ABI (returned as CPU tensors),
+      indx_S (T, Gr*G2) int32 1-based (plot_errorVSsnr.m:143).
+    """
+    from .solvers import colmajor
+    dev = draws["gains"].device
+    T = draws["gains"].shape[0]
+    Np = p.clusters * p.rays
+    c128 = torch.complex128
+    Dr = dft_dictionary(p.Nr, p.Gr, dev)
+    Dt = dft_dictionary(p.Nt, p.Gt, dev)
+    # --- channel: taps reuse tap 1's steering vectors (:24), cluster c's rays weighted (C - c) (:29)
+    Ar1 = _steer(_laplacian(draws["u_r"][:, 0, :]), p.Nr).transpose(1, 2)      # (T, Nr, Np)
+    At1 = _steer(_laplacian(draws["u_t"][:, 0, :]), p.Nt).transpose(1, 2)      # (T, Nt, Np)
+    w = (p.clusters - torch.arange(Np, device=dev) // p.rays).to(torch.float64)   # (Np,)
+    coef = draws["gains"] * w / math.sqrt(Np)                                   # (T, L, Np)   :33
+    # H[t,:,:,l] = Ar1 diag(coef[t,l]) At1^H
+    H = torch.einsum("trp,tlp,tsp->trsl", Ar1, coef.to(c128), At1.conj())       # (T, Nr, Nt, L)
+    Z = torch.einsum("rg,trsl,sh->tghl", Dr.conj(), H, Dt)                      # Dr' H_l Dt   :35
+    Zbar = Z.permute(0, 1, 3, 2).reshape(T, p.Gr, p.L * p.Gt)                   # [Z_1 ... Z_L] :38  (col = l*Gt + h)
+    # --- pilots: Psi_bar(k,:,l) = row l of toeplitz(s_k) (proposed_hbf.m:17), Hermitian Toeplitz
+    s = 1.0 / math.sqrt(2.0)
+    alphabet = torch.tensor([complex(s, s), complex(-s, s), complex(s, -s), complex(-s, -s)], device=dev, dtype=c128)
+    sym = alphabet[draws["qam_idx"]]                                            # (T, Nt, T_prop)
+    Tp = p.T_prop
+    j = torch.arange(Tp, device=dev)
+    rows = []
+    for l in range(p.L):
+        d = j - l
+        r = sym[:, :, d.abs()]
+        rows.append(torch.where((d >= 0)[None, None, :], r, r.conj()))
+    Psi_bar = torch.stack(rows, dim=-1)                                         # (T, Nt, T_prop, L)
+    # --- received signal, sampling mask, measurement (proposed_hbf.m:13-42)
+    Y = torch.einsum("trsl,tsjl->trj", H, Psi_bar)                              # sum_l H_l Psi_bar_l   :19
+    R = Y + math.sqrt(p.noise_var / 2.0) * draws["noise"]                       # :22, plot_errorVSsnr.m:60
+    W_e = zc_beamformer(p.Nr, dev)[:, :p.Mr_e]                                  # :11, plot_errorVSsnr.m:124
+    Omega = torch.zeros((T, p.Mr_e, Tp), device=dev, dtype=torch.float64)
+    Omega.scatter_(1, draws["omega_rows"].transpose(1, 2), 1.0)                 # :36-41
+    subY = Omega * torch.einsum("re,trj->tej", W_e.conj(), R)                   # :42
+    # --- hyper-parameters (plot_errorVSsnr.m:127-130): eigs() returns the 6 largest => sigma_6^2
+    fro2 = (subY.abs() ** 2).sum(dim=(1, 2))
+    tau_Y = 1.0 / fro2
+    tau_Z = 0.5 / (Zbar.abs() ** 2).sum(dim=(1, 2))
+    sv = torch.linalg.svdvals(subY)
+    rho = torch.sqrt(sv[:, 5] ** 2 / fro2)
+    # --- dictionary factors (:132-136)
+    A = W_e.conj().transpose(0, 1) @ Dr                                         # Mr_e x Gr
+    B = torch.einsum("sh,tsjl->tlhj", Dt.conj(), Psi_bar).reshape(T, p.L * p.Gt, Tp)   # rows l*Gt + h
+    absz = Zbar.transpose(1, 2).reshape(T, -1).abs()                            # vec order (column-major)
+    indx_S = (torch.argsort(absz, dim=1, descending=True, stable=True) + 1).to(torch.int32)
+    return dict(subY=colmajor(subY.to(out_dtype)), Omega=colmajor(Omega.to(torch.float32)),
+                A=colmajor(A.to(out_dtype)), B=colmajor(B.to(out_dtype)), Zbar=Zbar, H=H,
+                tau_Y=tau_Y.cpu(), tau_Z=tau_Z.cpu(), rho=rho.cpu(), indx_S=indx_S)

@@ -1,0 +1,55 @@
+"""Product-side batched input builder (torch) vs the oracle's per-trial literal restatement of
+plot_errorVSsnr.m:57-136, on the same random draws.  Runs on CPU."""
+import numpy as np
+import torch
+
+from jstsp19_amd.system_model import SweepParams, build_inputs, draw_trials
+from oracle import system_model as osm
+
+
+def _to_np(draws, t):
+    return dict(gains=draws["gains"][t].numpy(), u_r=draws["u_r"][t].numpy(), u_t=draws["u_t"][t].numpy(),
+                noise=draws["noise"][t].numpy(), qam_idx=draws["qam_idx"][t].numpy(),
+                omega_rows=draws["omega_rows"][t].numpy())
+
+
+def test_build_inputs_matches_oracle_per_trial():
+    p = SweepParams(Nt=4, Nr=16, L=3, T=6, Mr=4, snr_db=5.0)
+    draws = draw_trials(p, [0, 1, 7], seed=123, device="cpu")
+    out = build_inputs(p, draws, out_dtype=torch.complex128)
+    op = dict(Nt=p.Nt, Nr=p.Nr, Mr_e=p.Mr_e, Gr=p.Gr, Gt=p.Gt, clusters=p.clusters, rays=p.rays, L=p.L,
+              Mr=p.Mr, T=p.T, noise_var=p.noise_var)
+    for t in range(3):
+        ref = osm.training_inputs_errorVSsnr(op, _to_np(draws, t))
+        np.testing.assert_allclose(out["H"][t].numpy(), ref["H"], atol=1e-12)
+        np.testing.assert_allclose(out["Zbar"][t].numpy(), ref["Zbar"], atol=1e-12)
+        np.testing.assert_allclose(out["subY"][t].numpy(), ref["subY"], atol=1e-11)
+        np.testing.assert_array_equal(out["Omega"][t].numpy(), ref["Omega"])
+        np.testing.assert_allclose(out["A"].numpy(), ref["A"], atol=1e-12)
+        np.testing.assert_allclose(out["B"][t].numpy(), ref["B"], atol=1e-12)
+        np.testing.assert_allclose(float(out["tau_Y"][t]), ref["tau_Y"], rtol=1e-12)
+        np.testing.assert_allclose(float(out["tau_Z"][t]), ref["tau_Z"], rtol=1e-12)
+        np.testing.assert_allclose(float(out["rho"][t]), ref["rho"], rtol=1e-10)
+        np.testing.assert_array_equal(out["indx_S"][t].numpy(), ref["indx_S"])
+        assert int(out["Omega"][t].sum(dim=0).min()) == p.Mr == int(out["Omega"][t].sum(dim=0).max())
+
+
+def test_draws_do_not_depend_on_batch_composition():
+    """A trial's numbers are keyed by (seed, sweep, trial id): sharding trials over GPUs cannot
+    change them."""
+    p = SweepParams(Nt=2, Nr=8, L=2, T=4, Mr=2)
+    a = draw_trials(p, [0, 1, 2, 3], seed=5, device="cpu")
+    b = draw_trials(p, [2, 3], seed=5, device="cpu")
+    for k in a:
+        assert torch.equal(a[k][2:], b[k])
+    c = draw_trials(p, [2, 3], seed=5, sweep_idx=1, device="cpu")
+    assert not torch.equal(c["gains"], b["gains"])
+
+
+def test_colmajor_layout_of_outputs():
+    p = SweepParams(Nt=2, Nr=8, L=2, T=4, Mr=2)
+    out = build_inputs(p, draw_trials(p, [0, 1], device="cpu"))
+    N, M, Gr, G2 = p.solver_shape
+    assert out["subY"].shape == (2, N, M) and out["subY"].stride() == (N * M, 1, N)
+    assert out["B"].shape == (2, G2, M) and out["B"].stride() == (G2 * M, 1, G2)
+    assert out["A"].shape == (N, Gr) and out["A"].stride() == (1, N)
