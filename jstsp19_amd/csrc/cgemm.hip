@@ -21,6 +21,7 @@
 // order), so problem t = 8*q + (b % 8) keeps all tiles of one Monte-Carlo trial — which
 // share the a-panel (K or A*S) — on one XCD's L2.
 #include "common.h"
+#include <cstdlib>
 
 namespace jstsp {
 
@@ -31,7 +32,14 @@ constexpr int BK = 16;
 
 // TAG only gives the hot call sites their own kernel symbol (identical code), so that
 // rocprofv3's per-kernel statistics and the roofline in bench.py refer to one shape each.
-template <int BN, int TAG>
+//
+// M64 (long contractions): the fp32 MFMA accumulates as one k-ordered fmaf chain, whose
+// rounding error grows ~ eps*k.  Over the 4096-term correlation that noise, re-injected
+// every ADMM iteration through res = K2'k - R v (a difference of two nearly equal terms),
+// is what limits NMSE parity with the float64 reference.  With M64 the fp32 accumulators
+// are flushed into fp64 master accumulators every 32 k (two panels) and restarted, so the
+// chain length is 32 and the long sum is carried in double — on the VALU, next to the MFMAs.
+template <int BN, int TAG, bool M64>
 __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int tiles_n)
 {
     constexpr int LDA = BM + 1;
@@ -118,10 +126,14 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     };
 
     f32x16 acc_re[NB], acc_im[NB];
+    double m_re[M64 ? NB : 1][16], m_im[M64 ? NB : 1][16];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc_re[nb][r] = 0.f; acc_im[nb][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) {
+            acc_re[nb][r] = 0.f; acc_im[nb][r] = 0.f;
+            if (M64) { m_re[nb][r] = 0.0; m_im[nb][r] = 0.0; }
+        }
 
     const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     if (nk > 0) {
@@ -150,6 +162,16 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                 acc_im[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.x, acc_im[nb], 0, 0, 0);
             }
         }
+        if (M64 && ((kt & 1) == 1 || kt + 1 == nk)) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    m_re[nb][r] += (double)acc_re[nb][r];
+                    m_im[nb][r] += (double)acc_im[nb][r];
+                    acc_re[nb][r] = 0.f; acc_im[nb][r] = 0.f;
+                }
+        }
         if (kt + 1 < nk) sstore(buf ^ 1);
         __syncthreads();
     }
@@ -165,7 +187,9 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
             for (int r = 0; r < 16; ++r) {
                 const int gj = n0 + wj * (BN / 2) + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (gj < d.n) {
-                    float2 o = make_float2(d.alpha * acc_re[nb][r], d.alpha * acc_im[nb][r]);
+                    const float vr = M64 ? (float)m_re[nb][r] : acc_re[nb][r];
+                    const float vi = M64 ? (float)m_im[nb][r] : acc_im[nb][r];
+                    float2 o = make_float2(d.alpha * vr, d.alpha * vi);
                     if (Dp) {
                         const float2 dv = Dp[gi + (long long)gj * d.ldd];
                         o.x += d.beta * dv.x;
@@ -179,14 +203,17 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 }
 
 template <int TAG>
-static void launch_tagged(jstsp_ctx *ctx, const GemmDesc &d, bool wide, long long grid, int tiles_m,
+static void launch_tagged(jstsp_ctx *ctx, const GemmDesc &d, int variant, long long grid, int tiles_m,
                           int tiles_n)
 {
-    if (wide)
-        hipLaunchKernelGGL((cgemm_kernel<128, TAG>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
+    if (variant == 2)
+        hipLaunchKernelGGL((cgemm_kernel<64, TAG, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
+                           tiles_m, tiles_n);
+    else if (variant == 1)
+        hipLaunchKernelGGL((cgemm_kernel<128, TAG, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
                            tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((cgemm_kernel<64, TAG>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
+        hipLaunchKernelGGL((cgemm_kernel<64, TAG, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
                            tiles_m, tiles_n);
 }
 
@@ -196,8 +223,11 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
 {
     if (d.m <= 0 || d.n <= 0 || d.batch <= 0) return 0;
     const int tiles_m = (d.m + BM - 1) / BM;
-    const bool wide = d.n > 64;
-    const int bn = wide ? 128 : 64;
+    // variant 2: 64-wide tile with fp64 master accumulators for long contractions (k per split >= 256)
+    static const int long_k = getenv("JSTSP_M64_MINK") ? atoi(getenv("JSTSP_M64_MINK")) : 256;
+    const int kper = (d.k + d.splitk - 1) / d.splitk;
+    const int variant = (kper >= long_k) ? 2 : (d.n > 64 ? 1 : 0);
+    const int bn = variant == 1 ? 128 : 64;
     const int tiles_n = (d.n + bn - 1) / bn;
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_m * tiles_n * d.splitk;
@@ -205,10 +235,10 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     const char *prof_name = (tag != GEMM_MISC) ? kTagNames[tag] : nullptr;
     if (prof_name) prof_begin(ctx, prof_name);
     switch (tag) {
-    case GEMM_CORRELATE: launch_tagged<GEMM_CORRELATE>(ctx, d, wide, grid, tiles_m, tiles_n); break;
-    case GEMM_SYNTH: launch_tagged<GEMM_SYNTH>(ctx, d, wide, grid, tiles_m, tiles_n); break;
-    case GEMM_GRAM: launch_tagged<GEMM_GRAM>(ctx, d, wide, grid, tiles_m, tiles_n); break;
-    default: launch_tagged<GEMM_MISC>(ctx, d, wide, grid, tiles_m, tiles_n); break;
+    case GEMM_CORRELATE: launch_tagged<GEMM_CORRELATE>(ctx, d, variant, grid, tiles_m, tiles_n); break;
+    case GEMM_SYNTH: launch_tagged<GEMM_SYNTH>(ctx, d, variant, grid, tiles_m, tiles_n); break;
+    case GEMM_GRAM: launch_tagged<GEMM_GRAM>(ctx, d, variant, grid, tiles_m, tiles_n); break;
+    default: launch_tagged<GEMM_MISC>(ctx, d, variant, grid, tiles_m, tiles_n); break;
     }
     if (prof_name) prof_end(ctx, prof_name);
     JSTSP_HIP(hipGetLastError());

@@ -177,7 +177,13 @@ def rho_from_eigs(Y, which="min6"):
     plot_errorVSdelays.m:128)."""
     s = np.linalg.svd(Y, compute_uv=False)
     fro2 = np.linalg.norm(Y, "fro") ** 2
-    lam = s[5] ** 2 if which == "min6" else s[0] ** 2
+    if which == "min6":
+        # eigenvalues of the M x M matrix Y'*Y: the squared singular values padded with zeros
+        M = Y.shape[1]
+        ev = np.concatenate([s ** 2, np.zeros(max(0, M - s.size))])
+        lam = ev[min(5, M - 1)]
+    else:
+        lam = s[0] ** 2
     return float(np.sqrt(lam * (1 / fro2)))
 
 

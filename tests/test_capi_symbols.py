@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports every symbol include/jstsp.h declares (no compute:
+there is no GPU in the CPU test tier), the ctypes table mirrors the header, and the product
+fails loudly — never silently falls back — without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import jstsp19_amd
+from jstsp19_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "jstsp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(jstsp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    names = _declared()
+    assert "jstsp_proposed_algorithm_c32" in names and "jstsp_correlate_c32" in names and len(names) >= 18
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -m jstsp19_amd.build"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, "jstsp19_amd/_lib.py SIGNATURES out of sync with include/jstsp.h"
+
+
+def test_version_and_error_string_without_gpu():
+    lib = jstsp19_amd.load()
+    assert b"gfx950" in lib.jstsp_version()
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(jstsp19_amd.JstspError):
+        jstsp19_amd.Context(0)
+    import numpy as np
+    with pytest.raises(jstsp19_amd.JstspError):
+        jstsp19_amd.svt(np.eye(3, dtype=complex), 0.1)
+
+
+def test_product_does_not_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under jstsp19_amd/ may import it."""
+    pkg = os.path.join(ROOT, "jstsp19_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
