@@ -111,7 +111,8 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag = GEMM_MISC);
 // mode EIG_SVT_Q : Q[t] = U diag(min(1, tau_t/sigma_i)) U^H with sigma = sqrt(lambda)
 //                  (so that svt(Z, tau) = Z - Q Z);  tau_t = prm[t].tauY_rho or tau[t]
 // mode EIG_LMAX  : lam_out[t] = largest eigenvalue
-enum { EIG_SVT_Q = 0, EIG_LMAX = 1 };
+// mode EIG_VECS  : Q[t] = eigenvectors (columns), lam_out[t*n + i] = eigenvalues (unsorted)
+enum { EIG_SVT_Q = 0, EIG_LMAX = 1, EIG_VECS = 2 };
 int launch_eig(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt,
                int nsplit, long long sGs, const TrialParams *prm, const float *tau,
                float2 *Q, float *lam_out, float2 *Vg);

@@ -186,6 +186,16 @@ __global__ __launch_bounds__(256) void jacobi_kernel(int mode, int n, int batch,
         if (tid == 0) lam_out[t] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         return;
     }
+    if (WITH_V && mode == EIG_VECS) {
+        // eigenvectors (columns) -> Q, eigenvalues -> lam_out[t*n + i]
+        float2 *Qt = Q + (size_t)t * n * n;
+        for (int e = tid; e < n * n; e += 256) {
+            const int r = e % n, c = e / n;
+            Qt[e] = V_IN_LDS ? V[r + ld * c] : Vg[r + (size_t)ne * c];
+        }
+        for (int i = tid; i < n; i += 256) lam_out[(size_t)t * n + i] = G[i + ld * i].x;
+        return;
+    }
     if (WITH_V) {
         // q_i = min(1, tau / sigma_i), sigma_i = sqrt(max(lambda_i, 0)); store in rot[]
         const float tv = tau ? tau[t] : prm[t].tauY_rho;

@@ -101,11 +101,13 @@ int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat
 {
     GemmDesc d;
     d.A = A.p; d.sAt = A.st;
-    if (opA == 'N') { d.sAi = 1; d.sAk = A.ld; d.conjA = 0; }       // a(i,kk) = A[i + ld*kk]
-    else            { d.sAi = A.ld; d.sAk = 1; d.conjA = 1; }       // a(i,kk) = conj(A[kk + ld*i])
+    // op: 'N' as stored, 'T' transpose, 'C' conjugate transpose, 'J' conjugate (no transpose)
+    const bool tA = (opA == 'T' || opA == 'C'), tB = (opB == 'T' || opB == 'C');
+    d.conjA = (opA == 'C' || opA == 'J');
+    d.conjB = (opB == 'C' || opB == 'J');
+    if (!tA) { d.sAi = 1; d.sAk = A.ld; } else { d.sAi = A.ld; d.sAk = 1; }   // a(i,kk) = A[i + ld*kk] | A[kk + ld*i]
     d.B = B.p; d.sBt = B.st;
-    if (opB == 'N') { d.sBk = 1; d.sBj = B.ld; d.conjB = 0; }       // b(kk,j) = B[kk + ld*j]
-    else            { d.sBk = B.ld; d.sBj = 1; d.conjB = 1; }       // b(kk,j) = conj(B[j + ld*kk])
+    if (!tB) { d.sBk = 1; d.sBj = B.ld; } else { d.sBk = B.ld; d.sBj = 1; }   // b(kk,j) = B[kk + ld*j] | B[j + ld*kk]
     d.C = C; d.sCt = sCt; d.ldc = ldc;
     d.D = D; d.sDt = sDt; d.ldd = ldd;
     d.alpha = alpha; d.beta = beta;

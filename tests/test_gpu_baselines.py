@@ -1,0 +1,113 @@
+"""HIP path vs golden / oracle for the benchmark solvers: OMP (dense and Kronecker dictionary)
+and sparse_admm.  Index selections must be bit-exact (integer work); coefficients to fp32."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_omp_dft_known_answer_exact_support():
+    import jstsp19_amd as J
+    g = load_golden("omp")
+    x, idx, v, T = J.OMP(g["A0"], g["v0"], int(g["m0"]), None)
+    assert np.array_equal(idx, g["idx0"])
+    assert rel_err(x, g["xtrue0"]) < 1e-5
+    assert rel_err(T, g["T0"]) < 1e-6
+
+
+def test_omp_random_dictionary_matches_golden():
+    import jstsp19_amd as J
+    g = load_golden("omp")
+    x, idx, _, T = J.OMP(g["A1"], g["v1"], int(g["m1"]))
+    assert np.array_equal(idx, g["idx1"])
+    assert rel_err(x, g["x1"]) < 1e-4
+    assert rel_err(T, g["T1"]) < 1e-6
+
+
+def test_omp_kron_matches_dense_literal():
+    import jstsp19_amd as J
+    g = load_golden("omp")
+    x, idx = J.omp_kron(g["Af2"], g["Bf2"], g["y2"], int(g["m2"]))
+    assert np.array_equal(idx, g["idx2"])
+    assert rel_err(x, g["x2"]) < 1e-4
+    # the same problem through the dense entry point with the materialised dictionary
+    Phi = np.kron(g["Bf2"].T, g["Af2"])
+    xd, idxd, _, _ = J.OMP(Phi, g["y2"], int(g["m2"]))
+    assert np.array_equal(idxd, g["idx2"]) and rel_err(xd, g["x2"]) < 1e-4
+
+
+def test_omp_reselected_atom_and_batch():
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    A = np.eye(3, dtype=complex)
+    x, idx, _, _ = J.OMP(A, np.array([2.0, 0, 0], dtype=complex), 2)
+    assert list(idx) == [1, 1] and np.allclose(x, [1.0, 0, 0])          # pinv splits 2 -> 1 + 1 (OMP.m:19,29-32)
+    rng = np.random.default_rng(21)
+    meas, size_d, m, batch = 40, 90, 6, 5
+    Ash = (rng.standard_normal((meas, size_d)) + 1j * rng.standard_normal((meas, size_d))) / np.sqrt(meas)
+    Apt = (rng.standard_normal((batch, meas, size_d)) + 1j * rng.standard_normal((batch, meas, size_d))) / np.sqrt(meas)
+    V = rng.standard_normal((batch, meas)) + 1j * rng.standard_normal((batch, meas))
+    xs, idxs, _, Ts = J.OMP(Ash, V, m)
+    xp, idxp, _, Tp = J.OMP(Apt, V, m)
+    for t in range(batch):
+        xo, io, _, To = O.omp_literal(Ash, V[t], m)
+        assert np.array_equal(idxs[t], io) and rel_err(xs[t], xo) < 1e-4 and rel_err(Ts[t], To) < 1e-6
+        xo, io, _, To = O.omp_literal(Apt[t], V[t], m)
+        assert np.array_equal(idxp[t], io) and rel_err(xp[t], xo) < 1e-4
+
+
+def test_omp_config1_kron_dictionary_1024():
+    """BASELINE configs[0]: Nt=Nr=16, Nrf=4, K=16, L=4 — Phi = kron(B.', A) is 1024 x 1024,
+    OMP(Phi, y, m=24); the HIP path never forms Phi."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    from oracle import system_model as sm
+    rng = np.random.default_rng(16)
+    Nr = Nt = 16; L = 4; T_hbf = 64
+    p = dict(Nt=Nt, Nr=Nr, Mr_e=Nr, Gr=Nr, Gt=Nt, clusters=2, rays=3, L=L, Mr=4, T=4, noise_var=10 ** -1.5)
+    d = sm.draw_trial(rng, p)
+    H, Zbar, _, _, Dr, Dt = sm.wideband_mmwave_channel(L, Nr, Nt, 2, 3, Nr, Nt, d["gains"], d["u_r"], d["u_t"])
+    Psi_rows = np.stack([sm.toeplitz_rows(sm.qam4_alphabet()[d["qam_idx"][k]], L) for k in range(Nt)], axis=2)
+    Nn = np.sqrt(p["noise_var"] / 2) * d["noise"]
+    Yc, Wc, Psi_bar, _ = sm.hbf(H, Nn[:, :T_hbf], Psi_rows[:, :T_hbf, :], T_hbf, Nr, sm.create_beamformer(Nr, "ZC"))
+    A = Wc.conj().T @ Dr                                                     # plot_errorVSsnr.m:74
+    B = np.concatenate([Dt.conj().T @ Psi_bar[:, :, l] for l in range(L)])   # :75-78, 64 x 64
+    y = O.vec(Yc)
+    xo, io, _, _ = O.omp_kron(A, B, y, 24)
+    x, idx = J.omp_kron(A, B, y, 24)
+    assert np.array_equal(idx, io)
+    assert rel_err(x, xo) < 2e-4
+
+
+def test_sparse_admm_matches_golden():
+    import jstsp19_amd as J
+    g = load_golden("sparse_admm")
+    S, ce = J.sparse_admm(g["Htrue"], g["OH"], g["Dr"], g["Dt"], int(g["Imax"]))
+    assert rel_err(S, g["S"]) < 1e-4
+    np.testing.assert_allclose(ce, g["ce"], rtol=2e-3)
+    S2, ce2 = J.sparse_admm(g["Htrue"], g["OH"], g["Dr2"], g["Dt2"], int(g["Imax"]))
+    assert rel_err(S2, g["S2"]) < 5e-4
+    np.testing.assert_allclose(ce2, g["ce2"], rtol=5e-3)
+
+
+def test_sparse_admm_config3_shape_batched():
+    """BASELINE configs[2] shape (128 x 128, unitary DFT dictionaries) on a small batch."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(33)
+    n, batch = 128, 3
+    D = np.exp(-2j * np.pi * np.outer(np.arange(n), np.arange(n)) / n) / np.sqrt(n)
+    Sp = np.zeros((batch, n, n), complex)
+    for t in range(batch):
+        Sp[t, rng.integers(0, n, 12), rng.integers(0, n, 12)] = rng.standard_normal(12) + 1j * rng.standard_normal(12)
+    H = D @ Sp @ D.conj().T
+    OH = H + 0.02 * (rng.standard_normal(H.shape) + 1j * rng.standard_normal(H.shape))
+    S, ce = J.sparse_admm(H, OH, D, D, 30)
+    for t in range(batch):
+        So, ceo = O.sparse_admm(H[t], OH[t], D, D, 30)
+        assert rel_err(S[t], So) < 2e-4
+        np.testing.assert_allclose(ce[t], ceo, rtol=5e-3)
+    with pytest.raises(J.JstspError):
+        J.sparse_admm(H[0], OH[0], D[:, :64], D, 5)          # Gr != Mr is rejected (sparse_admm.m:16,21)
