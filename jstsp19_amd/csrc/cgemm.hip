@@ -80,30 +80,54 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     const float sgnA = d.conjA ? -1.f : 1.f;
     const float sgnB = d.conjB ? -1.f : 1.f;
 
+    // Per-thread panel coordinates are fixed for the whole k loop: element pointers advance by
+    // one panel per step (no 64-bit index arithmetic inside the loop), rows/columns outside the
+    // matrix are redirected to element 0 and zeroed by a select, so every load is unconditional
+    // (a predicated load makes hipcc branch around it and serialises the panel fetch).
     float2 ra[NLA], rb[NLB];
+    const float2 *pa[NLA], *pb[NLB];
+    int la[NLA], lb[NLB], ka[NLA], kb[NLB];
+    bool va[NLA], vb[NLB];
+#pragma unroll
+    for (int p = 0; p < NLA; ++p) {
+        const int e = tid + 256 * p;
+        const int i = a_icont ? (e % BM) : (e / BK);
+        ka[p] = a_icont ? (e / BM) : (e % BK);
+        const int gi = m0 + i;
+        va[p] = gi < d.m;
+        pa[p] = Ap + (long long)(va[p] ? gi : 0) * d.sAi + (long long)(kbeg + ka[p]) * d.sAk;
+        la[p] = ka[p] * LDA + i;
+    }
+#pragma unroll
+    for (int p = 0; p < NLB; ++p) {
+        const int e = tid + 256 * p;
+        const int j = b_jcont ? (e % BN) : (e / BK);
+        kb[p] = b_jcont ? (e / BN) : (e % BK);
+        const int gj = n0 + j;
+        vb[p] = gj < d.n;
+        pb[p] = Bp + (long long)(kbeg + kb[p]) * d.sBk + (long long)(vb[p] ? gj : 0) * d.sBj;
+        lb[p] = kb[p] * LDB + j;
+    }
+    const long long stepA = (long long)BK * d.sAk, stepB = (long long)BK * d.sBk;
 
+    // gload only ISSUES the loads (raw values stay in registers across the MFMA loop); the
+    // zero-select / conjugation happen in sstore, after the MFMAs, so that hipcc places the
+    // vmcnt wait there and the HBM latency is covered by the matrix pipe.
+    bool tail = false;
+    int tail_k0 = 0;
     auto gload = [&](int k0) {
+        tail = (k0 + BK > kend);
+        tail_k0 = k0;
+        if (!tail) {                    // full panel (wave-uniform branch)
 #pragma unroll
-        for (int p = 0; p < NLA; ++p) {
-            const int e = tid + 256 * p;
-            const int i = a_icont ? (e % BM) : (e / BK);
-            const int kk = a_icont ? (e / BM) : (e % BK);
-            const int gi = m0 + i, gk = k0 + kk;
-            float2 v = make_float2(0.f, 0.f);
-            if (gi < d.m && gk < kend) v = Ap[(long long)gi * d.sAi + (long long)gk * d.sAk];
-            v.y *= sgnA;
-            ra[p] = v;
-        }
+            for (int p = 0; p < NLA; ++p) { ra[p] = *pa[p]; pa[p] += stepA; }
 #pragma unroll
-        for (int p = 0; p < NLB; ++p) {
-            const int e = tid + 256 * p;
-            const int j = b_jcont ? (e % BN) : (e / BK);
-            const int kk = b_jcont ? (e / BN) : (e % BK);
-            const int gj = n0 + j, gk = k0 + kk;
-            float2 v = make_float2(0.f, 0.f);
-            if (gj < d.n && gk < kend) v = Bp[(long long)gk * d.sBk + (long long)gj * d.sBj];
-            v.y *= sgnB;
-            rb[p] = v;
+            for (int p = 0; p < NLB; ++p) { rb[p] = *pb[p]; pb[p] += stepB; }
+        } else {                        // k tail: out-of-range elements read element 0 (zeroed in sstore)
+#pragma unroll
+            for (int p = 0; p < NLA; ++p) ra[p] = *((va[p] && (k0 + ka[p] < kend)) ? pa[p] : Ap);
+#pragma unroll
+            for (int p = 0; p < NLB; ++p) rb[p] = *((vb[p] && (k0 + kb[p] < kend)) ? pb[p] : Bp);
         }
     };
     auto sstore = [&](int buf) {
@@ -111,17 +135,19 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
         float2 *bb = sB + buf * BK * LDB;
 #pragma unroll
         for (int p = 0; p < NLA; ++p) {
-            const int e = tid + 256 * p;
-            const int i = a_icont ? (e % BM) : (e / BK);
-            const int kk = a_icont ? (e / BM) : (e % BK);
-            a[kk * LDA + i] = ra[p];
+            float2 v = ra[p];
+            const bool ok = va[p] && (!tail || (tail_k0 + ka[p] < kend));
+            if (!ok) v = make_float2(0.f, 0.f);
+            v.y *= sgnA;
+            a[la[p]] = v;
         }
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
-            const int e = tid + 256 * p;
-            const int j = b_jcont ? (e % BN) : (e / BK);
-            const int kk = b_jcont ? (e / BN) : (e % BK);
-            bb[kk * LDB + j] = rb[p];
+            float2 v = rb[p];
+            const bool ok = vb[p] && (!tail || (tail_k0 + kb[p] < kend));
+            if (!ok) v = make_float2(0.f, 0.f);
+            v.y *= sgnB;
+            bb[lb[p]] = v;
         }
     };
 
@@ -145,22 +171,46 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     const int l31 = lane & 31, lhi = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
+        const bool refresh = (kt + 1 < nk);
+        if (refresh) gload(kbeg + (kt + 1) * BK);
         const float2 *a = sA + buf * BK * LDA + wi * 32 + l31;
         const float2 *bb = sB + buf * BK * LDB + wj * (BN / 2) + l31;
+        // Fragments of k-pair kp+1 are fetched from LDS before the MFMAs of k-pair kp are issued
+        // (explicit register double buffer + scheduling groups), so a wave's MFMA stream does not
+        // stall on LDS latency: on a SIMD the oldest wave owns the matrix pipe, and whatever it
+        // stalls on is idle pipe time.
+        float2 av = a[lhi * LDA], bv[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) bv[nb] = bb[lhi * LDB + nb * 32];
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
-            const int kr = 2 * kp + lhi;
-            const float2 av = a[kr * LDA];
+            float2 an = av, bn[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bn[nb] = bv[nb];
+            if (kp + 1 < BK / 2) {
+                const int kr = 2 * (kp + 1) + lhi;
+                an = a[kr * LDA];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bn[nb] = bb[kr * LDB + nb * 32];
+            }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const float2 bv = bb[kr * LDB + nb * 32];
                 // (b_re + i b_im)(a_re + i a_im): MFMA A-op = b (rows j), B-op = a (cols i)
-                acc_re[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc_re[nb], 0, 0, 0);
-                acc_re[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(-bv.y, av.y, acc_re[nb], 0, 0, 0);
-                acc_im[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.y, acc_im[nb], 0, 0, 0);
-                acc_im[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.x, acc_im[nb], 0, 0, 0);
+                acc_re[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].x, av.x, acc_re[nb], 0, 0, 0);
+                acc_im[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].x, av.y, acc_im[nb], 0, 0, 0);
             }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                acc_re[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(-bv[nb].y, av.y, acc_re[nb], 0, 0, 0);
+                acc_im[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].y, av.x, acc_im[nb], 0, 0, 0);
+            }
+            if (kp + 1 < BK / 2) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1 + NB, 0);   // DS reads of the next k-pair first
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB, 0);   // then this k-pair's MFMAs
+            }
+            av = an;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bv[nb] = bn[nb];
         }
         if (M64 && ((kt & 1) == 1 || kt + 1 == nk)) {
 #pragma unroll
@@ -172,7 +222,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                     acc_re[nb][r] = 0.f; acc_im[nb][r] = 0.f;
                 }
         }
-        if (kt + 1 < nk) sstore(buf ^ 1);
+        if (refresh) sstore(buf ^ 1);
         __syncthreads();
     }
 

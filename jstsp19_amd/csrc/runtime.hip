@@ -2,6 +2,7 @@
 // helpers (GEMM shorthands, batched SVT / spectral norm) of libjstsp_mi355x.so.
 #include "solver_common.h"
 #include <cstring>
+#include <cstdlib>
 #include <algorithm>
 
 namespace jstsp {
