@@ -29,6 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 64;
 constexpr int BK = 16;
+#ifndef JSTSP_M64_STEPS
+#define JSTSP_M64_STEPS 2
+#endif
+constexpr int M64_STEPS = JSTSP_M64_STEPS;   // fp32 chain length = 16 * M64_STEPS terms between fp64 flushes
 
 // TAG only gives the hot call sites their own kernel symbol (identical code), so that
 // rocprofv3's per-kernel statistics and the roofline in bench.py refer to one shape each.
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) bv[nb] = bn[nb];
         }
-        if (M64 && ((kt & 1) == 1 || kt + 1 == nk)) {
+        if (M64 && ((kt % M64_STEPS) == M64_STEPS - 1 || kt + 1 == nk)) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -273,8 +277,11 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
 {
     if (d.m <= 0 || d.n <= 0 || d.batch <= 0) return 0;
     const int tiles_m = (d.m + BM - 1) / BM;
-    // variant 2: 64-wide tile with fp64 master accumulators for long contractions (k per split >= 256)
-    static const int long_k = getenv("JSTSP_M64_MINK") ? atoi(getenv("JSTSP_M64_MINK")) : 256;
+    // variant 2: 64-wide tile with fp64 master accumulators for long contractions.  Measured at
+    // BASELINE configs[1]: only the 4096-term correlation needs it for |dNMSE| <= 1e-6 (1.2e-7 with
+    // the threshold at 2048, 1.7e-7 at 256, 4e-6 without); 512/1024-term chains stay on the faster
+    // 128-wide fp32 kernel.
+    static const int long_k = getenv("JSTSP_M64_MINK") ? atoi(getenv("JSTSP_M64_MINK")) : 2048;
     const int kper = (d.k + d.splitk - 1) / d.splitk;
     const int variant = (kper >= long_k) ? 2 : (d.n > 64 ? 1 : 0);
     const int bn = variant == 1 ? 128 : 64;

@@ -34,7 +34,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
 {
     const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
     size_t b = 0;
-    b += 7 * rnd256(batch * nm * sizeof(float2));
+    b += rnd256(3 * batch * nm * sizeof(float2)) + 4 * rnd256(batch * nm * sizeof(float2));
     b += rnd256(batch * nm * sizeof(float));
     b += 6 * rnd256(batch * g * sizeof(float2));
     b += 2 * rnd256(batch * ng * sizeof(float2));
@@ -44,7 +44,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     b += rnd256((size_t)batch * 3 * Imax * sizeof(double));
     b += rnd256(3 * (size_t)batch * sizeof(float));
     b += GramWS::bytes(N, M, batch, true);
-    if (want_ce) b += GramWS::bytes(N, M, batch, false);
+    if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false);
     return b;
 }
 
@@ -52,7 +52,10 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
                           bool angles, bool want_ce, int Imax)
 {
     const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
-    w.X = a.get<float2>(batch * nm); w.V1 = a.get<float2>(batch * nm); w.V2 = a.get<float2>(batch * nm);
+    // X, V1, V2 in one block: the spectral norms of the three are one batched Gram over 3*batch matrices
+    w.X = a.get<float2>(3 * batch * nm);
+    w.V1 = w.X ? w.X + batch * nm : nullptr;
+    w.V2 = w.X ? w.X + 2 * batch * nm : nullptr;
     w.C = a.get<float2>(batch * nm); w.Xs = a.get<float2>(batch * nm); w.Y = a.get<float2>(batch * nm);
     w.ZK = a.get<float2>(batch * nm);
     w.invD = a.get<float>(batch * nm);
@@ -69,7 +72,8 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
                       (!angles || w.rank),
                   JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     JSTSP_TRY(w.gz.alloc(a, N, M, batch, true));
-    if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, batch, false));
+    if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false));
+
     return 0;
 }
 
@@ -198,10 +202,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
         // -- convergence_error(i,1:2) = norm(V1)^2/norm(X)^2, norm(V2)^2/norm(X)^2           (:67,:69)
         if (want_ce) {
-            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.V1, w.lam));
-            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.V2, w.lam + batch));
-            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.X, w.lam + 2 * batch));
-            JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam, w.lam + batch, w.lam + 2 * batch, w.ce, Imax, it));
+            // one Gram + one lambda_max launch over the 3*batch matrices [X | V1 | V2]
+            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.X, w.lam));
+            JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));
         }
     }
 
