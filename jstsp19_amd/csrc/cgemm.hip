@@ -43,7 +43,14 @@ constexpr int M64_STEPS = JSTSP_M64_STEPS;   // fp32 chain length = 16 * M64_STE
 // is what limits NMSE parity with the float64 reference.  With M64 the fp32 accumulators
 // are flushed into fp64 master accumulators every 32 k (two panels) and restarted, so the
 // chain length is 32 and the long sum is carried in double — on the VALU, next to the MFMAs.
-template <int BN, int TAG, bool M64>
+//
+// M3: three real MFMAs per complex block instead of four (Gauss / "3M"):
+//   P1 = sum br*ar, P2 = sum bi*ai, P3 = sum (br+bi)(ar+ai);  re = P1 - P2, im = P3 - P1 - P2.
+// The fp32 matrix pipe on gfx950 is issue-throttled by data-dependent power (profiles/
+// r01_gemm_ladder_ubench.txt), so time follows the MFMA count: -25 %.  The operand sums are one
+// VALU add per fragment; the imaginary part carries a ~2-3x larger rounding error (difference of
+// larger sums), which is why M3 is combined with the fp64 master accumulators on the long chain.
+template <int BN, int TAG, bool M64, bool M3>
 __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int tiles_n)
 {
     constexpr int LDA = BM + 1;
@@ -155,14 +162,16 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
         }
     };
 
-    f32x16 acc_re[NB], acc_im[NB];
-    double m_re[M64 ? NB : 1][16], m_im[M64 ? NB : 1][16];
+    constexpr int NACC = M3 ? 3 : 2;       // M3: P1, P2, P3;  else: re, im
+    f32x16 acc[NB][NACC];
+    double mst[M64 ? NB : 1][2][16];       // fp64 masters always hold (re, im): P1..P3 are combined at flush time
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            acc_re[nb][r] = 0.f; acc_im[nb][r] = 0.f;
-            if (M64) { m_re[nb][r] = 0.0; m_im[nb][r] = 0.0; }
+#pragma unroll
+            for (int c = 0; c < NACC; ++c) acc[nb][c][r] = 0.f;
+            if (M64) { mst[nb][0][r] = 0.0; mst[nb][1][r] = 0.0; }
         }
 
     const int nk = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
@@ -197,20 +206,31 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) bn[nb] = bb[kr * LDB + nb * 32];
             }
+            // (b_re + i b_im)(a_re + i a_im): MFMA A-op = b (rows j), B-op = a (cols i)
+            if (M3) {
+                const float asum = av.x + av.y;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                // (b_re + i b_im)(a_re + i a_im): MFMA A-op = b (rows j), B-op = a (cols i)
-                acc_re[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].x, av.x, acc_re[nb], 0, 0, 0);
-                acc_im[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].x, av.y, acc_im[nb], 0, 0, 0);
-            }
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float bsum = bv[nb].x + bv[nb].y;
+                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].x, av.x, acc[nb][0], 0, 0, 0);
+                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].y, av.y, acc[nb][1], 0, 0, 0);
+                    acc[nb][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(bsum, asum, acc[nb][2], 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                acc_re[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(-bv[nb].y, av.y, acc_re[nb], 0, 0, 0);
-                acc_im[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].y, av.x, acc_im[nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].x, av.x, acc[nb][0], 0, 0, 0);
+                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].x, av.y, acc[nb][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    acc[nb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(-bv[nb].y, av.y, acc[nb][0], 0, 0, 0);
+                    acc[nb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[nb].y, av.x, acc[nb][1], 0, 0, 0);
+                }
             }
             if (kp + 1 < BK / 2) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1 + NB, 0);   // DS reads of the next k-pair first
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB, 0);   // then this k-pair's MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x008, (M3 ? 3 : 4) * NB, 0);   // then this k-pair's MFMAs
             }
             av = an;
 #pragma unroll
@@ -221,9 +241,16 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    m_re[nb][r] += (double)acc_re[nb][r];
-                    m_im[nb][r] += (double)acc_im[nb][r];
-                    acc_re[nb][r] = 0.f; acc_im[nb][r] = 0.f;
+                    if (M3) {       // exact in fp64: re = P1 - P2, im = P3 - P1 - P2
+                        const double p1 = (double)acc[nb][0][r], p2 = (double)acc[nb][1][r];
+                        mst[nb][0][r] += p1 - p2;
+                        mst[nb][1][r] += (double)acc[nb][NACC - 1][r] - p1 - p2;
+                    } else {
+                        mst[nb][0][r] += (double)acc[nb][0][r];
+                        mst[nb][1][r] += (double)acc[nb][1][r];
+                    }
+#pragma unroll
+                    for (int c = 0; c < NACC; ++c) acc[nb][c][r] = 0.f;
                 }
         }
         if (refresh) sstore(buf ^ 1);
@@ -241,8 +268,19 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
             for (int r = 0; r < 16; ++r) {
                 const int gj = n0 + wj * (BN / 2) + nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (gj < d.n) {
-                    const float vr = M64 ? (float)m_re[nb][r] : acc_re[nb][r];
-                    const float vi = M64 ? (float)m_im[nb][r] : acc_im[nb][r];
+                    float vr, vi;
+                    if (M3) {
+                        if (M64) {
+                            vr = (float)mst[nb][0][r];
+                            vi = (float)mst[nb][1][r];
+                        } else {
+                            vr = acc[nb][0][r] - acc[nb][1][r];
+                            vi = acc[nb][2][r] - acc[nb][0][r] - acc[nb][1][r];
+                        }
+                    } else {
+                        vr = M64 ? (float)mst[nb][0][r] : acc[nb][0][r];
+                        vi = M64 ? (float)mst[nb][1][r] : acc[nb][1][r];
+                    }
                     float2 o = make_float2(d.alpha * vr, d.alpha * vi);
                     if (Dp) {
                         const float2 dv = Dp[gi + (long long)gj * d.ldd];
@@ -257,18 +295,19 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 }
 
 template <int TAG>
-static void launch_tagged(jstsp_ctx *ctx, const GemmDesc &d, int variant, long long grid, int tiles_m,
+static void launch_tagged(jstsp_ctx *ctx, const GemmDesc &d, int variant, bool m3, long long grid, int tiles_m,
                           int tiles_n)
 {
-    if (variant == 2)
-        hipLaunchKernelGGL((cgemm_kernel<64, TAG, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
-                           tiles_m, tiles_n);
-    else if (variant == 1)
-        hipLaunchKernelGGL((cgemm_kernel<128, TAG, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
-                           tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((cgemm_kernel<64, TAG, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, d,
-                           tiles_m, tiles_n);
+    const dim3 g((unsigned)grid), b(256);
+    if (variant == 2) {
+        if (m3) hipLaunchKernelGGL((cgemm_kernel<64, TAG, true, true>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((cgemm_kernel<64, TAG, true, false>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+    } else if (variant == 1) {
+        if (m3) hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, true>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, false>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+    } else {
+        hipLaunchKernelGGL((cgemm_kernel<64, TAG, false, false>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+    }
 }
 
 static const char *const kTagNames[] = {"misc", "correlate", "synthesize", "gram"};
@@ -283,8 +322,12 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     // 128-wide fp32 kernel.
     static const int long_k = getenv("JSTSP_M64_MINK") ? atoi(getenv("JSTSP_M64_MINK")) : 2048;
     const int kper = (d.k + d.splitk - 1) / d.splitk;
-    const int variant = (kper >= long_k) ? 2 : (d.n > 64 ? 1 : 0);
+    // Grams only feed the SVT projector / spectral norms (not the gradient): plain fp32 chains are enough
+    const int variant = (kper >= long_k && tag != GEMM_GRAM) ? 2 : (d.n > 64 ? 1 : 0);
     const int bn = variant == 1 ? 128 : 64;
+    // 3M only where it pays and was validated: the two dominant contractions (JSTSP_M3=0 disables)
+    static const int m3_mask = getenv("JSTSP_M3") ? atoi(getenv("JSTSP_M3")) : 3;
+    const bool m3 = (tag == GEMM_CORRELATE && (m3_mask & 1)) || (tag == GEMM_SYNTH && (m3_mask & 2));
     const int tiles_n = (d.n + bn - 1) / bn;
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_m * tiles_n * d.splitk;
@@ -292,10 +335,10 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     const char *prof_name = (tag != GEMM_MISC) ? kTagNames[tag] : nullptr;
     if (prof_name) prof_begin(ctx, prof_name);
     switch (tag) {
-    case GEMM_CORRELATE: launch_tagged<GEMM_CORRELATE>(ctx, d, variant, grid, tiles_m, tiles_n); break;
-    case GEMM_SYNTH: launch_tagged<GEMM_SYNTH>(ctx, d, variant, grid, tiles_m, tiles_n); break;
-    case GEMM_GRAM: launch_tagged<GEMM_GRAM>(ctx, d, variant, grid, tiles_m, tiles_n); break;
-    default: launch_tagged<GEMM_MISC>(ctx, d, variant, grid, tiles_m, tiles_n); break;
+    case GEMM_CORRELATE: launch_tagged<GEMM_CORRELATE>(ctx, d, variant, m3, grid, tiles_m, tiles_n); break;
+    case GEMM_SYNTH: launch_tagged<GEMM_SYNTH>(ctx, d, variant, m3, grid, tiles_m, tiles_n); break;
+    case GEMM_GRAM: launch_tagged<GEMM_GRAM>(ctx, d, variant, m3, grid, tiles_m, tiles_n); break;
+    default: launch_tagged<GEMM_MISC>(ctx, d, variant, m3, grid, tiles_m, tiles_n); break;
     }
     if (prof_name) prof_end(ctx, prof_name);
     JSTSP_HIP(hipGetLastError());

@@ -84,6 +84,10 @@ struct jstsp_ctx {
     size_t pinned_cap = 0, pinned_off = 0;
     hipEvent_t pinned_done = nullptr;
     bool pinned_pending = false;
+    // side streams + events used by the ADMM driver to run the next iteration's SVT preparation
+    // and the convergence-error norms concurrently with the MFMA-bound GEMMs of the main stream
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace jstsp {

@@ -9,13 +9,14 @@
 // the whole batch on the context's stream.
 #include "solver_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <algorithm>
 
 namespace jstsp {
 
 struct ProposedWS {
     // state, N x M per problem
-    float2 *X, *V1, *V2, *C, *Xs, *Y, *ZK;
+    float2 *X, *V1, *V2, *C, *Xs, *Y, *ZK, *Zb;
     float *invD;
     // Gr x G2 per problem
     float2 *V, *RV, *Res, *RRes, *S, *P1;
@@ -34,7 +35,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
 {
     const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
     size_t b = 0;
-    b += rnd256(3 * batch * nm * sizeof(float2)) + 4 * rnd256(batch * nm * sizeof(float2));
+    b += rnd256(3 * batch * nm * sizeof(float2)) + 5 * rnd256(batch * nm * sizeof(float2));
     b += rnd256(batch * nm * sizeof(float));
     b += 6 * rnd256(batch * g * sizeof(float2));
     b += 2 * rnd256(batch * ng * sizeof(float2));
@@ -58,6 +59,7 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     w.V2 = w.X ? w.X + 2 * batch * nm : nullptr;
     w.C = a.get<float2>(batch * nm); w.Xs = a.get<float2>(batch * nm); w.Y = a.get<float2>(batch * nm);
     w.ZK = a.get<float2>(batch * nm);
+    w.Zb = a.get<float2>(batch * nm);
     w.invD = a.get<float>(batch * nm);
     w.V = a.get<float2>(batch * g); w.RV = a.get<float2>(batch * g); w.Res = a.get<float2>(batch * g);
     w.RRes = a.get<float2>(batch * g); w.S = a.get<float2>(batch * g); w.P1 = a.get<float2>(batch * g);
@@ -67,7 +69,7 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     w.rank = angles ? a.get<int32_t>(batch * g) : nullptr;
     w.ce = a.get<double>((size_t)batch * 3 * Imax);
     w.lam = a.get<float>(3 * (size_t)batch);
-    JSTSP_REQUIRE(w.X && w.V1 && w.V2 && w.C && w.Xs && w.Y && w.ZK && w.invD && w.V && w.RV && w.Res &&
+    JSTSP_REQUIRE(w.X && w.V1 && w.V2 && w.C && w.Xs && w.Y && w.ZK && w.Zb && w.invD && w.V && w.RV && w.Res &&
                       w.RRes && w.S && w.P1 && w.Tc && w.W && w.GA && w.GB && w.prm && w.ce && w.lam &&
                       (!angles || w.rank),
                   JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
@@ -173,12 +175,52 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
 
     const long long snm = (long long)nm, sg = (long long)g, sng = (long long)ng;
+    // Streams.  The critical path of an iteration is MFMA-bound
+    //   [Y = Z - QZ, X/K/V1 update] -> K B^H -> Gram applies -> step -> A S B -> [C/V2 update]
+    // and stays on the context's stream `sm`.  Two chains hang off it and run concurrently on side
+    // streams, fed by events:
+    //   s1: as soon as X, V1 of iteration i exist (after update_x) the NEXT iteration's SVT input
+    //       Z = X - V1/rho, its Gram and the Jacobi eigen-decomposition (memory / latency bound);
+    //   s2: the spectral norms of convergence_error(i,1:2): Gram of [X | V1] after update_x, Gram of
+    //       V2 after update_c, then lambda_max of all three.
+    // Buffer hazards are closed by events: update_x(i+1) waits for s1 (needs Q) and for s2's Gram of
+    // [X | V1] (reads what update_x overwrites); update_c(i+1) waits for s2's Gram of V2.
+    // Default: everything on the context's stream (same kernels, same arithmetic, identical
+    // results).  JSTSP_OVERLAP=1 enables the side streams: measured +3 % channel-estimates/s at
+    // BASELINE configs[1], but co-running kernels stretch each other (the K B^H launch goes from
+    // 2.66 to 4.26 ms), which muddles per-kernel accounting — off until the side chains are
+    // lighter than the MFMA-bound Grams they currently contain.
+    static const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0 : false;
+    JSTSP_TRY(ensure_side_streams(ctx));
+    hipStream_t sm = ctx->stream, s1 = overlap ? ctx->side[0] : sm, s2 = overlap ? ctx->side[1] : sm;
+    hipEvent_t ev_x = ctx->ev[0], ev_svt = ctx->ev[1], ev_gxv = ctx->ev[2], ev_c = ctx->ev[3], ev_gv2 = ctx->ev[4],
+               ev_ce = ctx->ev[5];
+    // iteration 0's SVT preparation on the main stream (X = V1 = 0)
+    if (Imax > 0) {
+        JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
+        JSTSP_TRY(svt_prepare(ctx, w.gz, w.Zb, w.prm, nullptr, true));
+    }
     for (int it = 0; it < Imax; ++it) {
-        // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho)                                          (:35)
-        JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.ZK));
-        JSTSP_TRY(svt_batched(ctx, w.gz, w.ZK, w.prm, nullptr, w.Y, true));
+        // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho) = Z - Q Z                                 (:35)
+        if (it > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));
+        JSTSP_TRY(svt_apply(ctx, w.gz, w.Zb, w.Y));
         // -- sub 2 + k of sub 3 + V1 dual update                                            (:38-43,:64)
+        if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gxv, 0));
         JSTSP_TRY(launch_update_x(ctx, snm, batch, w.X, w.V1, w.V2, w.C, w.Xs, w.Y, subY, w.invD, w.prm, w.ZK));
+        JSTSP_HIP(hipEventRecord(ev_x, sm));
+        if (it + 1 < Imax) {        // s1: next iteration's Z, Gram, eigen-decomposition
+            JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
+            StreamScope sc(ctx, s1);
+            JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
+            JSTSP_TRY(svt_prepare(ctx, w.gz, w.Zb, w.prm, nullptr, true));
+            JSTSP_HIP(hipEventRecord(ev_svt, s1));
+        }
+        if (want_ce) {              // s2: Gram of [X | V1]
+            JSTSP_HIP(hipStreamWaitEvent(s2, ev_x, 0));
+            StreamScope sc(ctx, s2);
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 0, 2 * batch));
+            JSTSP_HIP(hipEventRecord(ev_gxv, s2));
+        }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
         //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
         JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{w.ZK, snm, N}, Bm, w.Tc, sng, N, 1.f, nullptr, 0, 0,
@@ -199,14 +241,21 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N, 1.f, nullptr, 0, 0,
                        0.f, GEMM_SYNTH));
         // -- sub 4 + V2 dual update                                                          (:61,:65)
+        if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
         JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
         // -- convergence_error(i,1:2) = norm(V1)^2/norm(X)^2, norm(V2)^2/norm(X)^2           (:67,:69)
         if (want_ce) {
-            // one Gram + one lambda_max launch over the 3*batch matrices [X | V1 | V2]
-            JSTSP_TRY(sigma_max_sq(ctx, w.gn, w.X, w.lam));
+            JSTSP_HIP(hipEventRecord(ev_c, sm));
+            JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
+            StreamScope sc(ctx, s2);
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch));
+            JSTSP_HIP(hipEventRecord(ev_gv2, s2));
+            JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam));
             JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));
+            JSTSP_HIP(hipEventRecord(ev_ce, s2));
         }
     }
+    if (want_ce && Imax > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_ce, 0));
 
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), w.S, batch * g, memspace));
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), w.Y, batch * nm, memspace));

@@ -179,8 +179,26 @@ int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZ
                 0, 0, 0.f, GEMM_GRAM, w.nsplit, sG);
 }
 
-int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm,
-                const float *tau, float2 *Y, bool sequence)
+int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count)
+{
+    const Mat Zm{Z + (long long)t0 * sZt, sZt, w.rows};
+    const long long sG = (long long)w.n * w.n;
+    float2 *G = w.Gpart + (long long)t0 * sG * w.nsplit;
+    if (w.left)
+        return gemm(ctx, 'N', 'C', w.n, w.n, w.cols, count, Zm, Zm, G, sG * w.nsplit, w.n, 1.f, nullptr, 0, 0, 0.f,
+                    GEMM_GRAM, w.nsplit, sG);
+    return gemm(ctx, 'C', 'N', w.n, w.n, w.rows, count, Zm, Zm, G, sG * w.nsplit, w.n, 1.f, nullptr, 0, 0, 0.f,
+                GEMM_GRAM, w.nsplit, sG);
+}
+
+int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam)
+{
+    const long long sG = (long long)w.n * w.n;
+    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam);
+}
+
+int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
+                bool sequence)
 {
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
@@ -189,16 +207,38 @@ int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
         JSTSP_TRY(launch_eig_fast(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau,
                                   w.Q, nullptr, w.Uwarm, sequence ? w.warm : 0));
         w.warm = sequence ? 1 : 0;
-    } else {
-        JSTSP_TRY(launch_eig(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau, w.Q,
-                             nullptr, w.Vg));
+        return 0;
     }
+    return launch_eig(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau, w.Q, nullptr,
+                      w.Vg);
+}
+
+int svt_apply(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float2 *Y)
+{
+    const long long sZ = (long long)w.rows * w.cols;
+    const long long sG = (long long)w.n * w.n;
     const Mat Zm{Z, sZ, w.rows}, Qm{w.Q, sG, w.n};
     if (w.left)     // Y = Z - Q Z
         return gemm(ctx, 'N', 'N', w.rows, w.cols, w.n, w.batch, Qm, Zm, Y, sZ, w.rows, -1.f, Z, sZ, w.rows,
                     1.f);
     // Y = Z - Z Q
     return gemm(ctx, 'N', 'N', w.rows, w.cols, w.n, w.batch, Zm, Qm, Y, sZ, w.rows, -1.f, Z, sZ, w.rows, 1.f);
+}
+
+int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm,
+                const float *tau, float2 *Y, bool sequence)
+{
+    JSTSP_TRY(svt_prepare(ctx, w, Z, prm, tau, sequence));
+    return svt_apply(ctx, w, Z, Y);
+}
+
+int ensure_side_streams(jstsp_ctx *ctx)
+{
+    for (int i = 0; i < 2; ++i)
+        if (!ctx->side[i]) JSTSP_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+    for (int i = 0; i < 6; ++i)
+        if (!ctx->ev[i]) JSTSP_HIP(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
+    return 0;
 }
 
 int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam)
@@ -285,6 +325,8 @@ int jstsp_destroy(jstsp_ctx *ctx)
     prof_collect(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned_done) (void)hipEventDestroy(ctx->pinned_done);
+    for (int i = 0; i < 2; ++i) if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
+    for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->arena.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

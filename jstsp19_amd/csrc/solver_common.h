@@ -36,6 +36,22 @@ int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZ
 // eigenvector basis of the previous call warm-starts the Jacobi sweeps.
 int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm,
                 const float *tau, float2 *Y, bool sequence = false);
+// The two halves of svt_batched: Gram + eigen-decomposition -> projector Q; then Y = Z - Q Z.
+int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
+                bool sequence);
+int svt_apply(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float2 *Y);
+// Gram partials of problems [t0, t0 + count) only (same workspace layout as gram_partials).
+int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count);
+// lam[t] = lambda_max of the Gram partials already in the workspace, all w.batch problems
+int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam);
+// Make sure the context's side streams / events exist.
+int ensure_side_streams(jstsp_ctx *ctx);
+// Temporarily route the launch helpers (which use ctx->stream) to another stream.
+struct StreamScope {
+    jstsp_ctx *c; hipStream_t saved;
+    StreamScope(jstsp_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
+    ~StreamScope() { c->stream = saved; }
+};
 // lam[t] = sigma_max(Z_t)^2
 int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam);
 
