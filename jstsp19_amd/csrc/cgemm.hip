@@ -50,7 +50,12 @@ constexpr int M64_STEPS = JSTSP_M64_STEPS;   // fp32 chain length = 16 * M64_STE
 // r01_gemm_ladder_ubench.txt), so time follows the MFMA count: -25 %.  The operand sums are one
 // VALU add per fragment; the imaginary part carries a ~2-3x larger rounding error (difference of
 // larger sums), which is why M3 is combined with the fp64 master accumulators on the long chain.
-template <int BN, int TAG, bool M64, bool M3>
+//
+// EPI: the element-wise ADMM updates that consume a GEMM result are applied to the accumulator
+// tile before it leaves the registers (one pass over the N x M state instead of a GEMM store
+// plus a separate streaming kernel): EPI_UPDATE_C after the synthesis, EPI_UPDATE_X after the
+// SVT re-projection.
+template <int BN, int TAG, bool M64, bool M3, int EPI>
 __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int tiles_n)
 {
     constexpr int LDA = BM + 1;
@@ -287,7 +292,33 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                         o.x += d.beta * dv.x;
                         o.y += d.beta * dv.y;
                     }
-                    Cp[gi + (long long)gj * d.ldc] = o;
+                    const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
+                    if (EPI == EPI_UPDATE_C) {
+                        // o = Xs
+                        const float rho = d.prm[t].rho, ir = d.prm[t].irho, cc = d.prm[t].c_coef;
+                        const float2 x = d.e_r0[ix];
+                        float2 v2 = d.e_rw0[ix];
+                        const float2 c = make_float2(cc * (x.x - o.x - ir * v2.x), cc * (x.y - o.y - ir * v2.y));
+                        v2.x += rho * (c.x - x.x + o.x);
+                        v2.y += rho * (c.y - x.y + o.y);
+                        d.e_w1[ix] = c;
+                        d.e_rw0[ix] = v2;
+                        Cp[gi + (long long)gj * d.ldc] = o;
+                    } else if (EPI == EPI_UPDATE_X) {
+                        // o = Y
+                        const float rho = d.prm[t].rho, ir = d.prm[t].irho;
+                        float2 v1 = d.e_rw0[ix];
+                        const float2 v2 = d.e_r0[ix], c = d.e_r1[ix], xs = d.e_r2[ix], sy = d.e_r3[ix];
+                        const float id = d.e_f0[ix];
+                        const float2 x = make_float2((v1.x + rho * o.x + sy.x + v2.x + rho * c.x + rho * xs.x) * id,
+                                                     (v1.y + rho * o.y + sy.y + v2.y + rho * c.y + rho * xs.y) * id);
+                        d.e_w1[ix] = x;
+                        d.e_w2[ix] = make_float2(x.x - ir * v2.x - c.x, x.y - ir * v2.y - c.y);
+                        d.e_rw0[ix] = make_float2(v1.x + rho * (o.x - x.x), v1.y + rho * (o.y - x.y));
+                        if (d.epi_store_c) Cp[gi + (long long)gj * d.ldc] = o;
+                    } else {
+                        Cp[gi + (long long)gj * d.ldc] = o;
+                    }
                 }
             }
         }
@@ -300,13 +331,26 @@ static void launch_tagged(jstsp_ctx *ctx, const GemmDesc &d, int variant, bool m
 {
     const dim3 g((unsigned)grid), b(256);
     if (variant == 2) {
-        if (m3) hipLaunchKernelGGL((cgemm_kernel<64, TAG, true, true>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((cgemm_kernel<64, TAG, true, false>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        if (m3) hipLaunchKernelGGL((cgemm_kernel<64, TAG, true, true, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((cgemm_kernel<64, TAG, true, false, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
     } else if (variant == 1) {
-        if (m3) hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, true>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, false>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        if (m3) hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, true, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, false, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
     } else {
-        hipLaunchKernelGGL((cgemm_kernel<64, TAG, false, false>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        hipLaunchKernelGGL((cgemm_kernel<64, TAG, false, false, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+    }
+}
+
+// Fused-epilogue launches: 128- or 64-wide fp32 tile (never split-K, never M64).
+template <int TAG, int EPI>
+static void launch_epi(jstsp_ctx *ctx, const GemmDesc &d, bool wide, bool m3, long long grid, int tiles_m, int tiles_n)
+{
+    const dim3 g((unsigned)grid), b(256);
+    if (wide) {
+        if (m3) hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, true, EPI>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, false, EPI>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+    } else {
+        hipLaunchKernelGGL((cgemm_kernel<64, TAG, false, false, EPI>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
     }
 }
 
@@ -323,7 +367,7 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     static const int long_k = getenv("JSTSP_M64_MINK") ? atoi(getenv("JSTSP_M64_MINK")) : 2048;
     const int kper = (d.k + d.splitk - 1) / d.splitk;
     // Grams only feed the SVT projector / spectral norms (not the gradient): plain fp32 chains are enough
-    const int variant = (kper >= long_k && tag != GEMM_GRAM) ? 2 : (d.n > 64 ? 1 : 0);
+    const int variant = (kper >= long_k && tag != GEMM_GRAM && d.epi == EPI_NONE) ? 2 : (d.n > 64 ? 1 : 0);
     const int bn = variant == 1 ? 128 : 64;
     // 3M only where it pays and was validated: the two dominant contractions (JSTSP_M3=0 disables)
     static const int m3_mask = getenv("JSTSP_M3") ? atoi(getenv("JSTSP_M3")) : 3;
@@ -334,6 +378,9 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "cgemm grid too large");
     const char *prof_name = (tag != GEMM_MISC) ? kTagNames[tag] : nullptr;
     if (prof_name) prof_begin(ctx, prof_name);
+    if (d.epi == EPI_UPDATE_C) launch_epi<GEMM_SYNTH, EPI_UPDATE_C>(ctx, d, variant == 1, m3, grid, tiles_m, tiles_n);
+    else if (d.epi == EPI_UPDATE_X) launch_epi<GEMM_MISC, EPI_UPDATE_X>(ctx, d, variant == 1, false, grid, tiles_m, tiles_n);
+    else
     switch (tag) {
     case GEMM_CORRELATE: launch_tagged<GEMM_CORRELATE>(ctx, d, variant, m3, grid, tiles_m, tiles_n); break;
     case GEMM_SYNTH: launch_tagged<GEMM_SYNTH>(ctx, d, variant, m3, grid, tiles_m, tiles_n); break;

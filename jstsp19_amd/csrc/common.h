@@ -106,7 +106,20 @@ struct GemmDesc {
     float alpha, beta;
     int m, n, k, batch;
     int splitk; long long sCsplit;
+    // Fused ADMM epilogues (EPI_*): extra N x M arrays indexed like C (t*sCt + i + ldc*j)
+    int epi;
+    const TrialParams *prm;
+    float2 *e_rw0, *e_w1, *e_w2;            // in/out and output arrays
+    const float2 *e_r0, *e_r1, *e_r2, *e_r3;
+    const float *e_f0;
+    int epi_store_c;                        // EPI_UPDATE_X: also store Y into C
 };
+// EPI_UPDATE_C (after Xs = A S B, proposed_algorithm.m:58):  C = rho/(rho+1)(X - Xs - V2/rho) (:61);
+//   V2 += rho (C - X + Xs) (:65).   e_r0 = X, e_rw0 = V2, e_w1 = C; Xs -> d.C
+// EPI_UPDATE_X (after Y = Z - Q Z, :35):  X = (V1 + rho Y + subY + V2 + rho C + rho Xs) .* invD (:38-40);
+//   K = X - V2/rho - C (:43);  V1 += rho (Y - X) (:64).
+//   e_rw0 = V1, e_w1 = X, e_w2 = K, e_r0 = V2, e_r1 = C, e_r2 = Xs, e_r3 = subY, e_f0 = invD; Y -> d.C if epi_store_c
+enum { EPI_NONE = 0, EPI_UPDATE_C = 1, EPI_UPDATE_X = 2 };
 enum { GEMM_MISC = 0, GEMM_CORRELATE = 1, GEMM_SYNTH = 2, GEMM_GRAM = 3 };
 int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag = GEMM_MISC);
 

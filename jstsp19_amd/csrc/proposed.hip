@@ -190,6 +190,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     // BASELINE configs[1], but co-running kernels stretch each other (the K B^H launch goes from
     // 2.66 to 4.26 ms), which muddles per-kernel accounting — off until the side chains are
     // lighter than the MFMA-bound Grams they currently contain.
+    static const bool fuse = getenv("JSTSP_FUSE") ? atoi(getenv("JSTSP_FUSE")) != 0 : true;
     static const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0 : false;
     JSTSP_TRY(ensure_side_streams(ctx));
     hipStream_t sm = ctx->stream, s1 = overlap ? ctx->side[0] : sm, s2 = overlap ? ctx->side[1] : sm;
@@ -203,10 +204,21 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     for (int it = 0; it < Imax; ++it) {
         // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho) = Z - Q Z                                 (:35)
         if (it > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));
-        JSTSP_TRY(svt_apply(ctx, w.gz, w.Zb, w.Y));
-        // -- sub 2 + k of sub 3 + V1 dual update                                            (:38-43,:64)
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gxv, 0));
-        JSTSP_TRY(launch_update_x(ctx, snm, batch, w.X, w.V1, w.V2, w.C, w.Xs, w.Y, subY, w.invD, w.prm, w.ZK));
+        if (w.gz.left && fuse) {
+            // Y = Z - Q Z with the X / K / V1 updates applied to the tile in registers      (:35-43,:64)
+            GemmDesc dq = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{w.Zb, snm, N}, w.Y,
+                                    snm, N, -1.f, w.Zb, snm, N, 1.f);
+            dq.epi = EPI_UPDATE_X; dq.prm = w.prm;
+            dq.e_rw0 = w.V1; dq.e_w1 = w.X; dq.e_w2 = w.ZK;
+            dq.e_r0 = w.V2; dq.e_r1 = w.C; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
+            dq.epi_store_c = (it + 1 == Imax);          // Y itself is only an output of the last iteration
+            JSTSP_TRY(launch_cgemm(ctx, dq, GEMM_MISC));
+        } else {
+            JSTSP_TRY(svt_apply(ctx, w.gz, w.Zb, w.Y));
+            // -- sub 2 + k of sub 3 + V1 dual update                                        (:38-43,:64)
+            JSTSP_TRY(launch_update_x(ctx, snm, batch, w.X, w.V1, w.V2, w.C, w.Xs, w.Y, subY, w.invD, w.prm, w.ZK));
+        }
         JSTSP_HIP(hipEventRecord(ev_x, sm));
         if (it + 1 < Imax) {        // s1: next iteration's Z, Gram, eigen-decomposition
             JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
@@ -238,11 +250,19 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                                 Imax, it));
         // -- Xs = A S B                                                                      (:58)
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
-        JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N, 1.f, nullptr, 0, 0,
-                       0.f, GEMM_SYNTH));
-        // -- sub 4 + V2 dual update                                                          (:61,:65)
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
-        JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
+        if (fuse) {
+            // Xs = W B with sub 4 + the V2 dual update applied in the epilogue              (:58,:61,:65)
+            GemmDesc ds = make_gemm('N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N);
+            ds.epi = EPI_UPDATE_C; ds.prm = w.prm;
+            ds.e_r0 = w.X; ds.e_rw0 = w.V2; ds.e_w1 = w.C;
+            JSTSP_TRY(launch_cgemm(ctx, ds, GEMM_SYNTH));
+        } else {
+            JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N, 1.f, nullptr, 0, 0,
+                           0.f, GEMM_SYNTH));
+            // -- sub 4 + V2 dual update                                                      (:61,:65)
+            JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
+        }
         // -- convergence_error(i,1:2) = norm(V1)^2/norm(X)^2, norm(V2)^2/norm(X)^2           (:67,:69)
         if (want_ce) {
             JSTSP_HIP(hipEventRecord(ev_c, sm));

@@ -96,9 +96,9 @@ static void prof_collect(jstsp_ctx *ctx)
 }
 
 // ---- GEMM shorthand ---------------------------------------------------------------------------
-int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C,
-         long long sCt, int ldc, float alpha, const float2 *D, long long sDt, int ldd, float beta, int tag,
-         int splitk, long long sCsplit)
+GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C, long long sCt,
+                   int ldc, float alpha, const float2 *D, long long sDt, int ldd, float beta, int splitk,
+                   long long sCsplit)
 {
     GemmDesc d;
     d.A = A.p; d.sAt = A.st;
@@ -114,7 +114,17 @@ int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat
     d.alpha = alpha; d.beta = beta;
     d.m = m; d.n = n; d.k = k; d.batch = batch;
     d.splitk = splitk < 1 ? 1 : splitk; d.sCsplit = sCsplit;
-    return launch_cgemm(ctx, d, tag);
+    d.epi = EPI_NONE; d.prm = nullptr; d.e_rw0 = d.e_w1 = d.e_w2 = nullptr;
+    d.e_r0 = d.e_r1 = d.e_r2 = d.e_r3 = nullptr; d.e_f0 = nullptr; d.epi_store_c = 1;
+    return d;
+}
+
+int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C,
+         long long sCt, int ldc, float alpha, const float2 *D, long long sDt, int ldd, float beta, int tag,
+         int splitk, long long sCsplit)
+{
+    return launch_cgemm(ctx, make_gemm(opA, opB, m, n, k, batch, A, B, C, sCt, ldc, alpha, D, sDt, ldd, beta, splitk,
+                                       sCsplit), tag);
 }
 
 // ---- Gram-form SVT ------------------------------------------------------------------------------

@@ -16,6 +16,11 @@ int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat
          long long sCt, int ldc, float alpha = 1.f, const float2 *D = nullptr, long long sDt = 0,
          int ldd = 0, float beta = 0.f, int tag = GEMM_MISC, int splitk = 1, long long sCsplit = 0);
 
+// Descriptor only (the caller may attach a fused epilogue before launch_cgemm).
+GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C, long long sCt,
+                   int ldc, float alpha = 1.f, const float2 *D = nullptr, long long sDt = 0, int ldd = 0,
+                   float beta = 0.f, int splitk = 1, long long sCsplit = 0);
+
 // Workspace of the Gram-form SVT / spectral norm of rows x cols matrices.
 struct GramWS {
     int rows = 0, cols = 0, n = 0, nsplit = 1, batch = 0;
