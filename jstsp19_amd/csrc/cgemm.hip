@@ -294,27 +294,28 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                     }
                     const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
                     if (EPI == EPI_UPDATE_C) {
-                        // o = Xs
-                        const float rho = d.prm[t].rho, ir = d.prm[t].irho, cc = d.prm[t].c_coef;
+                        // o = Xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (= the reference's :61 + :65, C == -V2)
+                        const float rho = d.prm[t].rho, omc = 1.f - d.prm[t].c_coef;
                         const float2 x = d.e_r0[ix];
                         float2 v2 = d.e_rw0[ix];
-                        const float2 c = make_float2(cc * (x.x - o.x - ir * v2.x), cc * (x.y - o.y - ir * v2.y));
-                        v2.x += rho * (c.x - x.x + o.x);
-                        v2.y += rho * (c.y - x.y + o.y);
-                        d.e_w1[ix] = c;
+                        v2.x = omc * (v2.x - rho * (x.x - o.x));
+                        v2.y = omc * (v2.y - rho * (x.y - o.y));
                         d.e_rw0[ix] = v2;
                         Cp[gi + (long long)gj * d.ldc] = o;
                     } else if (EPI == EPI_UPDATE_X) {
                         // o = Y
                         const float rho = d.prm[t].rho, ir = d.prm[t].irho;
                         float2 v1 = d.e_rw0[ix];
-                        const float2 v2 = d.e_r0[ix], c = d.e_r1[ix], xs = d.e_r2[ix], sy = d.e_r3[ix];
+                        const float2 v2 = d.e_r0[ix], xs = d.e_r2[ix], sy = d.e_r3[ix];
                         const float id = d.e_f0[ix];
-                        const float2 x = make_float2((v1.x + rho * o.x + sy.x + v2.x + rho * c.x + rho * xs.x) * id,
-                                                     (v1.y + rho * o.y + sy.y + v2.y + rho * c.y + rho * xs.y) * id);
+                        const float omr = 1.f - rho, omir = 1.f - ir;
+                        const float2 x = make_float2((v1.x + rho * o.x + sy.x + omr * v2.x + rho * xs.x) * id,
+                                                     (v1.y + rho * o.y + sy.y + omr * v2.y + rho * xs.y) * id);
                         d.e_w1[ix] = x;
-                        d.e_w2[ix] = make_float2(x.x - ir * v2.x - c.x, x.y - ir * v2.y - c.y);
-                        d.e_rw0[ix] = make_float2(v1.x + rho * (o.x - x.x), v1.y + rho * (o.y - x.y));
+                        d.e_w2[ix] = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);
+                        v1 = make_float2(v1.x + rho * (o.x - x.x), v1.y + rho * (o.y - x.y));
+                        d.e_rw0[ix] = v1;
+                        if (d.e_w3) d.e_w3[ix] = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
                         if (d.epi_store_c) Cp[gi + (long long)gj * d.ldc] = o;
                     } else {
                         Cp[gi + (long long)gj * d.ldc] = o;
@@ -337,7 +338,8 @@ static void launch_tagged(jstsp_ctx *ctx, const GemmDesc &d, int variant, bool m
         if (m3) hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, true, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
         else hipLaunchKernelGGL((cgemm_kernel<128, TAG, false, false, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
     } else {
-        hipLaunchKernelGGL((cgemm_kernel<64, TAG, false, false, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        if (m3) hipLaunchKernelGGL((cgemm_kernel<64, TAG, false, true, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
+        else hipLaunchKernelGGL((cgemm_kernel<64, TAG, false, false, EPI_NONE>), g, b, 0, ctx->stream, d, tiles_m, tiles_n);
     }
 }
 
@@ -370,8 +372,9 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     const int variant = (kper >= long_k && tag != GEMM_GRAM && d.epi == EPI_NONE) ? 2 : (d.n > 64 ? 1 : 0);
     const int bn = variant == 1 ? 128 : 64;
     // 3M only where it pays and was validated: the two dominant contractions (JSTSP_M3=0 disables)
-    static const int m3_mask = getenv("JSTSP_M3") ? atoi(getenv("JSTSP_M3")) : 3;
-    const bool m3 = (tag == GEMM_CORRELATE && (m3_mask & 1)) || (tag == GEMM_SYNTH && (m3_mask & 2));
+    static const int m3_mask = getenv("JSTSP_M3") ? atoi(getenv("JSTSP_M3")) : 15;
+    const bool m3 = (tag == GEMM_CORRELATE && (m3_mask & 1)) || (tag == GEMM_SYNTH && (m3_mask & 2)) ||
+                    (tag == GEMM_GRAM && (m3_mask & 4)) || (tag == GEMM_MISC && kper >= 256 && (m3_mask & 8));
     const int tiles_n = (d.n + bn - 1) / bn;
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_m * tiles_n * d.splitk;

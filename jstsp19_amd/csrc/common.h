@@ -109,16 +109,21 @@ struct GemmDesc {
     // Fused ADMM epilogues (EPI_*): extra N x M arrays indexed like C (t*sCt + i + ldc*j)
     int epi;
     const TrialParams *prm;
-    float2 *e_rw0, *e_w1, *e_w2;            // in/out and output arrays
+    float2 *e_rw0, *e_w1, *e_w2, *e_w3;     // in/out and output arrays
     const float2 *e_r0, *e_r1, *e_r2, *e_r3;
     const float *e_f0;
     int epi_store_c;                        // EPI_UPDATE_X: also store Y into C
 };
-// EPI_UPDATE_C (after Xs = A S B, proposed_algorithm.m:58):  C = rho/(rho+1)(X - Xs - V2/rho) (:61);
-//   V2 += rho (C - X + Xs) (:65).   e_r0 = X, e_rw0 = V2, e_w1 = C; Xs -> d.C
-// EPI_UPDATE_X (after Y = Z - Q Z, :35):  X = (V1 + rho Y + subY + V2 + rho C + rho Xs) .* invD (:38-40);
-//   K = X - V2/rho - C (:43);  V1 += rho (Y - X) (:64).
-//   e_rw0 = V1, e_w1 = X, e_w2 = K, e_r0 = V2, e_r1 = C, e_r2 = Xs, e_r3 = subY, e_f0 = invD; Y -> d.C if epi_store_c
+// The N x M array C of the reference is never stored: with cc = rho/(rho+1), D = X - Xs,
+//   C   = cc (D - V2/rho)                       (proposed_algorithm.m:61)
+//   V2' = V2 + rho (C - D) = (1 - cc)(V2 - rho D) (:65)     and   -C = (cc/rho)(V2 - rho D) = (1 - cc)(V2 - rho D)
+// because cc/rho = 1/(rho+1) = 1 - cc: after every iteration C == -V2 exactly (both start at 0).
+// EPI_UPDATE_C (after Xs = A S B, :58):  V2 <- (1 - cc)(V2 - rho (X - Xs)).   e_r0 = X, e_rw0 = V2; Xs -> d.C
+// EPI_UPDATE_X (after Y = Z - Q Z, :35), with C = -V2:
+//   X = (V1 + rho Y + subY + (1 - rho) V2 + rho Xs) .* invD (:38-40);  K = X + (1 - 1/rho) V2 (:43);
+//   V1 += rho (Y - X) (:64);  Znext = X - V1/rho (the next iteration's svt argument, :35).
+//   e_rw0 = V1, e_w1 = X, e_w2 = K, e_r0 = V2, e_r2 = Xs, e_r3 = subY, e_f0 = invD, e_w3 = Znext (may be NULL);
+//   Y -> d.C if epi_store_c
 enum { EPI_NONE = 0, EPI_UPDATE_C = 1, EPI_UPDATE_X = 2 };
 enum { GEMM_MISC = 0, GEMM_CORRELATE = 1, GEMM_SYNTH = 2, GEMM_GRAM = 3 };
 int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag = GEMM_MISC);

@@ -16,7 +16,7 @@ namespace jstsp {
 
 struct ProposedWS {
     // state, N x M per problem
-    float2 *X, *V1, *V2, *C, *Xs, *Y, *ZK, *Zb;
+    float2 *X, *V1, *V2, *C, *Xs, *Y, *ZK, *Zb, *Zb2;
     float *invD;
     // Gr x G2 per problem
     float2 *V, *RV, *Res, *RRes, *S, *P1;
@@ -35,7 +35,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
 {
     const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
     size_t b = 0;
-    b += rnd256(3 * batch * nm * sizeof(float2)) + 5 * rnd256(batch * nm * sizeof(float2));
+    b += rnd256(3 * batch * nm * sizeof(float2)) + 6 * rnd256(batch * nm * sizeof(float2));
     b += rnd256(batch * nm * sizeof(float));
     b += 6 * rnd256(batch * g * sizeof(float2));
     b += 2 * rnd256(batch * ng * sizeof(float2));
@@ -60,6 +60,7 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     w.C = a.get<float2>(batch * nm); w.Xs = a.get<float2>(batch * nm); w.Y = a.get<float2>(batch * nm);
     w.ZK = a.get<float2>(batch * nm);
     w.Zb = a.get<float2>(batch * nm);
+    w.Zb2 = a.get<float2>(batch * nm);
     w.invD = a.get<float>(batch * nm);
     w.V = a.get<float2>(batch * g); w.RV = a.get<float2>(batch * g); w.Res = a.get<float2>(batch * g);
     w.RRes = a.get<float2>(batch * g); w.S = a.get<float2>(batch * g); w.P1 = a.get<float2>(batch * g);
@@ -69,7 +70,7 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     w.rank = angles ? a.get<int32_t>(batch * g) : nullptr;
     w.ce = a.get<double>((size_t)batch * 3 * Imax);
     w.lam = a.get<float>(3 * (size_t)batch);
-    JSTSP_REQUIRE(w.X && w.V1 && w.V2 && w.C && w.Xs && w.Y && w.ZK && w.Zb && w.invD && w.V && w.RV && w.Res &&
+    JSTSP_REQUIRE(w.X && w.V1 && w.V2 && w.C && w.Xs && w.Y && w.ZK && w.Zb && w.Zb2 && w.invD && w.V && w.RV && w.Res &&
                       w.RRes && w.S && w.P1 && w.Tc && w.W && w.GA && w.GB && w.prm && w.ce && w.lam &&
                       (!angles || w.rank),
                   JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
@@ -201,21 +202,25 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
         JSTSP_TRY(svt_prepare(ctx, w.gz, w.Zb, w.prm, nullptr, true));
     }
+    const bool fz = fuse && w.gz.left;          // fused epilogues (need the Z - Q Z orientation)
+    float2 *Zbuf[2] = {w.Zb, w.Zb2};            // svt argument of iteration it lives in Zbuf[it & 1]
     for (int it = 0; it < Imax; ++it) {
+        float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
         // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho) = Z - Q Z                                 (:35)
         if (it > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gxv, 0));
-        if (w.gz.left && fuse) {
-            // Y = Z - Q Z with the X / K / V1 updates applied to the tile in registers      (:35-43,:64)
-            GemmDesc dq = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{w.Zb, snm, N}, w.Y,
-                                    snm, N, -1.f, w.Zb, snm, N, 1.f);
+        if (fz) {
+            // Y = Z - Q Z with the X / K / V1 updates (and the next Z) applied to the tile in registers (:35-43,:64)
+            GemmDesc dq = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{Zc, snm, N}, w.Y,
+                                    snm, N, -1.f, Zc, snm, N, 1.f);
             dq.epi = EPI_UPDATE_X; dq.prm = w.prm;
             dq.e_rw0 = w.V1; dq.e_w1 = w.X; dq.e_w2 = w.ZK;
-            dq.e_r0 = w.V2; dq.e_r1 = w.C; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
+            dq.e_r0 = w.V2; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
+            dq.e_w3 = (it + 1 < Imax) ? Zn : nullptr;
             dq.epi_store_c = (it + 1 == Imax);          // Y itself is only an output of the last iteration
             JSTSP_TRY(launch_cgemm(ctx, dq, GEMM_MISC));
         } else {
-            JSTSP_TRY(svt_apply(ctx, w.gz, w.Zb, w.Y));
+            JSTSP_TRY(svt_apply(ctx, w.gz, Zc, w.Y));
             // -- sub 2 + k of sub 3 + V1 dual update                                        (:38-43,:64)
             JSTSP_TRY(launch_update_x(ctx, snm, batch, w.X, w.V1, w.V2, w.C, w.Xs, w.Y, subY, w.invD, w.prm, w.ZK));
         }
@@ -223,8 +228,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         if (it + 1 < Imax) {        // s1: next iteration's Z, Gram, eigen-decomposition
             JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
             StreamScope sc(ctx, s1);
-            JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
-            JSTSP_TRY(svt_prepare(ctx, w.gz, w.Zb, w.prm, nullptr, true));
+            if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
+            JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true));
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
         }
         if (want_ce) {              // s2: Gram of [X | V1]
@@ -251,11 +256,11 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         // -- Xs = A S B                                                                      (:58)
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
-        if (fuse) {
+        if (fz) {
             // Xs = W B with sub 4 + the V2 dual update applied in the epilogue              (:58,:61,:65)
             GemmDesc ds = make_gemm('N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N);
             ds.epi = EPI_UPDATE_C; ds.prm = w.prm;
-            ds.e_r0 = w.X; ds.e_rw0 = w.V2; ds.e_w1 = w.C;
+            ds.e_r0 = w.X; ds.e_rw0 = w.V2;
             JSTSP_TRY(launch_cgemm(ctx, ds, GEMM_SYNTH));
         } else {
             JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N, 1.f, nullptr, 0, 0,
