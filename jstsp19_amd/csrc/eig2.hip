@@ -13,6 +13,7 @@
 //  * lmax_kernel<NE>: lambda_max only — Householder tridiagonalisation (zhetd2-style) in LDS,
 //    then 256-way multisection on the Sturm sequence of the real tridiagonal matrix.
 #include "common.h"
+#include <cstdlib>
 
 namespace jstsp {
 
@@ -84,7 +85,8 @@ template <int NE>
 __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const float2 *Gpart, long long sGt,
                                                        int nsplit, long long sGs, const TrialParams *prm,
                                                        const float *tau, float2 *Q, float *lam_out,
-                                                       float2 *Uwarm, int warm)
+                                                       float2 *Uwarm, int warm, float conv_tol, int max_sweeps,
+                                                       int *sweep_stat)
 {
     constexpr int LD = NE + 1;
     constexpr int H = NE / 2;
@@ -146,8 +148,10 @@ __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const flo
 
     constexpr int NBLKS = H * H;                       // 2x2 blocks of G per round
     constexpr int BPT = (NBLKS + 255) / 256;           // blocks per thread
-    const int MAX_SWEEPS = 14;
+    const int MAX_SWEEPS = max_sweeps;
+    int sweeps_done = 0;
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
+        ++sweeps_done;
         if (tid == 0) red[0] = 0.f;
         float worst = 0.f;
         for (int s = 0; s < NE - 1; ++s) {
@@ -230,9 +234,10 @@ __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const flo
         __syncthreads();
         const float w = red[0];
         __syncthreads();
-        if (w < 3e-7f) break;
+        if (w < conv_tol) break;
     }
 
+    if (sweep_stat && tid == 0) atomicAdd(sweep_stat, sweeps_done);
     if (mode == EIG_LMAX) {
         float m = -1e30f;
         for (int i = tid; i < n; i += 256) m = fmaxf(m, G[i + LD * i].x);
@@ -442,8 +447,21 @@ static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const fl
     const size_t sh = jacobi2_smem<NE>();
     JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi2_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh));
+    static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 3e-7f;
+    static const int maxsw = getenv("JSTSP_JACOBI_SWEEPS") ? atoi(getenv("JSTSP_JACOBI_SWEEPS")) : 14;
+    static int *stat = nullptr;
+    if (getenv("JSTSP_JACOBI_STAT") && !stat) { (void)hipMalloc((void **)&stat, 4); (void)hipMemset(stat, 0, 4); }
     hipLaunchKernelGGL((jacobi2_kernel<NE>), dim3(batch), dim3(256), sh, ctx->stream, mode, n, Gpart, sGt, nsplit,
-                       sGs, prm, tau, Q, lam_out, Uwarm, warm);
+                       sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, stat);
+    if (stat) {
+        static int calls = 0;
+        if (++calls % 100 == 0) {
+            int h = 0;
+            (void)hipMemcpy(&h, stat, 4, hipMemcpyDeviceToHost);
+            (void)hipMemset(stat, 0, 4);
+            fprintf(stderr, "[jacobi] avg sweeps over last 100 launches: %.2f\n", h / (100.0 * batch));
+        }
+    }
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -135,6 +135,33 @@ def gen_mc():
     save("mc", Htrue=H, OH=OH, Omega=Omega, tau=tau, rho=rho, Imax=Imax, X_svt=X1, X_admm=X2, ce_admm=ce2)
 
 
+def gen_vamp():
+    """vamp.m on the conventional-HBF system of plot_errorVSsnr.m:73-101 (small parameters):
+    Phi = kron((B*B').', A), y = vec(Y_hbf*B'), sigma = 1, L = numOfnz."""
+    from . import vamp as V
+    rng = np.random.default_rng(15)
+    p = dict(PARAMS_SMALL)
+    p["noise_var"] = 10 ** (-1.0)
+    d = sm.draw_trial(rng, p)
+    H, Zbar, _, _, Dr, Dt = sm.wideband_mmwave_channel(p["L"], p["Nr"], p["Nt"], 2, 3, p["Gr"], p["Gt"], d["gains"],
+                                                       d["u_r"], d["u_t"])
+    T_hbf = 8
+    Psi_rows = np.stack([sm.toeplitz_rows(sm.qam4_alphabet()[d["qam_idx"][k]], p["L"]) for k in range(p["Nt"])], axis=2)
+    Nn = np.sqrt(p["noise_var"] / 2) * d["noise"]
+    Yc, Wc, Psi_bar, _ = sm.hbf(H, Nn[:, :T_hbf], Psi_rows[:, :T_hbf, :], T_hbf, p["Nr"], sm.create_beamformer(p["Nr"], "ZC"))
+    A = Wc.conj().T @ Dr                                                       # :74
+    B = np.concatenate([Dt.conj().T @ Psi_bar[:, :, l] for l in range(p["L"])])   # :75-78
+    Gb = B @ B.conj().T
+    Phi = np.kron(Gb.T, A)                                                     # :79
+    Ym = Yc @ B.conj().T                                                       # :80 (before vec)
+    y = S.vec(Ym)
+    t0 = time.time()
+    x_lit = V.vamp_literal(y, Phi, 1, 12)                                      # :100, numOfnz scaled down
+    x_kron = V.vamp_kron(Ym, A, Gb, 1, 12)
+    print("  vamp literal vs kron: %.2e (%.1fs)" % (np.abs(x_lit - S.vec(x_kron)).max(), time.time() - t0))
+    save("vamp", A=A, B=B, Gb=Gb, Y=Ym, Phi=Phi, y=y, sigma=1.0, L=12, x=x_lit, Zbar=Zbar)
+
+
 def main():
     t0 = time.time()
     gen_proposed("proposed_small", PARAMS_SMALL, 5.0, 1, 30, literal=True, types=("approximate", "std"))
@@ -143,6 +170,7 @@ def main():
     gen_omp()
     gen_sparse_admm()
     gen_mc()
+    gen_vamp()
     if "--fast" not in sys.argv:
         # reference-native shape (N=32, M=140, Gr=32, G2=16): dense K1 is 4480^2, K2 4480x512
         gen_proposed("proposed_refnative", PARAMS_REF, 5.0, 3, 100, literal=True, types=("approximate",))
