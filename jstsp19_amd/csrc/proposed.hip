@@ -106,9 +106,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                   std::min(N, M));
     JSTSP_REQUIRE(strideA == 0 || strideA >= (long long)N * Gr, JSTSP_E_SHAPE, "strideA too small");
     JSTSP_REQUIRE(strideB == 0 || strideB >= (long long)G2 * M, JSTSP_E_SHAPE, "strideB too small");
-    JSTSP_REQUIRE(type == JSTSP_TYPE_APPROXIMATE, JSTSP_E_UNSUPPORTED,
-                  "proposed_algorithm: only type 'approximate' (Algorithm 2) is implemented; "
-                  "'std' (LU least squares, proposed_algorithm.m:29,53) is not");
+    const bool approx = type == JSTSP_TYPE_APPROXIMATE;
+    JSTSP_REQUIRE(approx || (N >= Gr && M >= G2), JSTSP_E_UNSUPPORTED,
+                  "proposed_algorithm 'std': K2 = kron(B.', A) must have full column rank (N >= Gr, M >= G2); the "
+                  "under-determined U\\(L\\k) of the reference returns a basic, not least-squares, solution");
     JSTSP_HIP(hipSetDevice(ctx->device));
 
     const bool angles = indx_S_ != nullptr;
@@ -119,6 +120,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
 
     size_t need = proposed_bytes(N, M, Gr, G2, batch, nA, nB, angles, want_ce, std::max(Imax, 1));
+    if (!approx)
+        need += rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + rnd256((size_t)nB * G2 * G2 * sizeof(float2)) +
+                std::max(hinv_bytes(Gr, nA), hinv_bytes(G2, nB));
     if (memspace == JSTSP_HOST) {
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
                 rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
@@ -166,6 +170,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_HIP(hipMemsetAsync(w.Y, 0, batch * nm * sizeof(float2), st));
     JSTSP_HIP(hipMemsetAsync(w.V, 0, batch * g * sizeof(float2), st));
     JSTSP_HIP(hipMemsetAsync(w.S, 0, batch * g * sizeof(float2), st));
+    JSTSP_HIP(hipMemsetAsync(w.ce, 0, (size_t)batch * 3 * std::max(Imax, 1) * sizeof(double), st));   // ce(:,3) stays 0 for 'std' (:6)
     JSTSP_TRY(launch_inv_d(ctx, (long long)nm, batch, Omega, 2.f, w.prm, w.invD));
     if (angles) JSTSP_TRY(launch_rank_from_index(ctx, (int)g, batch, indx_S, w.rank));
 
@@ -175,6 +180,19 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
 
+    if (!approx) {
+        // 'std': v = U\(L\k) (:29,:53) = vec(G_A^-1 A^H K B^H G_B^-1): invert the two factor Grams once
+        // (into P1 / RV-sized scratch is too small for G_B: use the arena), then keep them in GA / GB.
+        float2 *GAi = ctx->arena.get<float2>((size_t)nA * Gr * Gr), *GBi = ctx->arena.get<float2>((size_t)nB * G2 * G2);
+        JSTSP_REQUIRE(GAi && GBi, JSTSP_E_NOMEM, "proposed_algorithm 'std': workspace exhausted");
+        const size_t mark = ctx->arena.off;
+        JSTSP_TRY(hermitian_inverse(ctx, Gr, nA, w.GA, GAi));
+        ctx->arena.off = mark;
+        JSTSP_TRY(hermitian_inverse(ctx, G2, nB, w.GB, GBi));
+        ctx->arena.off = mark;
+        JSTSP_HIP(hipMemcpyAsync(w.GA, GAi, (size_t)nA * Gr * Gr * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        JSTSP_HIP(hipMemcpyAsync(w.GB, GBi, (size_t)nB * G2 * G2 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+    }
     const long long snm = (long long)nm, sg = (long long)g, sng = (long long)ng;
     // Streams.  The critical path of an iteration is MFMA-bound
     //   [Y = Z - QZ, X/K/V1 update] -> K B^H -> Gram applies -> step -> A S B -> [C/V2 update]
@@ -242,17 +260,25 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
         JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{w.ZK, snm, N}, Bm, w.Tc, sng, N, 1.f, nullptr, 0, 0,
                        0.f, GEMM_CORRELATE));
-        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.V, sg, Gr}, w.P1, sg, Gr));
-        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RV, sg, Gr));
-        JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
-                       -1.f));
-        //    R*res for alpha = res'*res / (res'*R*res)                                        (:48)
-        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.Res, sg, Gr}, w.P1, sg, Gr));
-        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RRes, sg, Gr));
-        //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                                (:49-56, angles :36,:68)
         const long long cnt_ll = std::min<long long>(10 + 5ll * (it + 1), (long long)g);
-        JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
-                                Imax, it));
+        if (approx) {
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.V, sg, Gr}, w.P1, sg, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RV, sg, Gr));
+            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
+                           -1.f));
+            //    R*res for alpha = res'*res / (res'*R*res)                                    (:48)
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.Res, sg, Gr}, w.P1, sg, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RRes, sg, Gr));
+            //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
+            JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
+                                    Imax, it));
+        } else {
+            //    v = U\(L\k) = G_A^-1 (A^H Tc) G_B^-1   (GA / GB hold the inverses)          (:53)
+            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.Res, sg, Gr}, w.P1, sg, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.V, sg, Gr));
+            JSTSP_TRY(launch_soft(ctx, (int)g, batch, w.V, w.S, w.rank, (int)cnt_ll, w.prm));     // (:56)
+        }
         // -- Xs = A S B                                                                      (:58)
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));

@@ -60,6 +60,10 @@ struct StreamScope {
 // lam[t] = sigma_max(Z_t)^2
 int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam);
 
+// Ginv[t] = G[t]^-1 for `count` Hermitian PD n x n matrices (hinv.hip); workspace from ctx->arena.
+size_t hinv_bytes(int n, int count);
+int hermitian_inverse(jstsp_ctx *ctx, int n, int count, const float2 *G, float2 *Ginv);
+
 // Host -> device scalar block.
 int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes);
 

@@ -124,3 +124,30 @@ def test_bad_arguments_are_rejected_not_crashed():
         J.proposed_algorithm(g["subY"], g["Omega"][:, :-1], g["A"], g["B"], 5, 1.0, 1.0, 1.0)
     with pytest.raises(ValueError):
         J.proposed_algorithm(g["subY"], g["Omega"], g["A"][:-1], g["B"], 5, 1.0, 1.0, 1.0)
+
+
+def test_proposed_std_type_matches_golden_and_oracle():
+    """type ~= 'approximate' ('std'): v = U\\(L\\k), the LU least squares of proposed_algorithm.m:29,53."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    g = load_golden("proposed_small")
+    S, Y, ce = J.proposed_algorithm(g["subY"], g["Omega"], g["A"], g["B"], int(g["Imax"]), float(g["tau_Y"]),
+                                    float(g["tau_Z"]), float(g["rho"]), "std")
+    assert rel_err(S, g["S_std"]) < 5e-4 and rel_err(Y, g["Y_std"]) < 5e-4
+    assert np.all(ce[:, 2] == 0)                         # column 3 is only written by 'approximate' (:51)
+    np.testing.assert_allclose(ce[:, :2], g["ce_std"][:, :2], rtol=5e-3)
+    # a larger, well-conditioned over-determined system incl. the Newton-Schulz inverse (G2 > 128)
+    rng = np.random.default_rng(77)
+    N, M, Gr, G2 = 24, 200, 16, 140
+    A = (rng.standard_normal((N, Gr)) + 1j * rng.standard_normal((N, Gr))) / np.sqrt(N)
+    B = (rng.standard_normal((G2, M)) + 1j * rng.standard_normal((G2, M))) / np.sqrt(M)
+    S0 = np.zeros((Gr, G2), complex)
+    S0[rng.integers(0, Gr, 10), rng.integers(0, G2, 10)] = rng.standard_normal(10) + 1j * rng.standard_normal(10)
+    Om = (rng.random((N, M)) < 0.6).astype(float)
+    subY = Om * (A @ S0 @ B + 0.02 * (rng.standard_normal((N, M)) + 1j * rng.standard_normal((N, M))))
+    args = (subY, Om, A, B, 20, 0.01, 0.02, 0.3, "std")
+    So, Yo, _ = O.proposed_algorithm(*args)
+    Sg, Yg, _ = J.proposed_algorithm(*args)
+    assert rel_err(Sg, So) < 1e-3 and rel_err(Yg, Yo) < 1e-3
+    with pytest.raises(J.JstspError):                    # under-determined K2 is refused, not approximated
+        J.proposed_algorithm(subY[:, :100], Om[:, :100], A, B[:, :100], 5, 0.01, 0.02, 0.3, "std")
