@@ -141,6 +141,21 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
                       const jstsp_c32 *OH, const float *Omega, int Imax, const double *tau,
                       const double *rho, jstsp_c32 *X_out, double *ce_out, int memspace);
 
+/* x = vamp(y, A, sigma, L)   benchmark_algorithms/vamp.m:1-55 (VampGlmEst.m:347-511 with the
+ * Bernoulli-Gaussian denoiser SparseScaEstim/CAwgnEstimIn and the CAwgnEstimOut likelihood).
+ * Dense dictionary A: M x N with M <= min(N, 128) (strideA 0 = shared); y: M x batch; x_out: N x batch.
+ * sigma = noise variance passed to the likelihood (every driver passes 1), L = expected number of
+ * non-zeros, nit = iterations (the reference always runs 100: its stopping rule is commented out). */
+int jstsp_vamp_c32(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c32 *y, const jstsp_c32 *A,
+                   long long strideA, double sigma, double L, int nit, jstsp_c32 *x_out, int memspace);
+
+/* The same for the dictionary the drivers actually pass (plot_errorVSsnr.m:79-80,100):
+ *   Phi = kron(Gb.', Af),  y = vec(Y),  Af: Na x Gr (Na <= min(Gr,128)),  Gb: G2 x G2 Hermitian (G2 <= 128).
+ * Phi is never formed.  Y: Na x G2 x batch; X_out: Gr x G2 x batch (x = vec(X)). */
+int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const jstsp_c32 *Y,
+                        const jstsp_c32 *Af, long long strideA, const jstsp_c32 *Gb, long long strideG,
+                        double sigma, double L, int nit, jstsp_c32 *X_out, int memspace);
+
 /* nmse[t] = min(1, norm(S - Zbar)^2 / norm(Zbar)^2) with spectral norms
  *   plot_errorVSsnr.m:138-141.   S, Zbar: R x C x batch; nmse: batch doubles (same memspace). */
 int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S,

@@ -43,6 +43,10 @@ SIGNATURES = {
                                  c_void_p, c_int]),
     "jstsp_mc_admm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_dp,
                                   c_dp, c_void_p, c_void_p, c_int]),
+    "jstsp_vamp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, C.c_double, C.c_double, c_int,
+                               c_void_p, c_int]),
+    "jstsp_vamp_kron_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
+                                    C.c_double, C.c_double, c_int, c_void_p, c_int]),
     "jstsp_nmse_spectral_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "jstsp_set_profiling": (c_int, [c_void_p, c_int]),
     "jstsp_get_profile": (c_int, [c_void_p, C.c_char_p, c_ip, c_dp]),

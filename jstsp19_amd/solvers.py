@@ -27,7 +27,8 @@ from . import _lib
 from ._lib import DEVICE, HOST, JstspError, check
 
 __all__ = ["proposed_algorithm", "proposed_algorithm_angles", "svt", "mc_svt", "mc_admm", "OMP", "omp_kron",
-           "sparse_admm", "correlate", "synthesize", "nmse_spectral", "colmajor", "empty_colmajor"]
+           "sparse_admm", "vamp", "vamp_kron", "correlate", "synthesize", "nmse_spectral", "colmajor",
+           "empty_colmajor"]
 
 
 # ----------------------------------------------------------------------------- array plumbing
@@ -347,3 +348,39 @@ def omp_kron(Af, Bf, y, m, *, ctx=None):
                                     a_B.ptr, _shared_stride(a_B, G2 * M, batch, "Bf"), a_y.ptr, int(m), px, pi, mem),
           "jstsp_omp_kron_c32")
     return fx(single)[..., 0], fi(single)[..., 0]
+
+
+def vamp(y, A, sigma, L, *, nit=100, ctx=None):
+    """benchmark_algorithms/vamp.m:1 — ``x = vamp(y, A, sigma, L)`` (dense dictionary, M <= min(N, 128)).
+    ``y``: (M,) or (batch, M).  ``nit`` = 100 is what the reference always runs."""
+    a_A = _Arg(A, np.complex64, "A")
+    tor = _is_torch(y)
+    single = y.ndim == 1
+    y3 = (y.reshape(1, -1, 1) if single else y.reshape(y.shape[0], -1, 1))
+    if tor:
+        y3 = colmajor(y3)
+    a_y = _Arg(y3, np.complex64, "y")
+    batch, M, N = a_y.batch, a_A.R, a_A.C
+    if a_y.R != M:
+        raise ValueError("length(y) must equal size(A,1)")
+    c, mem, dev = _ctx_for([a_A, a_y], ctx)
+    px, fx = _out(mem == DEVICE, batch, N, 1, np.complex64, dev)
+    check(c._lib.jstsp_vamp_c32(c.handle, M, N, batch, a_y.ptr, a_A.ptr, _shared_stride(a_A, M * N, batch, "A"),
+                                float(sigma), float(L), int(nit), px, mem), "jstsp_vamp_c32")
+    return fx(single)[..., 0]
+
+
+def vamp_kron(Y, Af, Gb, sigma, L, *, nit=100, ctx=None):
+    """``vamp(vec(Y), kron(Gb.', Af), sigma, L)`` without forming the dictionary — the call of
+    plot_errorVSsnr.m:79-80,100 with ``Gb = B*B'``, ``Y = Y_hbf*B'``.  Returns X (Gr x G2), x = vec(X)."""
+    a_Y, a_A, a_G = _Arg(Y, np.complex64, "Y"), _Arg(Af, np.complex64, "Af"), _Arg(Gb, np.complex64, "Gb")
+    batch, Na, G2, Gr = a_Y.batch, a_Y.R, a_Y.C, a_A.C
+    if a_A.R != Na or (a_G.R, a_G.C) != (G2, G2):
+        raise ValueError("shape mismatch")
+    c, mem, dev = _ctx_for([a_Y, a_A, a_G], ctx)
+    px, fx = _out(mem == DEVICE, batch, Gr, G2, np.complex64, dev)
+    check(c._lib.jstsp_vamp_kron_c32(c.handle, Na, Gr, G2, batch, a_Y.ptr, a_A.ptr,
+                                     _shared_stride(a_A, Na * Gr, batch, "Af"), a_G.ptr,
+                                     _shared_stride(a_G, G2 * G2, batch, "Gb"), float(sigma), float(L), int(nit), px,
+                                     mem), "jstsp_vamp_kron_c32")
+    return fx(not a_Y.batched)

@@ -111,3 +111,36 @@ def test_sparse_admm_config3_shape_batched():
         np.testing.assert_allclose(ce[t], ceo, rtol=5e-3)
     with pytest.raises(J.JstspError):
         J.sparse_admm(H[0], OH[0], D[:, :64], D, 5)          # Gr != Mr is rejected (sparse_admm.m:16,21)
+
+
+def test_vamp_kron_and_dense_track_the_oracle():
+    """VAMP (vamp.m -> VampGlmEst.m).  The reference's configuration (sigma = 1 whatever the noise, no
+    stopping rule) does not converge and amplifies rounding ~1e9 over its 100 iterations (see
+    tests/test_oracle.py), so fp32 is compared per iteration over the first iterations and through the
+    NMSE afterwards."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    from oracle import vamp as V
+    g = load_golden("vamp")
+    sig, L = float(g["sigma"]), int(g["L"])
+    for nit, tol in ((1, 1e-5), (5, 1e-4), (12, 5e-3)):
+        ref = V.vamp_kron(g["Y"], g["A"], g["Gb"], sig, L, nit=nit)
+        out = J.vamp_kron(g["Y"], g["A"], g["Gb"], sig, L, nit=nit)
+        assert rel_err(out, ref) < tol, (nit, rel_err(out, ref))
+    # dense entry point on a small random dictionary == Kronecker form with Gb = 1
+    rng = np.random.default_rng(8)
+    M, N = 20, 48
+    A = (rng.standard_normal((M, N)) + 1j * rng.standard_normal((M, N))) / np.sqrt(M)
+    x0 = np.zeros(N, complex); x0[rng.choice(N, 5, replace=False)] = 3 * (rng.standard_normal(5) + 1j * rng.standard_normal(5))
+    y = A @ x0 + 0.05 * (rng.standard_normal(M) + 1j * rng.standard_normal(M))
+    for nit, tol in ((3, 1e-4), (10, 5e-3)):
+        assert rel_err(J.vamp(y, A, 1.0, 10, nit=nit), V.vamp_literal(y, A, 1.0, 10, nit=nit)) < tol
+    # full 100 iterations: same estimation quality (statistical parity), batched call == per-problem calls
+    X100 = J.vamp_kron(g["Y"], g["A"], g["Gb"], sig, L)
+    ref100 = V.vamp_kron(g["Y"], g["A"], g["Gb"], sig, L)
+    n_gpu, n_ref = O.nmse_capped(np.asarray(X100, complex), g["Zbar"]), O.nmse_capped(ref100, g["Zbar"])
+    assert abs(n_gpu - n_ref) < 0.1 * max(n_ref, 0.05)
+    Yb = np.stack([g["Y"], 0.5 * g["Y"]]); Gbb = np.stack([g["Gb"], g["Gb"]])
+    Xb = J.vamp_kron(Yb, g["A"], Gbb, sig, L, nit=6)
+    assert rel_err(Xb[0], J.vamp_kron(g["Y"], g["A"], g["Gb"], sig, L, nit=6)) < 1e-5
+    assert rel_err(Xb[1], V.vamp_kron(0.5 * g["Y"], g["A"], g["Gb"], sig, L, nit=6)) < 5e-4
