@@ -30,7 +30,8 @@ __device__ __forceinline__ void lds_cgemm(const float2 *A, int sAi, int sAk, con
     constexpr int NBLK = (NE / 32) * (NE / 32);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    for (int blk = wave; blk < NBLK; blk += 4) {
+    const int nwaves = blockDim.x >> 6;
+    for (int blk = wave; blk < NBLK; blk += nwaves) {
         const int i0 = (blk % (NE / 32)) * 32, j0 = (blk / (NE / 32)) * 32;
         f32x16 re, im;
 #pragma unroll
@@ -81,8 +82,8 @@ __device__ __forceinline__ float2 cmulcf(float2 a, float2 b)   // conj(a) * b
     return make_float2(a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x);
 }
 
-template <int NE>
-__global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const float2 *Gpart, long long sGt,
+template <int NE, int NT>
+__global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const float2 *Gpart, long long sGt,
                                                        int nsplit, long long sGs, const TrialParams *prm,
                                                        const float *tau, float2 *Q, float *lam_out,
                                                        float2 *Uwarm, int warm, float conv_tol, int max_sweeps,
@@ -96,12 +97,12 @@ __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const flo
     float2 *T = U + NE * LD;
     float *rot = reinterpret_cast<float *>(T + NE * LD);    // [H][4]: c, wx, wy, (p | q<<16)
     float *red = rot + 4 * H;                               // [8]
-    float *qv = red + 8;                                    // [NE]
+    float *qv = red + 24;                                   // [NE]   (red: [0..3] scalars, [4..19] per-wave)
     const int t = blockIdx.x, tid = threadIdx.x;
     float2 *Uw = Uwarm ? Uwarm + (size_t)t * NE * NE : nullptr;
 
     // ---- load G (sum of split-K partials, zero padded), U (previous basis or identity) ------
-    for (int e = tid; e < NE * NE; e += 256) {
+    for (int e = tid; e < NE * NE; e += NT) {
         const int i = e % NE, j = e / NE;
         float2 g = make_float2(0.f, 0.f);
         if (i < n && j < n) {
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const flo
         __syncthreads();
     }
     // Hermitian-symmetrise (MFMA products are Hermitian only up to rounding)
-    for (int e = tid; e < NE * NE; e += 256) {
+    for (int e = tid; e < NE * NE; e += NT) {
         const int i = e % NE, j = e / NE;
         if (i < j) {
             const float2 u = G[i + LD * j], l = G[j + LD * i];
@@ -137,17 +138,17 @@ __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const flo
     __syncthreads();
     {
         float m = 0.f;
-        for (int i = tid; i < NE; i += 256) m = fmaxf(m, fabsf(G[i + LD * i].x));
+        for (int i = tid; i < NE; i += NT) m = fmaxf(m, fabsf(G[i + LD * i].x));
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if ((tid & 63) == 0) red[4 + (tid >> 6)] = m;
         __syncthreads();
-        if (tid == 0) red[1] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        if (tid == 0) { float mm = red[4]; for (int wv = 1; wv < NT / 64; ++wv) mm = fmaxf(mm, red[4 + wv]); red[1] = mm; }
         __syncthreads();
     }
     const float dmax = red[1];
 
     constexpr int NBLKS = H * H;                       // 2x2 blocks of G per round
-    constexpr int BPT = (NBLKS + 255) / 256;           // blocks per thread
+    constexpr int BPT = (NBLKS + NT - 1) / NT;           // blocks per thread
     const int MAX_SWEEPS = max_sweeps;
     int sweeps_done = 0;
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const flo
             // -- G <- J^H G J on 2x2 blocks (pair a rows, pair b columns); U <- U J on 2 x 2 blocks
 #pragma unroll
             for (int it = 0; it < BPT; ++it) {
-                const int blk = tid + 256 * it;
-                if (NBLKS % 256 != 0 && blk >= NBLKS) break;
+                const int blk = tid + NT * it;
+                if (NBLKS % NT != 0 && blk >= NBLKS) break;
                 const int a = blk % H, b = blk / H;
                 const float4 ra = *reinterpret_cast<const float4 *>(&rot[4 * a]);
                 const float4 rb = *reinterpret_cast<const float4 *>(&rot[4 * b]);
@@ -240,21 +241,21 @@ __global__ __launch_bounds__(256) void jacobi2_kernel(int mode, int n, const flo
     if (sweep_stat && tid == 0) atomicAdd(sweep_stat, sweeps_done);
     if (mode == EIG_LMAX) {
         float m = -1e30f;
-        for (int i = tid; i < n; i += 256) m = fmaxf(m, G[i + LD * i].x);
+        for (int i = tid; i < n; i += NT) m = fmaxf(m, G[i + LD * i].x);
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if ((tid & 63) == 0) red[4 + (tid >> 6)] = m;
         __syncthreads();
-        if (tid == 0) lam_out[t] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        if (tid == 0) { float mm = red[4]; for (int wv = 1; wv < NT / 64; ++wv) mm = fmaxf(mm, red[4 + wv]); lam_out[t] = mm; }
         return;
     }
     // ---- Q = U diag(q) U^H, q_i = min(1, tau/sigma_i); keep U for the next warm start ----------
     const float tv = tau ? tau[t] : prm[t].tauY_rho;
-    for (int i = tid; i < NE; i += 256) {
+    for (int i = tid; i < NE; i += NT) {
         const float sig = sqrtf(fmaxf(G[i + LD * i].x, 0.f));
         qv[i] = (sig > 0.f) ? fminf(1.f, tv / sig) : 1.f;
     }
     __syncthreads();
-    for (int e = tid; e < NE * NE; e += 256) {
+    for (int e = tid; e < NE * NE; e += NT) {
         const int i = e % NE, k = e / NE;
         const float2 u = U[i + LD * k];
         T[i + LD * k] = make_float2(u.x * qv[k], u.y * qv[k]);
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256) void lmax_kernel(int n, const float2 *Gpart, l
 
 template <int NE> static size_t jacobi2_smem()
 {
-    return (size_t)3 * NE * (NE + 1) * sizeof(float2) + (size_t)(4 * (NE / 2) + 8 + NE) * sizeof(float);
+    return (size_t)3 * NE * (NE + 1) * sizeof(float2) + (size_t)(4 * (NE / 2) + 24 + NE) * sizeof(float);
 }
 template <int NE> static size_t lmax_smem()
 {
@@ -439,19 +440,19 @@ template <int NE> static size_t lmax_smem()
            (size_t)(2 * NE + 16) * sizeof(float) + 256 * sizeof(int);
 }
 
-template <int NE>
+template <int NE, int NT>
 static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt,
                             int nsplit, long long sGs, const TrialParams *prm, const float *tau, float2 *Q,
                             float *lam_out, float2 *Uwarm, int warm)
 {
     const size_t sh = jacobi2_smem<NE>();
-    JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi2_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi2_kernel<NE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh));
     static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 3e-7f;
     static const int maxsw = getenv("JSTSP_JACOBI_SWEEPS") ? atoi(getenv("JSTSP_JACOBI_SWEEPS")) : 14;
     static int *stat = nullptr;
     if (getenv("JSTSP_JACOBI_STAT") && !stat) { (void)hipMalloc((void **)&stat, 4); (void)hipMemset(stat, 0, 4); }
-    hipLaunchKernelGGL((jacobi2_kernel<NE>), dim3(batch), dim3(256), sh, ctx->stream, mode, n, Gpart, sGt, nsplit,
+    hipLaunchKernelGGL((jacobi2_kernel<NE, NT>), dim3(batch), dim3(NT), sh, ctx->stream, mode, n, Gpart, sGt, nsplit,
                        sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, stat);
     if (stat) {
         static int calls = 0;
@@ -473,8 +474,8 @@ int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gp
 {
     JSTSP_REQUIRE(n >= 1 && n <= 64, JSTSP_E_UNSUPPORTED, "launch_eig_fast: n = %d > 64", n);
     if (n <= 32)
-        return launch_jacobi2_t<32>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
-    return launch_jacobi2_t<64>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
+        return launch_jacobi2_t<32, 256>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
+    return launch_jacobi2_t<64, 1024>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
 }
 
 int eig_fast_ne(int n) { return n <= 32 ? 32 : 64; }
