@@ -152,13 +152,22 @@ def main():
     n_s, ms_s = ctx.get_profile("synthesize")
     ctx.set_profiling(False)
     flops_per_launch = 8.0 * N * M * G2 * a.batch              # K * B^H, 8 real flops per complex MAC
+    # HBM traffic of the same kernel from the committed PMC measurement (separate rocprofv3 --pmc passes,
+    # FETCH_SIZE doubled as the microarch guide prescribes for gfx950); only valid for the profiled shape
+    traffic = None
+    try:
+        if not a.small and a.batch == 256:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["correlate"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
     roofline = None
     if n_l:
         avg_ms = ms / n_l
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "cgemm_kernel<128, CORRELATE> (K*B^H of A^H K B^H)",
+        roofline = {"bound": "mfma", "kernel": "cgemm_kernel<64, CORRELATE, M64, M3> (K*B^H of A^H K B^H)",
                     "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
                     "flops_per_launch": flops_per_launch,
                     "synthesize_avg_launch_ms": round(ms_s / n_s, 4) if n_s else None}

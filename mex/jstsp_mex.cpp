@@ -160,6 +160,15 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
             plhs[1] = mxCreateDoubleMatrix(Imax, 1, mxREAL);
             memcpy(mxGetDoubles(plhs[1]), ce.data(), ce.size() * sizeof(double));
         }
+    } else if (fn == "vamp") {
+        // (y, A, sigma, L) -> x      benchmark_algorithms/vamp.m:1 (always 100 iterations, VampGlmEst.m:509-511)
+        const int M = (int)mxGetM(prhs[2]), N = (int)mxGetN(prhs[2]);
+        std::vector<jstsp_c32> y, A, x((size_t)N);
+        to_c32(prhs[1], y); to_c32(prhs[2], A);
+        int rc = jstsp_vamp_c32(g_ctx, M, N, 1, y.data(), A.data(), 0, mxGetScalar(prhs[3]), mxGetScalar(prhs[4]), 100,
+                                x.data(), JSTSP_HOST);
+        if (rc) fail("jstsp_vamp_c32", rc);
+        plhs[0] = from_c32(x, N, 1);
     } else {
         mexErrMsgIdAndTxt("jstsp:args", "unknown function '%s'", name);
     }
