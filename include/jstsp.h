@@ -55,8 +55,12 @@ enum { JSTSP_TYPE_APPROXIMATE = 0, JSTSP_TYPE_STD = 1 };
 /* ---- context ---------------------------------------------------------------------- */
 int  jstsp_create(int device_id, jstsp_ctx **out);
 int  jstsp_destroy(jstsp_ctx *ctx);
-/* Use an externally owned hipStream_t (e.g. torch's current stream); NULL = own stream. */
+/* Run on an externally owned hipStream_t (e.g. torch's current stream).  NULL is taken literally: HIP's
+ * default (null) stream.  JSTSP_DEVICE calls are ordered on this stream, so it must be the stream on
+ * which the caller produces the inputs and consumes the outputs. */
 int  jstsp_set_stream(jstsp_ctx *ctx, void *hip_stream);
+/* Back to a private non-blocking stream owned by the context (the state after jstsp_create). */
+int  jstsp_use_own_stream(jstsp_ctx *ctx);
 int  jstsp_synchronize(jstsp_ctx *ctx);
 const char *jstsp_last_error(void);
 const char *jstsp_version(void);

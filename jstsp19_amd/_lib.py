@@ -21,6 +21,7 @@ SIGNATURES = {
     "jstsp_create": (c_int, [c_int, C.POINTER(c_void_p)]),
     "jstsp_destroy": (c_int, [c_void_p]),
     "jstsp_set_stream": (c_int, [c_void_p, c_void_p]),
+    "jstsp_use_own_stream": (c_int, [c_void_p]),
     "jstsp_synchronize": (c_int, [c_void_p]),
     "jstsp_last_error": (C.c_char_p, []),
     "jstsp_version": (C.c_char_p, []),

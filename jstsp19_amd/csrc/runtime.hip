@@ -346,17 +346,27 @@ int jstsp_destroy(jstsp_ctx *ctx)
 
 int jstsp_set_stream(jstsp_ctx *ctx, void *hip_stream)
 {
+    // NULL is a valid handle: HIP's default (null) stream — what torch.cuda.current_stream().cuda_stream
+    // is unless the caller opened a stream context.  The library's work must be ordered on the SAME stream
+    // as the caller's producers / consumers of the device arrays, so it is taken literally.
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
     JSTSP_HIP(hipSetDevice(ctx->device));
+    if (ctx->stream == (hipStream_t)hip_stream && !ctx->own_stream) return 0;
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (hip_stream) {
-        ctx->stream = (hipStream_t)hip_stream;
-        ctx->own_stream = false;
-    } else {
-        JSTSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return 0;
+}
+
+int jstsp_use_own_stream(jstsp_ctx *ctx)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_HIP(hipSetDevice(ctx->device));
+    if (ctx->own_stream) return 0;
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    JSTSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
     return 0;
 }
 

@@ -1,0 +1,100 @@
+"""BASELINE.json full sizes (configs[1]: N=64, M=4096, Gr=64, G2=512), device-resident, checked through
+size-independent properties instead of a CPU recomputation of everything:
+adjointness of correlate / synthesize, linearity, SVT fixed points, ADMM invariants, and a few trials
+against the float64 oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, M, Gr, G2 = 64, 4096, 64, 512
+
+
+def _rnd(g, *s):
+    import torch
+    return torch.complex(torch.randn(*s, generator=g, device="cuda"), torch.randn(*s, generator=g, device="cuda"))
+
+
+def _vdot(a, b):
+    import torch
+    return torch.sum(a.conj().to(torch.complex128) * b.to(torch.complex128), dim=(1, 2))
+
+
+def test_correlate_is_the_adjoint_of_synthesize_and_both_are_linear():
+    """<A^H K B^H, S> = <K, A S B> for every problem (K2' is the adjoint of K2), per-trial B."""
+    import torch
+    import jstsp19_amd as J
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    b = 24
+    cm = J.colmajor
+    K, S = cm(_rnd(g, b, N, M)), cm(_rnd(g, b, Gr, G2))
+    A, B = cm(_rnd(g, N, Gr)), cm(_rnd(g, b, G2, M))
+    C = J.correlate(K, A, B)
+    X = J.synthesize(S, A, B)
+    lhs, rhs = _vdot(C, S), _vdot(K, X)
+    rel = (lhs - rhs).abs() / rhs.abs()
+    assert float(rel.max()) < 2e-5
+    # linearity in the data: correlate(2 K1 - 3j K2) = 2 correlate(K1) - 3j correlate(K2)
+    K2 = cm(_rnd(g, b, N, M))
+    mix = J.correlate(cm(2 * K - 3j * K2), A, B)
+    lin = 2 * C - 3j * J.correlate(K2, A, B)
+    assert float((mix - lin).abs().max() / lin.abs().max()) < 2e-5
+    torch.cuda.synchronize()
+
+
+def test_svt_fixed_points_at_full_size():
+    """svt(Y, 0) = Y; svt is a shrinkage (no singular value grows, Frobenius norm shrinks);
+    svt(svt(Y, tau), 0) = svt(Y, tau); a huge threshold gives 0."""
+    import torch
+    import jstsp19_amd as J
+    g = torch.Generator(device="cuda"); g.manual_seed(12)
+    b = 16
+    Y = J.colmajor(_rnd(g, b, N, M))
+    X0 = J.svt(Y, np.zeros(b))
+    assert float((X0 - Y).abs().max() / Y.abs().max()) < 2e-5
+    sv = torch.linalg.svdvals(Y.to(torch.complex128))
+    tau = (0.5 * sv[:, N // 2]).cpu().numpy()
+    X = J.svt(Y, tau)
+    assert float((J.svt(X, np.zeros(b)) - X).abs().max() / X.abs().max()) < 2e-5
+    svx = torch.linalg.svdvals(X.to(torch.complex128))
+    ref = torch.clamp(sv - torch.from_numpy(tau).cuda()[:, None], min=0)
+    assert float((svx - ref).abs().max() / sv.max()) < 1e-5          # singular values are soft-thresholded
+    assert float(J.svt(Y, 10 * sv[:, 0].cpu().numpy()).abs().max()) < 1e-4 * float(Y.abs().max())
+
+
+def test_proposed_full_size_invariants_and_oracle_sample():
+    """One batched device-resident solve at configs[1]: finite outputs, ce(1,3) = Inf, monotone support growth
+    for _angles, batched == single, and 2 trials against the float64 oracle to |dNMSE| <= 1e-6."""
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import SweepParams, build_inputs, draw_trials
+    from oracle import solvers as O
+    p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=5.0)
+    inp = build_inputs(p, draw_trials(p, [1000, 1001, 1002, 1003], device="cuda"))
+    ty, tz, rho = inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy()
+    S, Y, ce = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], 100, ty, tz, rho, "approximate")
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(S)).all() and torch.isfinite(torch.view_as_real(Y)).all()
+    ce = ce.cpu().numpy()
+    assert np.all(np.isinf(ce[:, 0, 2])) and np.all(np.isfinite(ce[:, 1:, :])) and np.all(ce[:, :, :2] >= 0)
+    S1, _, _ = J.proposed_algorithm(inp["subY"][2:3], inp["Omega"][2:3], inp["A"], inp["B"][2:3], 100, ty[2:3], tz[2:3],
+                                    rho[2:3], "approximate", want_ce=False)
+    assert float((S1[0] - S[2]).abs().max() / S[2].abs().max()) < 1e-5
+    A_h = inp["A"].cpu().numpy().astype(np.complex128)
+    for t in range(2):
+        So, _, _ = O.proposed_algorithm(inp["subY"][t].cpu().numpy().astype(np.complex128),
+                                        inp["Omega"][t].cpu().numpy().astype(np.float64), A_h,
+                                        inp["B"][t].cpu().numpy().astype(np.complex128), 100, float(ty[t]), float(tz[t]),
+                                        float(rho[t]), "approximate", want_ce=False)
+        zb = inp["Zbar"][t].cpu().numpy()
+        Sg = S[t].cpu().numpy().astype(np.complex128)
+        assert abs(O.nmse_capped(Sg, zb) - O.nmse_capped(So, zb)) < 1e-6
+        assert np.max(np.abs(Sg - So)) / np.max(np.abs(So)) < 2e-4
+    # _angles: S is supported inside indx_S(1 : 10 + 5*Imax)
+    Sa, _, _ = J.proposed_algorithm_angles(inp["subY"], inp["Omega"], inp["indx_S"], inp["A"], inp["B"], 20, ty, tz, rho,
+                                           "approximate", None, want_ce=False)
+    torch.cuda.synchronize()
+    for t in range(4):
+        allowed = set((inp["indx_S"][t, :10 + 5 * 20] - 1).cpu().numpy().tolist())
+        nz = set(np.flatnonzero(Sa[t].cpu().numpy().reshape(-1, order="F")).tolist())
+        assert nz <= allowed
