@@ -108,6 +108,12 @@ int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
                                  jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out,
                                  int memspace);
 
+/* S_ls = pinv(A)*Y*pinv(B)   — the LS baseline of the drivers (plot_errorVSsnr.m:83) for full-rank factors
+ * (N >= Gr, M >= G2).  Y: N x M x batch; S_out: Gr x G2 x batch. */
+int jstsp_ls_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *Y,
+                 const jstsp_c32 *A, long long strideA, const jstsp_c32 *B, long long strideB,
+                 jstsp_c32 *S_out, int memspace);
+
 /* X = svt(Y, tau)   benchmark_algorithms/svt.m:1-15.   Y, X: Mr x Mt x batch; tau host double[batch]. */
 int jstsp_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Y,
                   const double *tau, jstsp_c32 *X, int memspace);

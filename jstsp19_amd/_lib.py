@@ -33,6 +33,8 @@ SIGNATURES = {
     "jstsp_proposed_algorithm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                              c_void_p, c_ll, c_void_p, c_ll, c_int, c_dp, c_dp, c_dp, c_int,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "jstsp_ls_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
+                             c_void_p, c_int]),
     "jstsp_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_dp, c_void_p, c_int]),
     "jstsp_omp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p,
                               c_void_p, c_void_p, c_int]),

@@ -161,6 +161,57 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     return 0;
 }
 
+int jstsp_ls_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *Y_, const jstsp_c32 *A_,
+                 long long strideA, const jstsp_c32 *B_, long long strideB, jstsp_c32 *S_out, int memspace)
+{
+    // S_ls = pinv(A)*Y*pinv(B) (plot_errorVSsnr.m:83) for full-rank factors:
+    //   pinv(A) = (A^H A)^-1 A^H (N >= Gr),  pinv(B) = B^H (B B^H)^-1 (M >= G2)
+    //   => S = G_A^-1 (A^H Y B^H) G_B^-1 : the correlation kernel + two small Hermitian inverses.
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_REQUIRE(Y_ && A_ && B_ && S_out, JSTSP_E_NULL, "ls: NULL array argument");
+    JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0, JSTSP_E_SHAPE, "ls: bad shape");
+    JSTSP_REQUIRE(N >= Gr && M >= G2, JSTSP_E_UNSUPPORTED,
+                  "ls: pinv is implemented for full column rank A (N >= Gr) and full row rank B (M >= G2)");
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
+    const int nA = strideA ? batch : 1, nB = strideB ? batch : 1;
+    const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
+    const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
+    size_t need = rnd256(batch * ng * sizeof(float2)) + 3 * rnd256(batch * g * sizeof(float2)) +
+                  2 * rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + 2 * rnd256((size_t)nB * G2 * G2 * sizeof(float2)) +
+                  std::max(hinv_bytes(Gr, nA), hinv_bytes(G2, nB));
+    if (memspace == JSTSP_HOST)
+        need += rnd256(batch * nm * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    Arena &a = ctx->arena;
+    const float2 *Y, *A, *B;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Y_), batch * nm, memspace, &Y));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(B_), szB, memspace, &B));
+    float2 *Tc = a.get<float2>(batch * ng), *R1 = a.get<float2>(batch * g), *R2 = a.get<float2>(batch * g),
+           *S = a.get<float2>(batch * g);
+    float2 *GA = a.get<float2>((size_t)nA * Gr * Gr), *GAi = a.get<float2>((size_t)nA * Gr * Gr);
+    float2 *GB = a.get<float2>((size_t)nB * G2 * G2), *GBi = a.get<float2>((size_t)nB * G2 * G2);
+    JSTSP_REQUIRE(Tc && R1 && R2 && S && GA && GAi && GB && GBi, JSTSP_E_NOMEM, "ls: workspace exhausted");
+    const Mat Am{A, strideA, N}, Bm{B, strideB, G2};
+    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, GA, (long long)Gr * Gr, Gr));
+    JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, GB, (long long)G2 * G2, G2));
+    const size_t mark = a.off;
+    JSTSP_TRY(hermitian_inverse(ctx, Gr, nA, GA, GAi));
+    a.off = mark;
+    JSTSP_TRY(hermitian_inverse(ctx, G2, nB, GB, GBi));
+    a.off = mark;
+    const long long sg = (long long)g, sng = (long long)ng;
+    JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{Y, (long long)nm, N}, Bm, Tc, sng, N, 1.f, nullptr, 0, 0, 0.f,
+                   GEMM_CORRELATE));
+    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{Tc, sng, N}, R1, sg, Gr));
+    JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, Mat{GAi, strideA ? (long long)Gr * Gr : 0, Gr}, Mat{R1, sg, Gr}, R2, sg, Gr));
+    JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{R2, sg, Gr}, Mat{GBi, strideB ? (long long)G2 * G2 : 0, G2}, S, sg, Gr));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), S, batch * g, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int jstsp_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Y_, const double *tau,
                   jstsp_c32 *X_, int memspace)
 {

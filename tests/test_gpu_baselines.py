@@ -144,3 +144,17 @@ def test_vamp_kron_and_dense_track_the_oracle():
     Xb = J.vamp_kron(Yb, g["A"], Gbb, sig, L, nit=6)
     assert rel_err(Xb[0], J.vamp_kron(g["Y"], g["A"], g["Gb"], sig, L, nit=6)) < 1e-5
     assert rel_err(Xb[1], V.vamp_kron(0.5 * g["Y"], g["A"], g["Gb"], sig, L, nit=6)) < 5e-4
+
+
+def test_ls_baseline_matches_pinv():
+    """S_ls = pinv(A)*Y*pinv(B) (plot_errorVSsnr.m:83)."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(5)
+    N, M, Gr, G2, b = 32, 200, 32, 150, 3           # G2 > 128: Newton-Schulz inverse of B B^H
+    A = (rng.standard_normal((N, Gr)) + 1j * rng.standard_normal((N, Gr))) / np.sqrt(N)
+    B = (rng.standard_normal((b, G2, M)) + 1j * rng.standard_normal((b, G2, M))) / np.sqrt(M)
+    Y = rng.standard_normal((b, N, M)) + 1j * rng.standard_normal((b, N, M))
+    S = J.ls_estimate(Y, A, B)
+    for t in range(b):
+        ref = np.linalg.pinv(A) @ Y[t] @ np.linalg.pinv(B[t])
+        assert rel_err(S[t], ref) < 2e-3
