@@ -16,7 +16,7 @@ import torch
 
 from .system_model import SweepParams, build_inputs, draw_trials
 
-__all__ = ["partition", "run_sweep"]
+__all__ = ["partition", "run_sweep", "run_points", "sweep_points"]
 
 
 def partition(n_items, world, rank):
@@ -25,6 +25,37 @@ def partition(n_items, world, rank):
     q, r = divmod(n_items, world)
     lo = rank * q + min(rank, r)
     return lo, lo + q + (1 if rank < r else 0)
+
+
+def sweep_points(base: SweepParams, name, values):
+    """Sweep points of the sibling drivers: vary one parameter of ``base`` —
+    ``snr_db`` (plot_errorVSsnr.m:24,48), ``L`` (plot_errorVSdelays.m:45-51), ``T``
+    (plot_errorVSframelength.m:46-51), ``Mr`` (plot_errorVSnrf.m:46), ``Nt`` (plot_errorVSnt.m:46-52),
+    ``rays`` (plot_errorVSpaths.m:47-51)."""
+    pts = []
+    for v in values:
+        kw = dict(Nt=base.Nt, Nr=base.Nr, L=base.L, T=base.T, Mr=base.Mr, Mr_e=base.Mr_e, Gr=base.Gr, Gt=base.Gt,
+                  clusters=base.clusters, rays=base.rays, snr_db=base.snr_db)
+        kw[name] = v
+        if name == "Nt":
+            kw["Gt"] = v                      # the drivers keep Gt = Nt
+        pts.append(SweepParams(**kw))
+    return pts
+
+
+def _hip_baselines(inp, numOfnz):
+    """LS and VAMP baselines of plot_errorVSsnr.m:73-105 on the conventional-HBF measurement."""
+    from . import solvers as J
+    zb = J.colmajor(inp["Zbar"].to(torch.complex64))
+    S_ls = J.ls_estimate(inp["Y_hbf"], inp["A_hbf"], inp["B_hbf"])                       # :83
+    out = {"ls": J.nmse_spectral(S_ls, zb)}
+    G2 = inp["B_hbf"].shape[1]
+    if G2 <= 128 and inp["A_hbf"].shape[0] <= 128:
+        Bh = inp["B_hbf"]
+        Gb = J.colmajor(Bh @ Bh.conj().transpose(1, 2))                                  # (B*B')  :79
+        Ym = J.colmajor(inp["Y_hbf"] @ Bh.conj().transpose(1, 2))                        # Y_hbf*B' :80
+        out["vamp"] = J.nmse_spectral(J.vamp_kron(Ym, inp["A_hbf"], Gb, 1.0, numOfnz), zb)   # :100
+    return out
 
 
 def _hip_solvers(device):
@@ -43,13 +74,14 @@ def _hip_solvers(device):
     return solve
 
 
-def run_sweep(base: SweepParams, snr_db_list, n_trials, *, Imax=100, batch=64, seed=20190913, device=None,
-              solve_fn=None, dist=None):
-    """Mean capped NMSE per sweep point for (proposed_algorithm, proposed_algorithm_angles).
+def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=None, solve_fn=None, dist=None,
+               baselines=False, numOfnz=100):
+    """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP]).
 
-    ``solve_fn(inputs, Imax) -> (nmse, nmse_angles)`` (two tensors of per-trial NMSE) defaults to
-    the HIP path.  ``dist``: ``torch.distributed`` (initialised) or None for a single process.
-    Returns a float64 tensor (len(snr_db_list), 2) identical on every rank.
+    ``solve_fn(inputs, Imax) -> (nmse, nmse_angles)`` (two tensors of per-trial NMSE) defaults to the HIP path.
+    ``baselines=True`` adds the LS and VAMP columns of plot_errorVSsnr.m:83-105 (HIP path only; VAMP is NaN
+    where the factor orders exceed 128).  ``dist``: ``torch.distributed`` (initialised) or None.
+    Returns a float64 tensor (len(points), ncol) identical on every rank.
     """
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
@@ -57,25 +89,34 @@ def run_sweep(base: SweepParams, snr_db_list, n_trials, *, Imax=100, batch=64, s
         device = torch.device("cuda", torch.cuda.current_device())
     if solve_fn is None:
         solve_fn = _hip_solvers(device)
-    n_pts = len(snr_db_list)
+    n_pts = len(points)
+    ncol = 4 if baselines else 2
     lo, hi = partition(n_pts * n_trials, world, rank)
-    acc = torch.zeros((n_pts, 3), dtype=torch.float64)          # sum nmse, sum nmse_angles, count
+    acc = torch.zeros((n_pts, ncol + 1), dtype=torch.float64)   # sums per column, then the trial count
     item = lo
     while item < hi:
         pt = item // n_trials
         t0 = item % n_trials
         t1 = min(n_trials, t0 + batch, t0 + (hi - item))
-        p = SweepParams(base.Nt, base.Nr, base.L, base.T, base.Mr, base.Mr_e, base.Gr, base.Gt, base.clusters,
-                        base.rays, snr_db=float(snr_db_list[pt]))
+        p = points[pt]
         draws = draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
-        inp = build_inputs(p, draws)
+        inp = build_inputs(p, draws, with_hbf=baselines)
         e, ea = solve_fn(inp, Imax)
         acc[pt, 0] += float(torch.as_tensor(e).double().sum())
         acc[pt, 1] += float(torch.as_tensor(ea).double().sum())
-        acc[pt, 2] += t1 - t0
+        if baselines:
+            b = _hip_baselines(inp, numOfnz)
+            acc[pt, 2] += float(b["ls"].double().sum())
+            acc[pt, 3] += float(b["vamp"].double().sum()) if "vamp" in b else float("nan")
+        acc[pt, ncol] += t1 - t0
         item += t1 - t0
     if dist is not None:
         buf = acc.to(device) if dist.get_backend() == "nccl" else acc
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # the single collective of the sweep
         acc = buf.cpu()
-    return acc[:, :2] / acc[:, 2:3]                      # plot_errorVSsnr.m:170-171
+    return acc[:, :ncol] / acc[:, ncol:ncol + 1]         # plot_errorVSsnr.m:170-171
+
+
+def run_sweep(base: SweepParams, snr_db_list, n_trials, **kw):
+    """The SNR sweep of plot_errorVSsnr.m:48-180 (see ``run_points``)."""
+    return run_points(sweep_points(base, "snr_db", [float(s) for s in snr_db_list]), n_trials, **kw)

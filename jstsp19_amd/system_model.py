@@ -40,6 +40,11 @@ class SweepParams:
         return 10.0 ** (-self.snr_db / 10.0)
 
     @property
+    def T_hbf(self):                        # plot_errorVSsnr.m:22 — MATLAB round() is half away from zero
+        x = self.T / (self.Nr / self.Mr)
+        return int(math.floor(abs(x) + 0.5) * (1 if x >= 0 else -1)) * self.Nt
+
+    @property
     def solver_shape(self):
         """(N, M, Gr, G2) of the proposed_algorithm call."""
         return self.Mr_e, self.T_prop, self.Gr, self.L * self.Gt
@@ -110,7 +115,7 @@ def _laplacian(u):
     return beta * (math.exp(-math.sqrt(2.0) / 50.0 * math.pi) - torch.cosh(u))
 
 
-def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64):
+def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=False):
     """plot_errorVSsnr.m:57-136 for a batch of trials.
 
     Returns a dict of device tensors, matrices column-major per problem as the C ABI wants:
@@ -165,6 +170,18 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64):
     B = torch.einsum("sh,tsjl->tlhj", Dt.conj(), Psi_bar).reshape(T, p.L * p.Gt, Tp)   # rows l*Gt + h
     absz = Zbar.transpose(1, 2).reshape(T, -1).abs()                            # vec order (column-major)
     indx_S = (torch.argsort(absz, dim=1, descending=True, stable=True) + 1).to(torch.int32)
-    return dict(subY=colmajor(subY.to(out_dtype)), Omega=colmajor(Omega.to(torch.float32)),
+    extra = {}
+    if with_hbf:
+        # conventional HBF with all Nr RF chains over a shorter frame (plot_errorVSsnr.m:73-80, hbf.m:1-26)
+        Th = p.T_hbf
+        Wc = zc_beamformer(p.Nr, dev)                                           # Mr_hbf = Nr columns (:11,:73)
+        Psi_c = Psi_bar[:, :, :Th, :]                                           # Psi_i(1:T_hbf,1:T_hbf,:) rows 1..L
+        Rc = torch.einsum("trsl,tsjl->trj", H, Psi_c) + math.sqrt(p.noise_var / 2.0) * draws["noise"][:, :, :Th]
+        Y_hbf = torch.einsum("re,trj->tej", Wc.conj(), Rc)                      # hbf.m:24
+        A_hbf = Wc.conj().transpose(0, 1) @ Dr                                  # :74
+        B_hbf = torch.einsum("sh,tsjl->tlhj", Dt.conj(), Psi_c).reshape(T, p.L * p.Gt, Th)   # :75-78
+        extra = dict(Y_hbf=colmajor(Y_hbf.to(out_dtype)), A_hbf=colmajor(A_hbf.to(out_dtype)),
+                     B_hbf=colmajor(B_hbf.to(out_dtype)))
+    return dict(**extra, subY=colmajor(subY.to(out_dtype)), Omega=colmajor(Omega.to(torch.float32)),
                 A=colmajor(A.to(out_dtype)), B=colmajor(B.to(out_dtype)), Zbar=Zbar, H=H,
                 tau_Y=tau_Y.cpu(), tau_Z=tau_Z.cpu(), rho=rho.cpu(), indx_S=indx_S)

@@ -151,3 +151,36 @@ def test_proposed_std_type_matches_golden_and_oracle():
     assert rel_err(Sg, So) < 1e-3 and rel_err(Yg, Yo) < 1e-3
     with pytest.raises(J.JstspError):                    # under-determined K2 is refused, not approximated
         J.proposed_algorithm(subY[:, :100], Om[:, :100], A, B[:, :100], 5, 0.01, 0.02, 0.3, "std")
+
+
+def test_sweep_runner_on_hip_matches_oracle_per_point():
+    """montecarlo.run_sweep (the plot_errorVSsnr.m:48-180 counterpart) with the HIP solvers vs the same
+    sweep with the oracle as solver: identical trials (RNG keyed by global ids) => identical means to 1e-6."""
+    import torch
+    from jstsp19_amd.montecarlo import run_sweep
+    from jstsp19_amd.system_model import SweepParams
+    from oracle import solvers as O
+
+    def oracle_solve(inp, Imax):
+        e, ea = [], []
+        A = inp["A"].cpu().numpy().astype(complex)
+        for t in range(inp["subY"].shape[0]):
+            args = (inp["subY"][t].cpu().numpy().astype(complex), inp["Omega"][t].cpu().numpy().astype(float), A,
+                    inp["B"][t].cpu().numpy().astype(complex), Imax, float(inp["tau_Y"][t]), float(inp["tau_Z"][t]),
+                    float(inp["rho"][t]), "approximate")
+            S, _, _ = O.proposed_algorithm(*args, want_ce=False)
+            Sa, _, _ = O.proposed_algorithm(*args, indx_S=inp["indx_S"][t].cpu().numpy(), want_ce=False)
+            zb = inp["Zbar"][t].cpu().numpy()
+            e.append(O.nmse_capped(S, zb)); ea.append(O.nmse_capped(Sa, zb))
+        return torch.tensor(e), torch.tensor(ea)
+
+    base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)
+    dev = torch.device("cuda:0")
+    hip = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev).numpy()
+    ref = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev, solve_fn=oracle_solve).numpy()
+    np.testing.assert_allclose(hip, ref, atol=1e-6)
+    assert hip.shape == (3, 2) and np.all(hip[:, 1] <= hip[:, 0] + 1e-3)      # angle information helps
+    # with the conventional-HBF baselines (LS, VAMP) as extra columns
+    full = run_sweep(base, [3], 4, Imax=100, batch=4, device=dev, baselines=True).numpy()
+    assert full.shape == (1, 4) and np.all(np.isfinite(full)) and np.all(full > 0) and np.all(full <= 1)
+    np.testing.assert_allclose(full[0, :2], run_sweep(base, [3], 4, Imax=100, batch=4, device=dev).numpy()[0], atol=1e-7)

@@ -53,3 +53,36 @@ def test_colmajor_layout_of_outputs():
     assert out["subY"].shape == (2, N, M) and out["subY"].stride() == (N * M, 1, N)
     assert out["B"].shape == (2, G2, M) and out["B"].stride() == (G2 * M, 1, G2)
     assert out["A"].shape == (N, Gr) and out["A"].stride() == (1, N)
+
+
+def test_conventional_hbf_inputs_match_oracle():
+    """hbf.m + plot_errorVSsnr.m:73-80 (the LS / VAMP baselines' measurement)."""
+    p = SweepParams(Nt=4, Nr=16, L=3, T=12, Mr=4, snr_db=0.0)
+    assert p.T_hbf == 3 * 4                                    # round(12/(16/4)) * Nt
+    assert SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4).T_hbf == 16   # round(4.375) = 4 (plot_errorVSsnr.m:22)
+    assert SweepParams(Nt=2, Nr=8, L=2, T=10, Mr=2).T_hbf == 3 * 2    # round(2.5) = 3: half AWAY from zero
+    draws = draw_trials(p, [3, 4], seed=9, device="cpu")
+    out = build_inputs(p, draws, out_dtype=torch.complex128, with_hbf=True)
+    for t in range(2):
+        d = _to_np(draws, t)
+        H = out["H"][t].numpy()
+        Psi_rows = np.stack([osm.toeplitz_rows(osm.qam4_alphabet()[d["qam_idx"][k]], p.L) for k in range(p.Nt)], axis=2)
+        Nn = np.sqrt(p.noise_var / 2) * d["noise"]
+        Th = p.T_hbf
+        Yc, Wc, Psi_bar, _ = osm.hbf(H, Nn[:, :Th], Psi_rows[:, :Th, :], Th, p.Nr, osm.create_beamformer(p.Nr, "ZC"))
+        Dr = np.exp(-2j * np.pi * np.outer(np.arange(p.Nr), np.arange(p.Gr)) / p.Gr) / np.sqrt(p.Nr)
+        Dt = np.exp(-2j * np.pi * np.outer(np.arange(p.Nt), np.arange(p.Gt)) / p.Gt) / np.sqrt(p.Nt)
+        np.testing.assert_allclose(out["Y_hbf"][t].numpy(), Yc, atol=1e-11)
+        np.testing.assert_allclose(out["A_hbf"].numpy(), Wc.conj().T @ Dr, atol=1e-12)
+        Bc = np.concatenate([Dt.conj().T @ Psi_bar[:, :, l] for l in range(p.L)])
+        np.testing.assert_allclose(out["B_hbf"][t].numpy(), Bc, atol=1e-12)
+
+
+def test_sweep_points_of_the_sibling_drivers():
+    from jstsp19_amd.montecarlo import sweep_points
+    base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)
+    pts = sweep_points(base, "L", [1, 3, 5])
+    assert [q.L for q in pts] == [1, 3, 5] and all(q.Nt == 4 and q.solver_shape[3] == q.L * 4 for q in pts)
+    pts = sweep_points(base, "Nt", [2, 8])
+    assert [q.Gt for q in pts] == [2, 8]
+    assert [q.snr_db for q in sweep_points(base, "snr_db", [-15, 0, 15])] == [-15.0, 0.0, 15.0]
