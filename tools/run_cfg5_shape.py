@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] shape for proposed_algorithm_angles: Nt=256, Nr=64, L=16, T=256 ->
+N=64, M=65536, Gr=64, G2=4096 (B is 2 GiB per pilot set: pilots shared by the batch here).
+Functional run with invariants (the float64 oracle would need ~30 TFLOP per trial on the host)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import jstsp19_amd as J
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+N, M, Gr, G2 = 64, 65536, 64, 4096
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(5)
+rnd = lambda *s: torch.complex(torch.randn(*s, generator=g, device=dev), torch.randn(*s, generator=g, device=dev))
+cm = J.colmajor
+A = cm(rnd(N, Gr) / np.sqrt(N))
+B = cm(rnd(G2, M) / np.sqrt(G2))                      # shared pilots
+S0 = torch.zeros(batch, Gr, G2, dtype=torch.complex64, device=dev)
+idx = torch.randint(0, Gr * G2, (batch, 40), generator=g, device=dev)
+S0.view(batch, -1).scatter_(1, idx, rnd(batch, 40))
+Om = (torch.rand(batch, N, M, generator=g, device=dev) < 0.125).float()
+X = torch.empty(batch, N, M, dtype=torch.complex64, device=dev)
+for t in range(batch):
+    X[t] = A @ S0[t] @ B
+subY = Om * (X + 0.05 * rnd(batch, N, M))
+del X
+indx = (torch.argsort(S0.transpose(1, 2).reshape(batch, -1).abs(), dim=1, descending=True, stable=True) + 1).to(torch.int32)
+fro2 = (subY.abs() ** 2).sum(dim=(1, 2)).double().cpu().numpy()
+tY = 1.0 / fro2; tS = np.full(batch, 1e-3); rho = np.full(batch, 0.2)
+t0 = time.perf_counter()
+S, Y, ce = J.proposed_algorithm_angles(cm(subY), cm(Om), indx, A, B, 20, tY, tS, rho, "approximate", None)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("config-5 shape, batch %d, 20 iterations: %.2f s; workspace %.1f GiB" % (batch, dt, J.default_context(0).workspace_bytes() / 2**30))
+assert torch.isfinite(torch.view_as_real(S)).all() and torch.isfinite(torch.view_as_real(Y)).all()
+ce = ce.cpu().numpy(); assert np.all(np.isinf(ce[:, 0, 2])) and np.all(np.isfinite(ce[:, 1:, :]))
+for t in range(batch):
+    allowed = set((indx[t, :10 + 5 * 20] - 1).cpu().numpy().tolist())
+    nz = set(np.flatnonzero(S[t].cpu().numpy().reshape(-1, order="F")).tolist())
+    assert nz <= allowed
+S1, _, _ = J.proposed_algorithm_angles(cm(subY[:1]), cm(Om[:1]), indx[:1], A, B, 20, tY[:1], tS[:1], rho[:1], "approximate", None, want_ce=False)
+print("batched vs single rel diff: %.2e" % float((S1[0] - S[0]).abs().max() / S[0].abs().max()))
+err = float((S - S0).abs().max() / S0.abs().max())
+print("recovery: max |S - S0| / max |S0| after 20 iterations = %.3f ; ce(20,:) = %s" % (err, ce[0, -1]))
