@@ -171,6 +171,47 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
 int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S,
                             const jstsp_c32 *Zbar, double *nmse, int memspace);
 
+/* ---- device-side construction of the solver inputs (the caller side of the path) ------------
+ * plot_errorVSsnr.m:57-136 for trials [trial0, trial0 + batch) of sweep point `sweep_idx`:
+ * channel (wideband_mmwave_channel.m:1-39), 4-QAM Toeplitz pilots (qam4mod.m:7-8, plot_errorVSsnr.m:63-67),
+ * noise (:60), random spatial sampling (proposed_hbf.m:1-44), A and B (:132-136), tau_Y / tau_Z / rho
+ * (:127-130, rho from the 6th largest eigenvalue as eigs() returns it) and indx_S (:143).
+ * Random numbers: Philox4x32-10 keyed by (seed, sweep_idx, global trial index) - independent of
+ * batch and of the sharding over GPUs. */
+typedef struct jstsp_model {
+    int Nt, Nr, L;          /* antennas, delay taps                                  plot_errorVSsnr.m:8-12 */
+    int T_prop;             /* training length of the proposed scheme (T*Nt)         :23                     */
+    int Mr, Mr_e;           /* RF chains sampled per slot / extended                 :15-16                  */
+    int Gr, Gt;             /* dictionary sizes                                      :13-14                  */
+    int clusters, rays;     /* total_num_of_clusters, total_num_of_rays              :18-19                  */
+    int T_hbf;              /* training length of the conventional HBF baseline (0 = not wanted) :22         */
+    double noise_var;       /* 10^(-snr_db/10)                                       :49                     */
+} jstsp_model;
+
+/* Output arrays of jstsp_build_trials_c32 (NULL = not wanted); column-major per trial, trial index last.
+ * With N = Mr_e, M = T_prop, G2 = L*Gt, Np = clusters*rays: */
+typedef struct jstsp_trials {
+    jstsp_c32 *subY;        /* N x M x batch                                                                  */
+    float *Omega;           /* N x M x batch                                                                  */
+    jstsp_c32 *A;           /* N x Gr        (trial-independent: ZC beamformer x DFT dictionary)              */
+    jstsp_c32 *B;           /* G2 x M x batch                                                                 */
+    jstsp_c32 *Zbar;        /* Gr x G2 x batch   the true angle-delay channel [Z_1 ... Z_L]                   */
+    jstsp_c32 *H;           /* Nr x (Nt*L) x batch   [H_1 ... H_L]                                            */
+    int32_t *indx_S;        /* (Gr*G2) x batch, 1-based: stable descending order of |vec(Zbar)|               */
+    double *tau_Y, *tau_Z, *rho;   /* batch each, HOST memory in either memspace                              */
+    jstsp_c32 *Y_hbf;       /* Nr x T_hbf x batch    hbf.m:24                                                 */
+    jstsp_c32 *A_hbf;       /* Nr x Gr               plot_errorVSsnr.m:74                                     */
+    jstsp_c32 *B_hbf;       /* G2 x T_hbf x batch    :75-78 (requires B)                                      */
+    /* the raw draws, for checking the construction against a CPU restatement */
+    jstsp_c32 *gains;       /* (L*Np) x batch, index l*Np + p                                                 */
+    float *u_r, *u_t;       /* Np x batch     uniform draws of tap 1's angle samplers                         */
+    jstsp_c32 *noise;       /* Nr x T_prop x batch   randn + 1j*randn, unscaled                               */
+    uint8_t *qam_idx;       /* batch x Nt x T_prop (row-major), values 0..3 in the alphabet order of qam4mod.m:7 */
+} jstsp_trials;
+
+int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *model, uint64_t seed, int sweep_idx,
+                           long long trial0, int batch, const jstsp_trials *out, int memspace);
+
 /* Per-kernel timing of the last proposed_algorithm call made with profiling enabled:
  * jstsp_set_profiling(ctx, 1) brackets every launch of the dominant kernel with HIP
  * events on the context's stream; jstsp_get_profile() returns launches and total ms. */

@@ -16,6 +16,21 @@ TYPE_APPROXIMATE, TYPE_STD = 0, 1
 
 c_void_p, c_int, c_ll, c_dp, c_ip = C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_int)
 
+
+
+class Model(C.Structure):
+    """struct jstsp_model (include/jstsp.h)."""
+    _fields_ = [(n, c_int) for n in ("Nt", "Nr", "L", "T_prop", "Mr", "Mr_e", "Gr", "Gt", "clusters", "rays",
+                                     "T_hbf")] + [("noise_var", C.c_double)]
+
+
+class Trials(C.Structure):
+    """struct jstsp_trials (include/jstsp.h): output pointers, NULL = not wanted."""
+    _fields_ = [(n, c_void_p) for n in ("subY", "Omega", "A", "B", "Zbar", "H", "indx_S")] + \
+               [(n, c_dp) for n in ("tau_Y", "tau_Z", "rho")] + \
+               [(n, c_void_p) for n in ("Y_hbf", "A_hbf", "B_hbf", "gains", "u_r", "u_t", "noise", "qam_idx")]
+
+
 # name -> (restype, argtypes); mirrors include/jstsp.h one to one
 SIGNATURES = {
     "jstsp_create": (c_int, [c_int, C.POINTER(c_void_p)]),
@@ -51,6 +66,8 @@ SIGNATURES = {
     "jstsp_vamp_kron_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
                                     C.c_double, C.c_double, c_int, c_void_p, c_int]),
     "jstsp_nmse_spectral_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),
+    "jstsp_build_trials_c32": (c_int, [c_void_p, C.POINTER(Model), C.c_uint64, c_int, c_ll, c_int, C.POINTER(Trials),
+                                       c_int]),
     "jstsp_set_profiling": (c_int, [c_void_p, c_int]),
     "jstsp_get_profile": (c_int, [c_void_p, C.c_char_p, c_ip, c_dp]),
 }

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import torch
 
-from .system_model import SweepParams, build_inputs, draw_trials
+from .system_model import SweepParams, build_inputs, build_trials, draw_trials
 
 __all__ = ["partition", "run_sweep", "run_points", "sweep_points"]
 
@@ -75,18 +75,25 @@ def _hip_solvers(device):
 
 
 def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=None, solve_fn=None, dist=None,
-               baselines=False, numOfnz=100):
+               baselines=False, numOfnz=100, builder=None):
     """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP]).
 
     ``solve_fn(inputs, Imax) -> (nmse, nmse_angles)`` (two tensors of per-trial NMSE) defaults to the HIP path.
     ``baselines=True`` adds the LS and VAMP columns of plot_errorVSsnr.m:83-105 (HIP path only; VAMP is NaN
     where the factor orders exceed 128).  ``dist``: ``torch.distributed`` (initialised) or None.
+    ``builder``: "hip" — inputs from the library's own kernels (``jstsp_build_trials_c32``; the default with
+    the HIP solvers) or "torch" — the tensor-op builder (the default with a custom ``solve_fn``, runs on CPU too).
+    The two use different generators, so their curves agree statistically, not sample by sample.
     Returns a float64 tensor (len(points), ncol) identical on every rank.
     """
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
+    if builder is None:
+        builder = "hip" if solve_fn is None else "torch"
+    if builder not in ("hip", "torch"):
+        raise ValueError("builder must be 'hip' or 'torch'")
     if solve_fn is None:
         solve_fn = _hip_solvers(device)
     n_pts = len(points)
@@ -99,8 +106,11 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
         t0 = item % n_trials
         t1 = min(n_trials, t0 + batch, t0 + (hi - item))
         p = points[pt]
-        draws = draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
-        inp = build_inputs(p, draws, with_hbf=baselines)
+        if builder == "hip":
+            inp = build_trials(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device, with_hbf=baselines)
+        else:
+            draws = draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
+            inp = build_inputs(p, draws, with_hbf=baselines)
         e, ea = solve_fn(inp, Imax)
         acc[pt, 0] += float(torch.as_tensor(e).double().sum())
         acc[pt, 1] += float(torch.as_tensor(ea).double().sum())

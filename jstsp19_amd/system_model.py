@@ -17,7 +17,7 @@ import math
 
 import torch
 
-__all__ = ["SweepParams", "draw_trials", "build_inputs", "zc_beamformer", "dft_dictionary"]
+__all__ = ["SweepParams", "draw_trials", "build_inputs", "build_trials", "zc_beamformer", "dft_dictionary"]
 
 
 class SweepParams:
@@ -185,3 +185,55 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=Fals
     return dict(**extra, subY=colmajor(subY.to(out_dtype)), Omega=colmajor(Omega.to(torch.float32)),
                 A=colmajor(A.to(out_dtype)), B=colmajor(B.to(out_dtype)), Zbar=Zbar, H=H,
                 tau_Y=tau_Y.cpu(), tau_Z=tau_Z.cpu(), rho=rho.cpu(), indx_S=indx_S)
+
+
+def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, device=None, with_hbf=False,
+                 want_draws=False, want_H=False, ctx=None):
+    """plot_errorVSsnr.m:57-136 for trials [trial0, trial0 + batch) on the HIP path
+    (``jstsp_build_trials_c32``, csrc/inputgen.hip): draws, channel, pilots, measurement, A, B,
+    hyper-parameters and indx_S are produced by the library's own kernels — nothing but the output
+    allocation goes through torch.  Same dict as ``build_inputs`` (Zbar complex64, column-major);
+    ``want_draws`` adds the raw draws (gains, u_r, u_t, noise, qam_idx) for checking against a CPU
+    restatement.  The Philox streams are keyed by (seed, sweep_idx, global trial index).
+    """
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    from .solvers import empty_colmajor
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    c = ctx if ctx is not None else _lib.default_context(device.index or 0)
+    c.use_torch_stream()
+    N, M, Gr, G2 = p.solver_shape
+    Np = p.clusters * p.rays
+    Th = p.T_hbf if with_hbf else 0
+    model = _lib.Model(p.Nt, p.Nr, p.L, p.T_prop, p.Mr, p.Mr_e, p.Gr, p.Gt, p.clusters, p.rays, Th, p.noise_var)
+    c64, f32 = torch.complex64, torch.float32
+    out = dict(subY=empty_colmajor(batch, N, M, c64, device), Omega=empty_colmajor(batch, N, M, f32, device),
+               A=empty_colmajor(1, N, Gr, c64, device)[0], B=empty_colmajor(batch, G2, M, c64, device),
+               Zbar=empty_colmajor(batch, Gr, G2, c64, device),
+               indx_S=torch.empty((batch, Gr * G2), dtype=torch.int32, device=device))
+    if want_H:
+        out["H"] = empty_colmajor(batch, p.Nr, p.Nt * p.L, c64, device)
+    if with_hbf:
+        out["Y_hbf"] = empty_colmajor(batch, p.Nr, Th, c64, device)
+        out["A_hbf"] = empty_colmajor(1, p.Nr, Gr, c64, device)[0]
+        out["B_hbf"] = empty_colmajor(batch, G2, Th, c64, device)
+    if want_draws:
+        out["gains"] = torch.empty((batch, p.L, Np), dtype=c64, device=device)
+        out["u_r"] = torch.empty((batch, Np), dtype=f32, device=device)
+        out["u_t"] = torch.empty((batch, Np), dtype=f32, device=device)
+        out["noise"] = empty_colmajor(batch, p.Nr, p.T_prop, c64, device)
+        out["qam_idx"] = torch.empty((batch, p.Nt, p.T_prop), dtype=torch.uint8, device=device)
+    hyp = {k: np.empty(batch, dtype=np.float64) for k in ("tau_Y", "tau_Z", "rho")}
+    tr = _lib.Trials()
+    for k, v in out.items():
+        setattr(tr, k, v.data_ptr())
+    for k, v in hyp.items():
+        setattr(tr, k, v.ctypes.data_as(C.POINTER(C.c_double)))
+    rc = c._lib.jstsp_build_trials_c32(c.handle, C.byref(model), C.c_uint64(seed), int(sweep_idx), int(trial0),
+                                       int(batch), C.byref(tr), _lib.DEVICE)
+    _lib.check(rc, "jstsp_build_trials_c32")
+    out.update({k: torch.from_numpy(v) for k, v in hyp.items()})
+    return out

@@ -10,13 +10,14 @@ from jstsp19_amd.system_model import SweepParams
 ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=64)
 ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--builder", default="hip", choices=["hip", "torch"])
 a = ap.parse_args()
 base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)              # plot_errorVSsnr.m:8-23
 snrs = list(range(-15, 16, 3))                                  # :24
 t0 = time.perf_counter()
-out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, numOfnz=100)
+out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, numOfnz=100, builder=a.builder)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("SNR(dB)  proposed  proposed+angles  LS        VAMP      (%d trials/point, %.1f s)" % (a.trials, dt))
+print("SNR(dB)  proposed  proposed+angles  LS        VAMP      (%d trials/point, %s input builder, %.1f s)" % (a.trials, a.builder, dt))
 for s, row in zip(snrs, out.tolist()):
     print("%6d   %.5f   %.5f          %.5f   %.5f" % (s, *row))
