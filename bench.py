@@ -52,31 +52,12 @@ def parse():
     return ap.parse_args()
 
 
-def make_inputs(p, trial_ids, device, chunk=16):
-    """Build the batch's solver inputs chunk by chunk directly into column-major buffers."""
-    from jstsp19_amd.solvers import empty_colmajor
-    from jstsp19_amd.system_model import build_inputs, draw_trials
-    T = len(trial_ids)
-    N, M, Gr, G2 = p.solver_shape
-    subY = empty_colmajor(T, N, M, torch.complex64, device)
-    Omega = empty_colmajor(T, N, M, torch.float32, device)
-    B = empty_colmajor(T, G2, M, torch.complex64, device)
-    Zbar = torch.empty((T, Gr, G2), dtype=torch.complex128, device=device)
-    tY, tZ, rho = [], [], []
-    A = None
-    for i in range(0, T, chunk):
-        ids = trial_ids[i:i + chunk]
-        o = build_inputs(p, draw_trials(p, ids, device=device))
-        subY[i:i + len(ids)] = o["subY"]
-        Omega[i:i + len(ids)] = o["Omega"]
-        B[i:i + len(ids)] = o["B"]
-        Zbar[i:i + len(ids)] = o["Zbar"]
-        tY.append(o["tau_Y"]); tZ.append(o["tau_Z"]); rho.append(o["rho"])
-        A = o["A"]
-        del o
-    torch.cuda.empty_cache()
-    return dict(subY=subY, Omega=Omega, A=A, B=B, Zbar=Zbar, tau_Y=torch.cat(tY).numpy(),
-                tau_Z=torch.cat(tZ).numpy(), rho=torch.cat(rho).numpy())
+def make_inputs(p, trial_ids, device):
+    """The batch's solver inputs, built in HBM by the library's own kernels (jstsp_build_trials_c32)."""
+    from jstsp19_amd.system_model import build_trials
+    o = build_trials(p, trial_ids[0], len(trial_ids), device=device)
+    return dict(subY=o["subY"], Omega=o["Omega"], A=o["A"], B=o["B"], Zbar=o["Zbar"], tau_Y=o["tau_Y"].numpy(),
+                tau_Z=o["tau_Z"].numpy(), rho=o["rho"].numpy())
 
 
 def main():
