@@ -105,6 +105,17 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         int rc = jstsp_svt_c32(g_ctx, Mr, Mt, 1, Y.data(), &tau, X.data(), JSTSP_HOST);
         if (rc) fail("jstsp_svt_c32", rc);
         plhs[0] = from_c32(X, Mr, Mt);
+    } else if (fn == "ls") {
+        // (Y, A, B) -> pinv(A)*Y*pinv(B)   (plot_errorVSsnr.m:83)
+        const int N = (int)mxGetM(prhs[1]), M = (int)mxGetN(prhs[1]);
+        const int Gr = (int)mxGetN(prhs[2]), G2 = (int)mxGetM(prhs[3]);
+        if ((int)mxGetM(prhs[2]) != N || (int)mxGetN(prhs[3]) != M)
+            mexErrMsgIdAndTxt("jstsp:shape", "ls: inconsistent dimensions");
+        std::vector<jstsp_c32> Y, A, B, S((size_t)Gr * G2);
+        to_c32(prhs[1], Y); to_c32(prhs[2], A); to_c32(prhs[3], B);
+        int rc = jstsp_ls_c32(g_ctx, N, M, Gr, G2, 1, Y.data(), A.data(), 0, B.data(), 0, S.data(), JSTSP_HOST);
+        if (rc) fail("jstsp_ls_c32", rc);
+        plhs[0] = from_c32(S, Gr, G2);
     } else if (fn == "OMP") {
         // (A, v, m, snr) -> [x_hat, indexSet (1 x m cell), v, targetMatrix]
         const int meas = (int)mxGetM(prhs[1]), size_d = (int)mxGetN(prhs[1]);
