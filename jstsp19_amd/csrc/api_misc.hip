@@ -109,6 +109,9 @@ int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
     const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
     const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
     size_t need = rnd256(batch * ng * sizeof(float2)) + rnd256(batch * g * sizeof(float2));
+    const bool h2 = use_hgemm(N, G2, M);
+    const int nB = strideB ? batch : 1;
+    if (h2) need += hgemm_pack_bytes(M, G2, nB) + rnd256(batch * sizeof(uint32_t));
     if (memspace == JSTSP_HOST)
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -121,6 +124,17 @@ int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
     float2 *O = ctx->arena.get<float2>(batch * g);
     JSTSP_REQUIRE(Tc && O, JSTSP_E_NOMEM, "correlate: workspace exhausted");
     // A^H (K B^H): the cheaper association (N*M*G2 + Gr*N*G2 MACs)
+    if (h2) {
+        // b(k = m, j = g) = conj(B[g + G2 m]) packed once; a = K
+        HPack pk;
+        JSTSP_TRY(hgemm_pack(ctx, pk, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
+        uint32_t *amax = ctx->arena.get<uint32_t>(batch);
+        JSTSP_REQUIRE(amax, JSTSP_E_NOMEM, "correlate: workspace exhausted");
+        JSTSP_TRY(hgemm_absmax(ctx, K, (long long)nm, (long long)nm, batch, amax));
+        HGemmDesc hd{K, (long long)nm, N, amax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS, pk.JT,
+                     Tc, (long long)ng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
+        JSTSP_TRY(launch_hgemm(ctx, hd, "correlate"));
+    } else
     JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{K, (long long)nm, N}, Mat{B, strideB, G2}, Tc,
                    (long long)ng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
     JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Mat{A, strideA, N}, Mat{Tc, (long long)ng, N}, O,
@@ -141,6 +155,9 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
     const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
     size_t need = rnd256(batch * ng * sizeof(float2)) + rnd256(batch * nm * sizeof(float2));
+    const bool h2 = use_hgemm(N, M, G2);
+    const int nB = strideB ? batch : 1;
+    if (h2) need += hgemm_pack_bytes(G2, M, nB) + rnd256(batch * sizeof(uint32_t));
     if (memspace == JSTSP_HOST)
         need += rnd256(batch * g * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -154,6 +171,17 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     JSTSP_REQUIRE(W && O, JSTSP_E_NOMEM, "synthesize: workspace exhausted");
     JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Mat{A, strideA, N}, Mat{S, (long long)g, Gr}, W,
                    (long long)ng, N));
+    if (h2) {
+        // b(k = g, j = m) = B[g + G2 m] packed once; a = A S
+        HPack pk;
+        JSTSP_TRY(hgemm_pack(ctx, pk, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M));
+        uint32_t *amax = ctx->arena.get<uint32_t>(batch);
+        JSTSP_REQUIRE(amax, JSTSP_E_NOMEM, "synthesize: workspace exhausted");
+        JSTSP_TRY(hgemm_absmax(ctx, W, (long long)ng, (long long)ng, batch, amax));
+        HGemmDesc hd{W, (long long)ng, N, amax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS, pk.JT,
+                     O, (long long)nm, N, N, M, G2, batch, EPI_NONE, nullptr, nullptr, nullptr};
+        JSTSP_TRY(launch_hgemm(ctx, hd, "synthesize"));
+    } else
     JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{W, (long long)ng, N}, Mat{B, strideB, G2}, O,
                    (long long)nm, N, 1.f, nullptr, 0, 0, 0.f, GEMM_SYNTH));
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(out), O, batch * nm, memspace));

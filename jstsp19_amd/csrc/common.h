@@ -128,6 +128,36 @@ enum { EPI_NONE = 0, EPI_UPDATE_C = 1, EPI_UPDATE_X = 2 };
 enum { GEMM_MISC = 0, GEMM_CORRELATE = 1, GEMM_SYNTH = 2, GEMM_GRAM = 3 };
 int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag = GEMM_MISC);
 
+// ---- split-f16 complex GEMM (hgemm.hip): fp32-equivalent accuracy on the f16 matrix pipe ----
+// C[t] (m x n) = a[t] (m x k, fp32, a(i,kk) = A[t*sAt + i + kk*sAk]) * b[t] (k x n, packed once by hgemm_pack)
+struct HPack {
+    uint4 *data = nullptr;      // [count][JT][KS][4 planes][64 lanes] 16-byte fragments
+    uint32_t *bmax = nullptr;   // [count] float bits of max(|re|, |im|)
+    int KS = 0, JT = 0, count = 0;
+    long long st = 0;           // uint4 per problem
+};
+struct HGemmDesc {
+    const float2 *A; long long sAt, sAk;
+    const uint32_t *amax;       // [batch] float bits of max(|re|, |im|) of a[t]
+    const uint4 *Bp; long long sPt;
+    const uint32_t *bmax; int sbmax;
+    int KS, JT;
+    float2 *C; long long sCt; int ldc;
+    int m, n, k, batch;
+    int epi;                    // EPI_NONE or EPI_UPDATE_C (fields as in GemmDesc)
+    const TrialParams *prm;
+    const float2 *e_r0;
+    float2 *e_rw0;
+};
+size_t hgemm_pack_bytes(int Kd, int J, int count);
+// amax[t] = max(|re|, |im|) over n contiguous elements of X[t*sXt ...]
+int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax);
+// b(kk, j) = B[t*sBt + kk*sBk + j*sBj] (conjugated if conj), kk < Kd, j < J; each B[t] spans n_contig contiguous elements
+int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long sBt, long long sBk, long long sBj,
+               int conj, int Kd, int J, int count, long long n_contig);
+int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name = nullptr);
+bool use_hgemm(long long m, long long n, long long k);   // policy (env JSTSP_H2), read at every call
+
 // ---- batched Hermitian eigen-solver (eig.hip) -------------------------------------------
 // G[t] = sum_{s<nsplit} Gpart[t*sGt + s*sGs + i + n*j]   (n x n Hermitian PSD Gram, n <= 128)
 // mode EIG_SVT_Q : Q[t] = U diag(min(1, tau_t/sigma_i)) U^H with sigma = sqrt(lambda)

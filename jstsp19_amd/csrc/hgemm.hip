@@ -1,0 +1,344 @@
+// Complex GEMM with fp32-equivalent accuracy on the f16 matrix pipe (16x the fp32 MFMA rate).
+//
+// Every fp32 operand value x, scaled by a per-problem power of two s so that max|x s| < 2^14,
+// is split into two halves  x s = h + l 2^-11  (h = RN_f16(x s), l = RN_f16((x s - h) 2^11)):
+// h + l 2^-11 carries 22-23 significant bits and the residual x s - h is exact in fp32.
+// A real product sum is then three f16 MFMA streams with fp32 accumulation,
+//     sum a b = [ sum ah bh ] + 2^-11 [ sum ah bl + al bh ]      (dropped: al bl 2^-22, <= 2^-24 |a b|),
+// every f16 x f16 product being exact in the fp32 accumulator.  A complex product is four real
+// ones (12 MFMAs per 32x32x16 block instead of 24 fp32 MFMAs per 32x32x16 with the 3M form, and
+// each at 1/2 the issue time: 4x less matrix-pipe time), so the big contractions of the ADMM
+// iteration (K B^H and (A S) B, proposed_algorithm.m:47,:58) become HBM-bound on their b operand.
+//
+// The b operand (the pilot dictionary B: constant over the iterations of a solve) is split and
+// packed ONCE into MFMA fragment order (hgemm_pack): per problem [j-tile of 32][k-step of 16]
+// [plane: re_h, re_l, im_h, im_l][lane][8 halves]; a workgroup streams it as 1 KiB fragment blocks
+// (16 B per lane, lane-linear in HBM and in LDS: conflict-free ds_write_b128 / ds_read_b128).
+// The a operand (K or A S: new every iteration) is loaded as fp32 (coalesced along i), split in
+// registers and written to LDS in the same fragment order.
+//
+// fp32 accumulators are folded into second-level fp32 sums every FLUSH stages (256 k), which keeps
+// the accumulation noise of a 4096-term chain at the level of the fp64-master path of cgemm.hip.
+#include "solver_common.h"
+
+namespace jstsp {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int HBK = 32;          // k per stage = 2 MFMA k-steps
+constexpr int FLUSH = 8;         // stages between folds of the fp32 accumulators
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+// e such that amax * 2^e lies in [2^13, 2^14)
+__device__ __host__ inline int scale_exp(uint32_t amax_bits)
+{
+    const int be = (int)((amax_bits >> 23) & 0xff);
+    if (be == 0 || be == 255) return 0;
+    return 13 - (be - 127);
+}
+
+__device__ __forceinline__ void split2(float x, _Float16 &h, _Float16 &l)
+{
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * LO_SCALE);
+}
+
+// ---- max(|re|, |im|) per problem (float bits in a uint: order-preserving for non-negative floats)
+__global__ __launch_bounds__(256) void absmax_kernel(long long n2, const float *X, long long sXt, uint32_t *amax)
+{
+    const int t = blockIdx.y;
+    const float *p = X + (long long)t * sXt;
+    float m = 0.f;
+    const bool vec = ((sXt & 3) == 0) && ((n2 & 3) == 0) && (((uintptr_t)X & 15) == 0);
+    if (vec) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2 / 4; i += (long long)gridDim.x * 256) {
+            const float4 v = p4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long long)gridDim.x * 256)
+            m = fmaxf(m, fabsf(p[i]));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&amax[t], __float_as_uint(m));
+}
+
+// ---- pack b(k, j) = B[t*sBt + k*sBk + j*sBj] (conjugated if conj) into fragment order ------------
+__global__ __launch_bounds__(256) void pack_b_kernel(const float2 *B, long long sBt, long long sBk, long long sBj,
+                                                     int conj, int Kd, int J, int KS, int JT, const uint32_t *bmax,
+                                                     uint4 *out)
+{
+    const int t = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)JT * KS * 64) return;
+    const int lane = (int)(idx & 63);
+    const long long blk = idx >> 6;
+    const int ks = (int)(blk % KS), jt = (int)(blk / KS);
+    const int j = jt * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+    const float s = ldexpf(1.f, scale_exp(bmax[t]));
+    const float sg = conj ? -s : s;
+    half8 rh, rl, ih, il;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        float2 x = make_float2(0.f, 0.f);
+        if (j < J && k0 + v < Kd) x = B[(long long)t * sBt + (long long)(k0 + v) * sBk + (long long)j * sBj];
+        _Float16 h, l;
+        split2(x.x * s, h, l); rh[v] = h; rl[v] = l;
+        split2(x.y * sg, h, l); ih[v] = h; il[v] = l;
+    }
+    uint4 *o = out + (((long long)t * JT + jt) * KS + ks) * 256 + lane;
+    o[0] = *reinterpret_cast<uint4 *>(&rh);
+    o[64] = *reinterpret_cast<uint4 *>(&rl);
+    o[128] = *reinterpret_cast<uint4 *>(&ih);
+    o[192] = *reinterpret_cast<uint4 *>(&il);
+}
+
+__device__ __forceinline__ half8 as_half8(uint4 u) { return *reinterpret_cast<half8 *>(&u); }
+__device__ __forceinline__ half8 neg_half8(uint4 u)
+{
+    u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+    return *reinterpret_cast<half8 *>(&u);
+}
+
+// 64 x 64 output tile per 256-thread workgroup (2 x 2 waves of 32 x 32), two workgroups per CU.
+// LDS stage: a blocks [it 2][ks 2][plane 4] then b blocks [jt 2][ks 2][plane 4], 1 KiB each.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i, int tiles_j)
+{
+    // ONE LDS object indexed at run time: the compiler must then keep the stores that fill the next buffer behind
+    // the fragment reads of the current one (with two objects it hoists them — and their vmcnt waits — above the MFMAs)
+    __shared__ uint4 smem[2 * 2048];
+
+    const int tiles = tiles_i * tiles_j;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int t = (slot / tiles) * 8 + xcd;
+    if (t >= d.batch) return;
+    const int rem = slot % tiles;
+    const int ti = rem % tiles_i, tj = rem / tiles_i;
+    const int i0 = ti * 64, j0 = tj * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+
+    const int ea = scale_exp(d.amax[t]);
+    const int eb = scale_exp(d.bmax[(long long)t * d.sbmax]);
+    const float sa = ldexpf(1.f, ea);
+
+    // a loader: thread -> (row i, run of 8 k); out-of-range elements are read from a valid dummy address
+    // and zeroed at the split (no branches around the loads: a branch would carry its own vmcnt(0))
+    const int ai = tid & 63, akg = tid >> 6;
+    const bool arow = (i0 + ai) < d.m;
+    const float2 *abase = d.A + (long long)t * d.sAt;
+    const float2 *pa = abase + (arow ? (i0 + ai) : 0) + (long long)(8 * akg) * d.sAk;
+    const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
+    // b loader: wave -> 4 fragment blocks of the stage (block q = wave*4 + r: jt = q>>3, ks = (q>>2)&1, plane = q&3)
+    const uint4 *pb = d.Bp + (long long)t * d.sPt + ((long long)(tj * 2) * d.KS) * 256 + lane;
+    const int nst = d.KS / 2;
+    const int kfull = d.k / HBK;            // stages whose 32 k are all inside the product
+
+    float2 areg[8];
+    auto load_a = [&](int s) {
+        if (s < kfull) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) areg[v] = pa[(long long)(s * HBK + v) * d.sAk];
+        } else {
+            const int kbase = s * HBK + 8 * akg;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const bool ok = kbase + v < d.k;
+                const float2 *p = ok ? pa + (long long)(s * HBK + v) * d.sAk : abase;
+                const float2 x = *p;
+                areg[v] = ok ? x : make_float2(0.f, 0.f);
+            }
+        }
+    };
+    const float sa_m = arow ? sa : 0.f;     // rows outside the product contribute zeros
+    auto store_a = [&](uint4 *buf) {
+        half8 rh, rl, ih, il;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            _Float16 h, l;
+            split2(areg[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
+            split2(areg[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
+        }
+        uint4 *s = buf + a_slot;
+        s[0] = *reinterpret_cast<uint4 *>(&rh);
+        s[64] = *reinterpret_cast<uint4 *>(&rl);
+        s[128] = *reinterpret_cast<uint4 *>(&ih);
+        s[192] = *reinterpret_cast<uint4 *>(&il);
+    };
+    // b: register-staged (4 x 16 B per thread per stage).  Direct-to-LDS loads were tried first: the compiler then
+    // put a vmcnt(0) in front of the fragment reads of the OTHER buffer (conservative LDS-DMA aliasing), which
+    // serialised every stage on the memory latency.
+    // (four named registers, not an array: the array form was promoted to LDS by the compiler)
+    uint4 b0, b1, b2, b3;
+    const uint4 *pbw = pb + ((long long)(wave >> 1) * d.KS + (wave & 1)) * 256;   // this wave's j-tile / k-step
+    auto load_b = [&](int s) {
+        const uint4 *g = pbw + (long long)(2 * s) * 256;
+        b0 = g[0]; b1 = g[64]; b2 = g[128]; b3 = g[192];
+    };
+    auto store_b = [&](uint4 *buf) {
+        uint4 *o = buf + 1024 + wave * 256 + lane;
+        o[0] = b0; o[64] = b1; o[128] = b2; o[192] = b3;
+    };
+
+    f32x16 re_h = {0}, re_l = {0}, im_h = {0}, im_l = {0};
+    f32x16 Lre = {0}, Lim = {0};
+    auto fold = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            Lre[r] += re_h[r] + re_l[r] * LO_INV;
+            Lim[r] += im_h[r] + im_l[r] * LO_INV;
+            re_h[r] = 0.f; re_l[r] = 0.f; im_h[r] = 0.f; im_l[r] = 0.f;
+        }
+    };
+    auto compute = [&](const uint4 *buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 *fa = buf + ((wi * 2 + ks) * 4) * 64 + lane;
+            const uint4 *fb = buf + 1024 + ((wj * 2 + ks) * 4) * 64 + lane;
+            const uint4 uar_h = fa[0], uar_l = fa[64], uai_h = fa[128], uai_l = fa[192];
+            const half8 br_h = as_half8(fb[0]), br_l = as_half8(fb[64]), bi_h = as_half8(fb[128]), bi_l = as_half8(fb[192]);
+            const half8 ar_h = as_half8(uar_h), ar_l = as_half8(uar_l), ai_h = as_half8(uai_h), ai_l = as_half8(uai_l);
+            const half8 nai_h = neg_half8(uai_h), nai_l = neg_half8(uai_l);
+            // rows of the MFMA tile = j (A operand = b fragment), columns = i (B operand = a fragment)
+            re_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, ar_h, re_h, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_l, ar_h, re_l, 0, 0, 0);
+            im_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, ar_h, im_h, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_l, ar_h, im_l, 0, 0, 0);
+            re_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, nai_h, re_h, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, ar_l, re_l, 0, 0, 0);
+            im_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, ai_h, im_h, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, ar_l, im_l, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_l, nai_h, re_l, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_l, ai_h, im_l, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, nai_l, re_l, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, ai_l, im_l, 0, 0, 0);
+        }
+    };
+    // one stage: prefetch stage s+1 into `nxt` while the MFMAs consume `cur`
+    auto stage = [&](int s, const uint4 *cur, uint4 *nxt) {
+        const bool more = s + 1 < nst;
+        if (more) {
+            load_b(s + 1);
+            load_a(s + 1);
+        }
+        compute(cur);
+        // keep the LDS stores of the prefetched panels (and the vmcnt waits they carry) behind the MFMAs: the
+        // compiler proves the two buffers disjoint and would otherwise hoist them to right after the loads
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            store_b(nxt);
+            store_a(nxt);
+        }
+        if (((s + 1) % FLUSH) == 0) fold();
+        __syncthreads();
+    };
+
+    // ---- prologue
+    load_b(0);
+    load_a(0);
+    store_b(smem);
+    store_a(smem);
+    __syncthreads();
+
+    for (int s = 0; s < nst; ++s) stage(s, smem + (s & 1) * 2048, smem + ((s & 1) ^ 1) * 2048);
+    fold();
+
+    // ---- epilogue: C(i, j), i = lane & 31 (contiguous), j = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const float alpha = ldexpf(1.f, -(ea + eb));
+    const int gi = i0 + wi * 32 + (lane & 31);
+    float2 *Cp = d.C + (long long)t * d.sCt;
+    if (gi < d.m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gj = j0 + wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gj >= d.n) continue;
+            const float2 o = make_float2(Lre[r] * alpha, Lim[r] * alpha);
+            const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
+            if (EPI == EPI_UPDATE_C) {
+                // o = Xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
+                const float rho = d.prm[t].rho, omc = 1.f - d.prm[t].c_coef;
+                const float2 x = d.e_r0[ix];
+                float2 v2 = d.e_rw0[ix];
+                v2.x = omc * (v2.x - rho * (x.x - o.x));
+                v2.y = omc * (v2.y - rho * (x.y - o.y));
+                d.e_rw0[ix] = v2;
+            }
+            Cp[gi + (long long)gj * d.ldc] = o;
+        }
+    }
+}
+
+}  // namespace
+
+// JSTSP_H2 = 0: never, 2: always, 1 / unset: when the contraction is big enough to pay for the two
+// extra absmax launches and the tile padding (m x n x k complex MACs per problem).
+bool use_hgemm(long long m, long long n, long long k)
+{
+    const char *e = getenv("JSTSP_H2");
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0) return false;
+    if (mode >= 2) return true;
+    return m * n * k >= (1ll << 22) && k >= 64 && n >= 64;
+}
+
+size_t hgemm_pack_bytes(int Kd, int J, int count)
+{
+    const size_t KS = 2 * (size_t)((Kd + 31) / 32), JT = 2 * (size_t)((J + 63) / 64);
+    return rnd256((size_t)count * JT * KS * 4096) + rnd256((size_t)count * sizeof(uint32_t));
+}
+
+int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax)
+{
+    JSTSP_HIP(hipMemsetAsync(amax, 0, (size_t)count * sizeof(uint32_t), ctx->stream));
+    const int gx = (int)std::min<long long>((2 * n / 4 + 255) / 256 + 1, 64);
+    absmax_kernel<<<dim3(gx, count), 256, 0, ctx->stream>>>(2 * n, reinterpret_cast<const float *>(X), 2 * sXt, amax);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long sBt, long long sBk, long long sBj,
+               int conj, int Kd, int J, int count, long long n_contig)
+{
+    p.KS = 2 * ((Kd + 31) / 32);
+    p.JT = 2 * ((J + 63) / 64);
+    p.count = count;
+    p.st = (long long)p.JT * p.KS * 256;
+    p.data = ar.get<uint4>((size_t)count * p.st);
+    p.bmax = ar.get<uint32_t>(count);
+    JSTSP_REQUIRE(p.data && p.bmax, JSTSP_E_NOMEM, "workspace exhausted (packed dictionary)");
+    JSTSP_TRY(hgemm_absmax(ctx, B, n_contig, sBt, count, p.bmax));
+    const long long slots = (long long)p.JT * p.KS * 64;
+    pack_b_kernel<<<dim3((unsigned)((slots + 255) / 256), count), 256, 0, ctx->stream>>>(B, sBt, sBk, sBj, conj, Kd, J,
+                                                                                         p.KS, p.JT, p.bmax, p.data);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
+{
+    JSTSP_REQUIRE(d.m > 0 && d.n > 0 && d.k > 0 && d.batch > 0, JSTSP_E_SHAPE, "hgemm: bad shape");
+    JSTSP_REQUIRE(d.KS >= 2 * ((d.k + 31) / 32) && d.JT >= 2 * ((d.n + 63) / 64), JSTSP_E_ARG,
+                  "hgemm: packed operand smaller than the product");
+    const int tiles_i = (d.m + 63) / 64, tiles_j = (d.n + 63) / 64;
+    const long long groups = (d.batch + 7) / 8;
+    const long long grid = groups * 8 * tiles_i * tiles_j;
+    JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
+    if (prof_name) prof_begin(ctx, prof_name);
+    if (d.epi == EPI_UPDATE_C)
+        hgemm_kernel<EPI_UPDATE_C><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+    else
+        hgemm_kernel<EPI_NONE><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+    if (prof_name) prof_end(ctx, prof_name);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace jstsp

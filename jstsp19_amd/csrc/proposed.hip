@@ -28,6 +28,10 @@ struct ProposedWS {
     double *ce;
     float *lam;            // 3 * batch
     GramWS gz, gn;         // SVT of Z; spectral norms of V1, V2, X
+    // split-f16 path (hgemm.hip): B packed once per solve in both orientations, per-problem operand maxima
+    bool h2 = false;
+    HPack Bc, Bs;          // b(k = m, j = g) = conj(B) for K B^H ;  b(k = g, j = m) = B for (A S) B
+    uint32_t *kmax = nullptr, *wmax = nullptr;
 };
 
 static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, int nB, bool angles,
@@ -46,6 +50,8 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     b += rnd256(3 * (size_t)batch * sizeof(float));
     b += GramWS::bytes(N, M, batch, true);
     if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false);
+    if (use_hgemm(N, G2, M))
+        b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(batch * sizeof(uint32_t));
     return b;
 }
 
@@ -76,7 +82,11 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
                   JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     JSTSP_TRY(w.gz.alloc(a, N, M, batch, true));
     if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false));
-
+    w.h2 = use_hgemm(N, G2, M);
+    if (w.h2) {
+        w.kmax = a.get<uint32_t>(batch); w.wmax = a.get<uint32_t>(batch);
+        JSTSP_REQUIRE(w.kmax && w.wmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
+    }
     return 0;
 }
 
@@ -180,6 +190,11 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
 
+    if (w.h2) {
+        JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
+        JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M));
+    }
+
     if (!approx) {
         // 'std': v = U\(L\k) (:29,:53) = vec(G_A^-1 A^H K B^H G_B^-1): invert the two factor Grams once
         // (into P1 / RV-sized scratch is too small for G_B: use the arena), then keep them in GA / GB.
@@ -258,6 +273,12 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
         //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
+        if (w.h2) {
+            JSTSP_TRY(hgemm_absmax(ctx, w.ZK, snm, snm, batch, w.kmax));
+            HGemmDesc hc{w.ZK, snm, N, w.kmax, w.Bc.data, strideB ? w.Bc.st : 0, w.Bc.bmax, strideB ? 1 : 0, w.Bc.KS,
+                         w.Bc.JT, w.Tc, sng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
+            JSTSP_TRY(launch_hgemm(ctx, hc, "correlate"));
+        } else
         JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{w.ZK, snm, N}, Bm, w.Tc, sng, N, 1.f, nullptr, 0, 0,
                        0.f, GEMM_CORRELATE));
         const long long cnt_ll = std::min<long long>(10 + 5ll * (it + 1), (long long)g);
@@ -282,7 +303,13 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         // -- Xs = A S B                                                                      (:58)
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
-        if (fz) {
+        if (w.h2) {
+            JSTSP_TRY(hgemm_absmax(ctx, w.W, sng, sng, batch, w.wmax));
+            HGemmDesc hs{w.W, sng, N, w.wmax, w.Bs.data, strideB ? w.Bs.st : 0, w.Bs.bmax, strideB ? 1 : 0, w.Bs.KS,
+                         w.Bs.JT, w.Xs, snm, N, N, M, G2, batch, fz ? EPI_UPDATE_C : EPI_NONE, w.prm, w.X, w.V2};
+            JSTSP_TRY(launch_hgemm(ctx, hs, "synthesize"));
+            if (!fz) JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
+        } else if (fz) {
             // Xs = W B with sub 4 + the V2 dual update applied in the epilogue              (:58,:61,:65)
             GemmDesc ds = make_gemm('N', 'N', N, M, G2, batch, Mat{w.W, sng, N}, Bm, w.Xs, snm, N);
             ds.epi = EPI_UPDATE_C; ds.prm = w.prm;

@@ -177,7 +177,7 @@ def test_sweep_runner_on_hip_matches_oracle_per_point():
     base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)
     dev = torch.device("cuda:0")
     hip = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev).numpy()
-    ref = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev, solve_fn=oracle_solve).numpy()
+    ref = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev, solve_fn=oracle_solve, builder="hip").numpy()
     np.testing.assert_allclose(hip, ref, atol=1e-6)
     assert hip.shape == (3, 2) and np.all(hip[:, 1] <= hip[:, 0] + 1e-3)      # angle information helps
     # with the conventional-HBF baselines (LS, VAMP) as extra columns

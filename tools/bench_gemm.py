@@ -34,3 +34,17 @@ for name in ("correlate", "synthesize"):
     n, ms = ctx.get_profile(name)
     print("%-10s %3d launches  %.3f ms avg  %.1f TFLOP/s (%.1f%% of 157.3)" % (name, n, ms / n, fl / (ms / n * 1e-3) / 1e12,
                                                                            fl / (ms / n * 1e-3) / 1e12 / 1.573))
+
+# accuracy of both GEMM paths against float64 on 4 problems
+def err(x, ref):
+    return float((x.to(torch.complex128) - ref).abs().max() / ref.abs().max())
+nchk = min(4, a.batch)
+Kd, Sd, Ad, Bd = (x.to(torch.complex128) for x in (K[:nchk], S[:nchk], A, B[:nchk]))
+ref_c = Ad.conj().T @ Kd @ Bd.conj().transpose(1, 2)
+ref_s = Ad @ Sd @ Bd
+for h2 in ("0", "1"):
+    os.environ["JSTSP_H2"] = h2
+    c = J.correlate(K[:nchk].contiguous() if False else J.colmajor(K[:nchk]), A, J.colmajor(B[:nchk]))
+    s = J.synthesize(J.colmajor(S[:nchk]), A, J.colmajor(B[:nchk]))
+    torch.cuda.synchronize()
+    print("JSTSP_H2=%s  correlate max rel err %.2e   synthesize max rel err %.2e" % (h2, err(c, ref_c), err(s, ref_s)))
