@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     float2 *Cp = d.C + (long long)t * d.sCt + (long long)split * d.sCsplit;
     const float2 *Dp = (d.D && d.splitk == 1) ? d.D + (long long)t * d.sDt : nullptr;
     const int gi = m0 + wi * 32 + l31;
+    float tmax = 0.f;           // max(|re|, |im|) of what this thread produces (d.amax_out)
     if (gi < d.m) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -312,17 +313,26 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                         const float2 x = make_float2((v1.x + rho * o.x + sy.x + omr * v2.x + rho * xs.x) * id,
                                                      (v1.y + rho * o.y + sy.y + omr * v2.y + rho * xs.y) * id);
                         d.e_w1[ix] = x;
-                        d.e_w2[ix] = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);
+                        const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);
+                        d.e_w2[ix] = kk;
+                        tmax = fmaxf(tmax, fmaxf(fabsf(kk.x), fabsf(kk.y)));
                         v1 = make_float2(v1.x + rho * (o.x - x.x), v1.y + rho * (o.y - x.y));
                         d.e_rw0[ix] = v1;
                         if (d.e_w3) d.e_w3[ix] = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
                         if (d.epi_store_c) Cp[gi + (long long)gj * d.ldc] = o;
                     } else {
                         Cp[gi + (long long)gj * d.ldc] = o;
+                        tmax = fmaxf(tmax, fmaxf(fabsf(o.x), fabsf(o.y)));
                     }
                 }
             }
         }
+    }
+    // operand maximum for the split-f16 consumer (hgemm.hip): K after EPI_UPDATE_X, the product otherwise
+    if (EPI != EPI_UPDATE_C && d.amax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
+        if (lane == 0) atomicMax(&d.amax_out[t], __float_as_uint(tmax));
     }
 }
 

@@ -113,6 +113,8 @@ struct GemmDesc {
     const float2 *e_r0, *e_r1, *e_r2, *e_r3;
     const float *e_f0;
     int epi_store_c;                        // EPI_UPDATE_X: also store Y into C
+    uint32_t *amax_out;                     // optional [batch]: atomicMax of max(|re|,|im|) (float bits) over the
+                                            // stored product (EPI_NONE) / over K (EPI_UPDATE_X); caller zeroes it
 };
 // The N x M array C of the reference is never stored: with cc = rho/(rho+1), D = X - Xs,
 //   C   = cc (D - V2/rho)                       (proposed_algorithm.m:61)

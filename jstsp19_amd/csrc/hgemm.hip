@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void absmax_kernel(long long n2, const float *
             m = fmaxf(m, fabsf(p[i]));
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(&amax[t], __float_as_uint(m));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)       // one atomic per block: thousands of atomics on one address serialise in L2
+        atomicMax(&amax[t], __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
 }
 
 // ---- pack b(k, j) = B[t*sBt + k*sBk + j*sBj] (conjugated if conj) into fragment order ------------
@@ -141,11 +145,18 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
     const int nst = d.KS / 2;
     const int kfull = d.k / HBK;            // stages whose 32 k are all inside the product
 
-    float2 areg[8];
-    auto load_a = [&](int s) {
+    // Register staging of one stage's panels.  Two sets alternate so that the loads of stage s+2 are issued
+    // before the MFMAs of stage s (prefetch distance 2: with distance 1 every stage waited ~2 us for HBM).
+    // (b as four named registers, not an array: the array form was promoted to LDS by the compiler.)
+    struct Stg { float2 a[8]; uint4 b0, b1, b2, b3; };
+    const uint4 *pbw = pb + ((long long)(wave >> 1) * d.KS + (wave & 1)) * 256;   // this wave's j-tile / k-step
+    const float sa_m = arow ? sa : 0.f;     // rows outside the product contribute zeros
+    auto load = [&](int s, Stg &R) {
+        const uint4 *g = pbw + (long long)(2 * s) * 256;
+        R.b0 = g[0]; R.b1 = g[64]; R.b2 = g[128]; R.b3 = g[192];
         if (s < kfull) {
 #pragma unroll
-            for (int v = 0; v < 8; ++v) areg[v] = pa[(long long)(s * HBK + v) * d.sAk];
+            for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
         } else {
             const int kbase = s * HBK + 8 * akg;
 #pragma unroll
@@ -153,38 +164,25 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
                 const bool ok = kbase + v < d.k;
                 const float2 *p = ok ? pa + (long long)(s * HBK + v) * d.sAk : abase;
                 const float2 x = *p;
-                areg[v] = ok ? x : make_float2(0.f, 0.f);
+                R.a[v] = ok ? x : make_float2(0.f, 0.f);
             }
         }
     };
-    const float sa_m = arow ? sa : 0.f;     // rows outside the product contribute zeros
-    auto store_a = [&](uint4 *buf) {
+    auto store = [&](const Stg &R, uint4 *buf) {
+        uint4 *o = buf + 1024 + wave * 256 + lane;
+        o[0] = R.b0; o[64] = R.b1; o[128] = R.b2; o[192] = R.b3;
         half8 rh, rl, ih, il;
 #pragma unroll
         for (int v = 0; v < 8; ++v) {
             _Float16 h, l;
-            split2(areg[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
-            split2(areg[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
+            split2(R.a[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
+            split2(R.a[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
         }
-        uint4 *s = buf + a_slot;
-        s[0] = *reinterpret_cast<uint4 *>(&rh);
-        s[64] = *reinterpret_cast<uint4 *>(&rl);
-        s[128] = *reinterpret_cast<uint4 *>(&ih);
-        s[192] = *reinterpret_cast<uint4 *>(&il);
-    };
-    // b: register-staged (4 x 16 B per thread per stage).  Direct-to-LDS loads were tried first: the compiler then
-    // put a vmcnt(0) in front of the fragment reads of the OTHER buffer (conservative LDS-DMA aliasing), which
-    // serialised every stage on the memory latency.
-    // (four named registers, not an array: the array form was promoted to LDS by the compiler)
-    uint4 b0, b1, b2, b3;
-    const uint4 *pbw = pb + ((long long)(wave >> 1) * d.KS + (wave & 1)) * 256;   // this wave's j-tile / k-step
-    auto load_b = [&](int s) {
-        const uint4 *g = pbw + (long long)(2 * s) * 256;
-        b0 = g[0]; b1 = g[64]; b2 = g[128]; b3 = g[192];
-    };
-    auto store_b = [&](uint4 *buf) {
-        uint4 *o = buf + 1024 + wave * 256 + lane;
-        o[0] = b0; o[64] = b1; o[128] = b2; o[192] = b3;
+        uint4 *q = buf + a_slot;
+        q[0] = *reinterpret_cast<uint4 *>(&rh);
+        q[64] = *reinterpret_cast<uint4 *>(&rl);
+        q[128] = *reinterpret_cast<uint4 *>(&ih);
+        q[192] = *reinterpret_cast<uint4 *>(&il);
     };
 
     f32x16 re_h = {0}, re_l = {0}, im_h = {0}, im_l = {0};
@@ -221,34 +219,32 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
             im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, ai_l, im_l, 0, 0, 0);
         }
     };
-    // one stage: prefetch stage s+1 into `nxt` while the MFMAs consume `cur`
-    auto stage = [&](int s, const uint4 *cur, uint4 *nxt) {
-        const bool more = s + 1 < nst;
-        if (more) {
-            load_b(s + 1);
-            load_a(s + 1);
-        }
+    // one stage: issue the loads of stage s+2 into `Rfar`, run the MFMAs on `cur`, then move stage s+1 (already in
+    // flight in `Rnear` for a whole stage) into `nxt`
+    auto stage = [&](int s, const uint4 *cur, uint4 *nxt, Stg &Rnear, Stg &Rfar) {
+        if (s + 2 < nst) load(s + 2, Rfar);
         compute(cur);
         // keep the LDS stores of the prefetched panels (and the vmcnt waits they carry) behind the MFMAs: the
         // compiler proves the two buffers disjoint and would otherwise hoist them to right after the loads
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            store_b(nxt);
-            store_a(nxt);
-        }
+        if (s + 1 < nst) store(Rnear, nxt);
         if (((s + 1) % FLUSH) == 0) fold();
         __syncthreads();
     };
 
     // ---- prologue
-    load_b(0);
-    load_a(0);
-    store_b(smem);
-    store_a(smem);
+    Stg R0, R1;
+    uint4 *buf0 = smem, *buf1 = smem + 2048;
+    load(0, R0);
+    if (nst > 1) load(1, R1);
+    store(R0, buf0);
     __syncthreads();
 
-    for (int s = 0; s < nst; ++s) stage(s, smem + (s & 1) * 2048, smem + ((s & 1) ^ 1) * 2048);
+    for (int s = 0; s < nst; s += 2) {
+        stage(s, buf0, buf1, R1, R0);
+        if (s + 1 < nst) stage(s + 1, buf1, buf0, R0, R1);
+    }
     fold();
 
     // ---- epilogue: C(i, j), i = lane & 31 (contiguous), j = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -298,7 +294,7 @@ size_t hgemm_pack_bytes(int Kd, int J, int count)
 int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax)
 {
     JSTSP_HIP(hipMemsetAsync(amax, 0, (size_t)count * sizeof(uint32_t), ctx->stream));
-    const int gx = (int)std::min<long long>((2 * n / 4 + 255) / 256 + 1, 64);
+    const int gx = (int)std::max<long long>(1, std::min<long long>(2 * n / 4 / 256 / 16, 16));
     absmax_kernel<<<dim3(gx, count), 256, 0, ctx->stream>>>(2 * n, reinterpret_cast<const float *>(X), 2 * sXt, amax);
     JSTSP_HIP(hipGetLastError());
     return 0;

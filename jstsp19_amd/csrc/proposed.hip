@@ -251,6 +251,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             dq.e_r0 = w.V2; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
             dq.e_w3 = (it + 1 < Imax) ? Zn : nullptr;
             dq.epi_store_c = (it + 1 == Imax);          // Y itself is only an output of the last iteration
+            if (w.h2) {                                 // max|K| for the split-f16 correlation, from the same epilogue
+                JSTSP_HIP(hipMemsetAsync(w.kmax, 0, batch * sizeof(uint32_t), sm));
+                dq.amax_out = w.kmax;
+            }
             JSTSP_TRY(launch_cgemm(ctx, dq, GEMM_MISC));
         } else {
             JSTSP_TRY(svt_apply(ctx, w.gz, Zc, w.Y));
@@ -274,7 +278,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
         //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
         if (w.h2) {
-            JSTSP_TRY(hgemm_absmax(ctx, w.ZK, snm, snm, batch, w.kmax));
+            if (!fz) JSTSP_TRY(hgemm_absmax(ctx, w.ZK, snm, snm, batch, w.kmax));
             HGemmDesc hc{w.ZK, snm, N, w.kmax, w.Bc.data, strideB ? w.Bc.st : 0, w.Bc.bmax, strideB ? 1 : 0, w.Bc.KS,
                          w.Bc.JT, w.Tc, sng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
             JSTSP_TRY(launch_hgemm(ctx, hc, "correlate"));
@@ -301,10 +305,15 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             JSTSP_TRY(launch_soft(ctx, (int)g, batch, w.V, w.S, w.rank, (int)cnt_ll, w.prm));     // (:56)
         }
         // -- Xs = A S B                                                                      (:58)
+        if (w.h2) {
+            GemmDesc dw = make_gemm('N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N);
+            JSTSP_HIP(hipMemsetAsync(w.wmax, 0, batch * sizeof(uint32_t), sm));
+            dw.amax_out = w.wmax;                       // max|A S| for the split-f16 synthesis
+            JSTSP_TRY(launch_cgemm(ctx, dw, GEMM_MISC));
+        } else
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
         if (w.h2) {
-            JSTSP_TRY(hgemm_absmax(ctx, w.W, sng, sng, batch, w.wmax));
             HGemmDesc hs{w.W, sng, N, w.wmax, w.Bs.data, strideB ? w.Bs.st : 0, w.Bs.bmax, strideB ? 1 : 0, w.Bs.KS,
                          w.Bs.JT, w.Xs, snm, N, N, M, G2, batch, fz ? EPI_UPDATE_C : EPI_NONE, w.prm, w.X, w.V2};
             JSTSP_TRY(launch_hgemm(ctx, hs, "synthesize"));
