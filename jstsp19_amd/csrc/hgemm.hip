@@ -25,6 +25,7 @@ namespace jstsp {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -153,7 +154,11 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
     const float sa_m = arow ? sa : 0.f;     // rows outside the product contribute zeros
     auto load = [&](int s, Stg &R) {
         const uint4 *g = pbw + (long long)(2 * s) * 256;
-        R.b0 = g[0]; R.b1 = g[64]; R.b2 = g[128]; R.b3 = g[192];
+        const u32x4 *gn = reinterpret_cast<const u32x4 *>(g);
+        const u32x4 x0 = __builtin_nontemporal_load(gn), x1 = __builtin_nontemporal_load(gn + 64),
+                    x2 = __builtin_nontemporal_load(gn + 128), x3 = __builtin_nontemporal_load(gn + 192);
+        R.b0 = make_uint4(x0.x, x0.y, x0.z, x0.w); R.b1 = make_uint4(x1.x, x1.y, x1.z, x1.w);
+        R.b2 = make_uint4(x2.x, x2.y, x2.z, x2.w); R.b3 = make_uint4(x3.x, x3.y, x3.z, x3.w);
         if (s < kfull) {
 #pragma unroll
             for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];

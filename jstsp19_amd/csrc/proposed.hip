@@ -32,6 +32,9 @@ struct ProposedWS {
     bool h2 = false;
     HPack Bc, Bs;          // b(k = m, j = g) = conj(B) for K B^H ;  b(k = g, j = m) = B for (A S) B
     uint32_t *kmax = nullptr, *wmax = nullptr;
+    bool h2g = false;      // the two (G_A V) G_B applies of the gradient step on the same path
+    HPack GBp;             // b(k, j) = G_B[k + G2 j]
+    uint32_t *pmax = nullptr;
 };
 
 static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, int nB, bool angles,
@@ -52,6 +55,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false);
     if (use_hgemm(N, G2, M))
         b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(batch * sizeof(uint32_t));
+    if (use_hgemm(Gr, G2, G2)) b += hgemm_pack_bytes(G2, G2, nB) + rnd256(batch * sizeof(uint32_t));
     return b;
 }
 
@@ -86,6 +90,11 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     if (w.h2) {
         w.kmax = a.get<uint32_t>(batch); w.wmax = a.get<uint32_t>(batch);
         JSTSP_REQUIRE(w.kmax && w.wmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
+    }
+    w.h2g = use_hgemm(Gr, G2, G2);
+    if (w.h2g) {
+        w.pmax = a.get<uint32_t>(batch);
+        JSTSP_REQUIRE(w.pmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     }
     return 0;
 }
@@ -190,6 +199,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
 
+    if (w.h2g && approx)
+        JSTSP_TRY(hgemm_pack(ctx, w.GBp, ctx->arena, w.GB, strideB ? (long long)G2 * G2 : 0, 1, G2, 0, G2, G2, nB,
+                             (long long)G2 * G2));
     if (w.h2) {
         JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
         JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M));
@@ -286,14 +298,26 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{w.ZK, snm, N}, Bm, w.Tc, sng, N, 1.f, nullptr, 0, 0,
                        0.f, GEMM_CORRELATE));
         const long long cnt_ll = std::min<long long>(10 + 5ll * (it + 1), (long long)g);
+        // (G_A X) G_B: the G2 x G2 factor is packed once per solve; max|G_A X| comes from the first product's epilogue
+        auto apply_R = [&](const float2 *Xin, float2 *out) -> int {
+            if (!w.h2g) {
+                JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{Xin, sg, Gr}, w.P1, sg, Gr));
+                return gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, out, sg, Gr);
+            }
+            GemmDesc dp = make_gemm('N', 'N', Gr, G2, Gr, batch, GAm, Mat{Xin, sg, Gr}, w.P1, sg, Gr);
+            JSTSP_HIP(hipMemsetAsync(w.pmax, 0, batch * sizeof(uint32_t), sm));
+            dp.amax_out = w.pmax;
+            JSTSP_TRY(launch_cgemm(ctx, dp, GEMM_MISC));
+            HGemmDesc hg{w.P1, sg, Gr, w.pmax, w.GBp.data, strideB ? w.GBp.st : 0, w.GBp.bmax, strideB ? 1 : 0,
+                         w.GBp.KS, w.GBp.JT, out, sg, Gr, Gr, G2, G2, batch, EPI_NONE, nullptr, nullptr, nullptr};
+            return launch_hgemm(ctx, hg, nullptr);
+        };
         if (approx) {
-            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.V, sg, Gr}, w.P1, sg, Gr));
-            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RV, sg, Gr));
+            JSTSP_TRY(apply_R(w.V, w.RV));
             JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
                            -1.f));
             //    R*res for alpha = res'*res / (res'*R*res)                                    (:48)
-            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.Res, sg, Gr}, w.P1, sg, Gr));
-            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.RRes, sg, Gr));
+            JSTSP_TRY(apply_R(w.Res, w.RRes));
             //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
                                     Imax, it));

@@ -10,8 +10,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 dur = collections.defaultdict(float)
 for r in rows:
-    k = r["Kernel_Name"][:72]
-    if pat and pat not in k:
+    k = r["Kernel_Name"][:72] + " grid=" + r.get("Grid_Size", "?")
+    if pat and pat not in r["Kernel_Name"]:
         continue
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Dispatch_Id"] not in disp[k]:
