@@ -267,6 +267,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     const float2 *Dp = (d.D && d.splitk == 1) ? d.D + (long long)t * d.sDt : nullptr;
     const int gi = m0 + wi * 32 + l31;
     float tmax = 0.f;           // max(|re|, |im|) of what this thread produces (d.amax_out)
+    float xmax = 0.f, v1max = 0.f, zmax = 0.f;
     if (gi < d.m) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -318,7 +319,11 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                         tmax = fmaxf(tmax, fmaxf(fabsf(kk.x), fabsf(kk.y)));
                         v1 = make_float2(v1.x + rho * (o.x - x.x), v1.y + rho * (o.y - x.y));
                         d.e_rw0[ix] = v1;
-                        if (d.e_w3) d.e_w3[ix] = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+                        const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+                        if (d.e_w3) d.e_w3[ix] = zn;
+                        xmax = fmaxf(xmax, fmaxf(fabsf(x.x), fabsf(x.y)));
+                        v1max = fmaxf(v1max, fmaxf(fabsf(v1.x), fabsf(v1.y)));
+                        zmax = fmaxf(zmax, fmaxf(fabsf(zn.x), fabsf(zn.y)));
                         if (d.epi_store_c) Cp[gi + (long long)gj * d.ldc] = o;
                     } else {
                         Cp[gi + (long long)gj * d.ldc] = o;
@@ -333,6 +338,19 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o));
         if (lane == 0) atomicMax(&d.amax_out[t], __float_as_uint(tmax));
+    }
+    if (EPI == EPI_UPDATE_X && d.amax_x) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+            v1max = fmaxf(v1max, __shfl_xor(v1max, o));
+            zmax = fmaxf(zmax, __shfl_xor(zmax, o));
+        }
+        if (lane == 0) {
+            atomicMax(&d.amax_x[t], __float_as_uint(xmax));
+            atomicMax(&d.amax_v1[t], __float_as_uint(v1max));
+            atomicMax(&d.amax_z[t], __float_as_uint(zmax));
+        }
     }
 }
 

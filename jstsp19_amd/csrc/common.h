@@ -113,6 +113,7 @@ struct GemmDesc {
     const float2 *e_r0, *e_r1, *e_r2, *e_r3;
     const float *e_f0;
     int epi_store_c;                        // EPI_UPDATE_X: also store Y into C
+    uint32_t *amax_x, *amax_v1, *amax_z;    // EPI_UPDATE_X: optional [batch] maxima of the new X, V1, Znext
     uint32_t *amax_out;                     // optional [batch]: atomicMax of max(|re|,|im|) (float bits) over the
                                             // stored product (EPI_NONE) / over K (EPI_UPDATE_X); caller zeroes it
 };
@@ -150,7 +151,12 @@ struct HGemmDesc {
     const TrialParams *prm;
     const float2 *e_r0;
     float2 *e_rw0;
+    uint32_t *amax_v2;          // EPI_UPDATE_C: optional [batch] atomicMax of max(|re|,|im|) of the new V2
 };
+// Gram partials of a rows x cols matrix, rows <= 64 (same layout as the GEMM_GRAM split-K output):
+// Gpart[(t*nsplit + s)*rows*rows + i + rows*j];  amax[t] bounds max(|re|,|im|) of Z[t]
+int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
+                 const uint32_t *amax, float2 *Gpart);
 size_t hgemm_pack_bytes(int Kd, int J, int count);
 // amax[t] = max(|re|, |im|) over n contiguous elements of X[t*sXt ...]
 int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax);

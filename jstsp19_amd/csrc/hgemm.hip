@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
     const float alpha = ldexpf(1.f, -(ea + eb));
     const int gi = i0 + wi * 32 + (lane & 31);
     float2 *Cp = d.C + (long long)t * d.sCt;
+    float vmax = 0.f;
     if (gi < d.m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -271,8 +272,135 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
                 v2.x = omc * (v2.x - rho * (x.x - o.x));
                 v2.y = omc * (v2.y - rho * (x.y - o.y));
                 d.e_rw0[ix] = v2;
+                vmax = fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y)));
             }
             Cp[gi + (long long)gj * d.ldc] = o;
+        }
+    }
+    if (EPI == EPI_UPDATE_C && d.amax_v2) {     // max|V2| for the split-f16 Gram of the convergence error
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) atomicMax(&d.amax_v2[t], __float_as_uint(vmax));
+    }
+}
+
+// ---- Gram partials G_s = sum_{k in chunk s} z_k z_k^H of a rows x cols matrix (rows <= 64), same split-f16
+//      arithmetic: ONE panel (64 rows x 32 k, split on the fly) feeds both MFMA operands,
+//        re G(i,j) = sum ar_i ar_j + ai_i ai_j,   im G(i,j) = sum ai_i ar_j - ar_i ai_j.
+__global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long long sZt, int rows, int cols, int nsplit,
+                                                       const uint32_t *amax, float2 *Gpart, int batch)
+{
+    __shared__ uint4 smem[2 * 1024];        // per stage: a blocks [it 2][ks 2][plane 4], 1 KiB each
+    const int t = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    if (t >= batch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int ea = scale_exp(amax[t]);
+    const int kchunk = ((cols + nsplit - 1) / nsplit + HBK - 1) / HBK * HBK;
+    const int kbeg = split * kchunk, kend = min(cols, kbeg + kchunk);
+    const int nst = kend > kbeg ? (kend - kbeg + HBK - 1) / HBK : 0;
+
+    const int ai = tid & 63, akg = tid >> 6;
+    const bool arow = ai < rows;
+    const float sa_m = arow ? ldexpf(1.f, ea) : 0.f;
+    const float2 *abase = Z + (long long)t * sZt;
+    const float2 *pa = abase + (arow ? ai : 0) + (long long)(kbeg + 8 * akg) * rows;
+    const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
+    const int kfull = (kend - kbeg) / HBK;
+
+    struct Stg { float2 a[8]; };
+    auto load = [&](int s, Stg &R) {
+        if (s < kfull) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * rows];
+        } else {
+            const int kbase = kbeg + s * HBK + 8 * akg;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const bool ok = kbase + v < kend;
+                const float2 *p = ok ? pa + (long long)(s * HBK + v) * rows : abase;
+                const float2 x = *p;
+                R.a[v] = ok ? x : make_float2(0.f, 0.f);
+            }
+        }
+    };
+    auto store = [&](const Stg &R, uint4 *buf) {
+        half8 rh, rl, ih, il;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            _Float16 h, l;
+            split2(R.a[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
+            split2(R.a[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
+        }
+        uint4 *q = buf + a_slot;
+        q[0] = *reinterpret_cast<uint4 *>(&rh);
+        q[64] = *reinterpret_cast<uint4 *>(&rl);
+        q[128] = *reinterpret_cast<uint4 *>(&ih);
+        q[192] = *reinterpret_cast<uint4 *>(&il);
+    };
+    f32x16 re_h = {0}, re_l = {0}, im_h = {0}, im_l = {0};
+    f32x16 Lre = {0}, Lim = {0};
+    auto fold = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            Lre[r] += re_h[r] + re_l[r] * LO_INV;
+            Lim[r] += im_h[r] + im_l[r] * LO_INV;
+            re_h[r] = 0.f; re_l[r] = 0.f; im_h[r] = 0.f; im_l[r] = 0.f;
+        }
+    };
+    auto compute = [&](const uint4 *buf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 *fi = buf + ((wi * 2 + ks) * 4) * 64 + lane;     // rows i: MFMA B operand (tile columns)
+            const uint4 *fj = buf + ((wj * 2 + ks) * 4) * 64 + lane;     // rows j: MFMA A operand (tile rows)
+            const half8 ir_h = as_half8(fi[0]), ir_l = as_half8(fi[64]), ii_h = as_half8(fi[128]), ii_l = as_half8(fi[192]);
+            const uint4 ujr_h = fj[0], ujr_l = fj[64], uji_h = fj[128], uji_l = fj[192];
+            const half8 jr_h = as_half8(ujr_h), jr_l = as_half8(ujr_l), ji_h = as_half8(uji_h), ji_l = as_half8(uji_l);
+            const half8 nji_h = neg_half8(uji_h), nji_l = neg_half8(uji_l);
+            re_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_h, re_h, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ir_h, re_l, 0, 0, 0);
+            im_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_h, im_h, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ii_h, im_l, 0, 0, 0);
+            re_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_h, re_h, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_l, re_l, 0, 0, 0);
+            im_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_h, im_h, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_l, im_l, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_l, ii_h, re_l, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_l, ir_h, im_l, 0, 0, 0);
+            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_l, re_l, 0, 0, 0);
+            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_l, im_l, 0, 0, 0);
+        }
+    };
+    auto stage = [&](int s, const uint4 *cur, uint4 *nxt, Stg &Rnear, Stg &Rfar) {
+        if (s + 2 < nst) load(s + 2, Rfar);
+        compute(cur);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nst) store(Rnear, nxt);
+        if (((s + 1) % FLUSH) == 0) fold();
+        __syncthreads();
+    };
+    if (nst > 0) {
+        Stg R0, R1;
+        uint4 *buf0 = smem, *buf1 = smem + 1024;
+        load(0, R0);
+        if (nst > 1) load(1, R1);
+        store(R0, buf0);
+        __syncthreads();
+        for (int s = 0; s < nst; s += 2) {
+            stage(s, buf0, buf1, R1, R0);
+            if (s + 1 < nst) stage(s + 1, buf1, buf0, R0, R1);
+        }
+    }
+    fold();
+    const float alpha = ldexpf(1.f, -2 * ea);
+    const int gi = wi * 32 + (lane & 31);
+    float2 *Gp = Gpart + ((long long)t * nsplit + split) * rows * rows;
+    if (gi < rows) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gj = wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gj < rows) Gp[gi + (long long)gj * rows] = make_float2(Lre[r] * alpha, Lim[r] * alpha);
         }
     }
 }
@@ -319,6 +447,19 @@ int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long s
     const long long slots = (long long)p.JT * p.KS * 64;
     pack_b_kernel<<<dim3((unsigned)((slots + 255) / 256), count), 256, 0, ctx->stream>>>(B, sBt, sBk, sBj, conj, Kd, J,
                                                                                          p.KS, p.JT, p.bmax, p.data);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
+                 const uint32_t *amax, float2 *Gpart)
+{
+    JSTSP_REQUIRE(rows > 0 && rows <= 64 && cols > 0 && count > 0 && nsplit > 0, JSTSP_E_SHAPE, "hgram: bad shape");
+    const long long grid = (long long)count * nsplit;
+    JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgram grid too large");
+    prof_begin(ctx, "gram");
+    hgram_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count);
+    prof_end(ctx, "gram");
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -32,6 +32,7 @@ struct ProposedWS {
     bool h2 = false;
     HPack Bc, Bs;          // b(k = m, j = g) = conj(B) for K B^H ;  b(k = g, j = m) = B for (A S) B
     uint32_t *kmax = nullptr, *wmax = nullptr;
+    uint32_t *nmax = nullptr, *zmax = nullptr;   // [X | V1 | V2] (3*batch, contiguous after kmax) and Znext maxima
     bool h2g = false;      // the two (G_A V) G_B applies of the gradient step on the same path
     HPack GBp;             // b(k, j) = G_B[k + G2 j]
     uint32_t *pmax = nullptr;
@@ -54,7 +55,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     b += GramWS::bytes(N, M, batch, true);
     if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false);
     if (use_hgemm(N, G2, M))
-        b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(batch * sizeof(uint32_t));
+        b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(5 * batch * sizeof(uint32_t));
     if (use_hgemm(Gr, G2, G2)) b += hgemm_pack_bytes(G2, G2, nB) + rnd256(batch * sizeof(uint32_t));
     return b;
 }
@@ -88,8 +89,9 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false));
     w.h2 = use_hgemm(N, G2, M);
     if (w.h2) {
-        w.kmax = a.get<uint32_t>(batch); w.wmax = a.get<uint32_t>(batch);
+        w.kmax = a.get<uint32_t>(5 * (size_t)batch); w.wmax = a.get<uint32_t>(batch);   // kmax | X | V1 | V2 | Znext
         JSTSP_REQUIRE(w.kmax && w.wmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
+        w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch;
     }
     w.h2g = use_hgemm(Gr, G2, G2);
     if (w.h2g) {
@@ -248,6 +250,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         JSTSP_TRY(svt_prepare(ctx, w.gz, w.Zb, w.prm, nullptr, true));
     }
     const bool fz = fuse && w.gz.left;          // fused epilogues (need the Z - Q Z orientation)
+    const bool hmax = w.h2 && fz && N <= 64;    // the epilogues also deliver max|X|, |V1|, |V2|, |Znext|: split-f16 Grams
     float2 *Zbuf[2] = {w.Zb, w.Zb2};            // svt argument of iteration it lives in Zbuf[it & 1]
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
@@ -264,8 +267,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             dq.e_w3 = (it + 1 < Imax) ? Zn : nullptr;
             dq.epi_store_c = (it + 1 == Imax);          // Y itself is only an output of the last iteration
             if (w.h2) {                                 // max|K| for the split-f16 correlation, from the same epilogue
-                JSTSP_HIP(hipMemsetAsync(w.kmax, 0, batch * sizeof(uint32_t), sm));
+                JSTSP_HIP(hipMemsetAsync(w.kmax, 0, 5 * (size_t)batch * sizeof(uint32_t), sm));
                 dq.amax_out = w.kmax;
+                if (N <= 64) { dq.amax_x = w.nmax; dq.amax_v1 = w.nmax + batch; dq.amax_z = w.zmax; }
             }
             JSTSP_TRY(launch_cgemm(ctx, dq, GEMM_MISC));
         } else {
@@ -278,13 +282,13 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
             StreamScope sc(ctx, s1);
             if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
-            JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true));
+            JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
         }
         if (want_ce) {              // s2: Gram of [X | V1]
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_x, 0));
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 0, 2 * batch));
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gxv, s2));
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
@@ -339,7 +343,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
         if (w.h2) {
             HGemmDesc hs{w.W, sng, N, w.wmax, w.Bs.data, strideB ? w.Bs.st : 0, w.Bs.bmax, strideB ? 1 : 0, w.Bs.KS,
-                         w.Bs.JT, w.Xs, snm, N, N, M, G2, batch, fz ? EPI_UPDATE_C : EPI_NONE, w.prm, w.X, w.V2};
+                         w.Bs.JT, w.Xs, snm, N, N, M, G2, batch, fz ? EPI_UPDATE_C : EPI_NONE, w.prm, w.X, w.V2,
+                         hmax ? w.nmax + 2 * (size_t)batch : nullptr};
             JSTSP_TRY(launch_hgemm(ctx, hs, "synthesize"));
             if (!fz) JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
         } else if (fz) {
@@ -359,7 +364,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             JSTSP_HIP(hipEventRecord(ev_c, sm));
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch));
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gv2, s2));
             JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam));
             JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));

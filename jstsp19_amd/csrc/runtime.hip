@@ -115,7 +115,7 @@ GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Ma
     d.m = m; d.n = n; d.k = k; d.batch = batch;
     d.splitk = splitk < 1 ? 1 : splitk; d.sCsplit = sCsplit;
     d.epi = EPI_NONE; d.prm = nullptr; d.e_rw0 = d.e_w1 = d.e_w2 = d.e_w3 = nullptr;
-    d.e_r0 = d.e_r1 = d.e_r2 = d.e_r3 = nullptr; d.e_f0 = nullptr; d.epi_store_c = 1; d.amax_out = nullptr;
+    d.e_r0 = d.e_r1 = d.e_r2 = d.e_r3 = nullptr; d.e_f0 = nullptr; d.epi_store_c = 1; d.amax_out = nullptr; d.amax_x = d.amax_v1 = d.amax_z = nullptr;
     return d;
 }
 
@@ -189,8 +189,12 @@ int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZ
                 0, 0, 0.f, GEMM_GRAM, w.nsplit, sG);
 }
 
-int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count)
+int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count,
+                        const uint32_t *amax)
 {
+    if (amax && w.left && w.n <= 64)       // split-f16 path: amax[t0 + i] bounds problem t0 + i
+        return launch_hgram(ctx, Z + (long long)t0 * sZt, sZt, w.rows, w.cols, count, w.nsplit, amax + t0,
+                            w.Gpart + (long long)t0 * w.n * w.n * w.nsplit);
     const Mat Zm{Z + (long long)t0 * sZt, sZt, w.rows};
     const long long sG = (long long)w.n * w.n;
     float2 *G = w.Gpart + (long long)t0 * sG * w.nsplit;
@@ -208,11 +212,12 @@ int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam)
 }
 
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
-                bool sequence)
+                bool sequence, const uint32_t *amax)
 {
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
-    JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
+    if (amax) JSTSP_TRY(gram_partials_range(ctx, w, Z, sZ, 0, w.batch, amax));
+    else JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
     if (w.n <= 64) {
         JSTSP_TRY(launch_eig_fast(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau,
                                   w.Q, nullptr, w.Uwarm, sequence ? w.warm : 0));
