@@ -1,0 +1,105 @@
+"""The split-f16 GEMM / Gram path (csrc/hgemm.hip) forced on at every shape (JSTSP_H2=2; by default it is
+only chosen for big contractions): fp32-equivalent accuracy against float64, ragged tiles, two row tiles,
+shared and per-trial dictionaries, operand scales far from 1, zeros — and the whole ADMM through it against
+the golden fixtures with the same tolerances as the fp32 path."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def force_h2():
+    old = os.environ.get("JSTSP_H2")
+    os.environ["JSTSP_H2"] = "2"
+    yield
+    if old is None:
+        del os.environ["JSTSP_H2"]
+    else:
+        os.environ["JSTSP_H2"] = old
+
+
+def _rand(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize("N,M,Gr,G2,batch,shared", [
+    (32, 140, 32, 16, 1, True),        # reference-native: everything smaller than one tile
+    (64, 256, 64, 128, 3, False),      # tile-aligned, per-trial dictionaries
+    (7, 13, 5, 9, 2, True),            # ragged, k shorter than one stage
+    (33, 65, 70, 130, 2, False),       # one past the tile / stage in every dimension
+    (100, 97, 40, 75, 2, True),        # two row tiles of the a operand
+    (64, 1100, 64, 192, 9, False),     # batch not a multiple of the 8 XCDs, several folds of the accumulators
+])
+def test_correlate_and_synthesize_split_f16_match_numpy(force_h2, N, M, Gr, G2, batch, shared):
+    import jstsp19_amd as J
+    rng = np.random.default_rng(N * 1000 + M)
+    K, S = _rand(rng, batch, N, M), _rand(rng, batch, Gr, G2)
+    A = _rand(rng, N, Gr) if shared else _rand(rng, batch, N, Gr)
+    B = _rand(rng, G2, M) if shared else _rand(rng, batch, G2, M)
+    Ab, Bb = np.broadcast_to(A, (batch, N, Gr)), np.broadcast_to(B, (batch, G2, M))
+    ref_c = np.conj(np.swapaxes(Ab, 1, 2)) @ K @ np.conj(np.swapaxes(Bb, 1, 2))
+    ref_s = Ab @ S @ Bb
+    assert rel_err(J.correlate(K, A, B), ref_c) < 5e-6
+    assert rel_err(J.synthesize(S, A, B), ref_s) < 5e-6
+
+
+def test_split_f16_is_scale_free_and_handles_zeros(force_h2):
+    """The per-problem power-of-two scaling keeps the f16 pieces in range whatever the magnitudes are."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(5)
+    K, A, B = _rand(rng, 3, 48, 200), _rand(rng, 48, 40), _rand(rng, 3, 72, 200)
+    K[0] *= 3e7; K[1] *= 2e-9; B[2] *= 5e5; B[0] *= 1e-6         # far outside the f16 range unscaled
+    ref = np.conj(A.T)[None] @ K @ np.conj(np.swapaxes(B, 1, 2))
+    out = J.correlate(K, A, B)
+    for t in range(3):
+        assert rel_err(out[t], ref[t]) < 5e-6
+    # strongly non-uniform magnitudes inside one problem: small entries keep their relative accuracy budget
+    K2 = _rand(rng, 1, 48, 200)
+    K2[0, :, :100] *= 1e-4
+    ref2 = np.conj(A.T)[None] @ K2 @ np.conj(np.swapaxes(B[1:2], 1, 2))
+    assert rel_err(J.correlate(K2, A, B[1:2]), ref2) < 5e-6
+    assert np.all(J.correlate(np.zeros((1, 48, 200), complex), A, B[:1]) == 0)
+    assert np.all(J.synthesize(np.zeros((1, 40, 72), complex), A, B[:1]) == 0)
+
+
+def test_split_f16_matches_the_fp32_mfma_path(force_h2):
+    """Same inputs through both matrix-pipe paths: they agree to fp32 round-off."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(8)
+    K, A, B = _rand(rng, 4, 64, 512), _rand(rng, 64, 64), _rand(rng, 4, 128, 512)
+    h = J.correlate(K, A, B)
+    os.environ["JSTSP_H2"] = "0"
+    f = J.correlate(K, A, B)
+    assert rel_err(h, f) < 3e-6
+
+
+@pytest.mark.parametrize("name", ["proposed_small", "proposed_small_lowsnr", "proposed_refnative"])
+def test_proposed_through_split_f16_matches_golden(force_h2, name):
+    """GEMMs, the G_B applies and the SVT / convergence-error Grams all on the split-f16 kernels."""
+    import jstsp19_amd as J
+    from test_gpu_parity_proposed import _check
+    g = load_golden(name)
+    out = J.proposed_algorithm(g["subY"], g["Omega"], g["A"], g["B"], int(g["Imax"]), float(g["tau_Y"]),
+                               float(g["tau_Z"]), float(g["rho"]), "approximate")
+    _check(out, g, "approximate", nmse_tol=1e-6 if name == "proposed_refnative" else 2e-6)
+    if name != "proposed_small_lowsnr":
+        out = J.proposed_algorithm_angles(g["subY"], g["Omega"], g["indx_S"], g["A"], g["B"], int(g["Imax"]),
+                                          float(g["tau_Y"]), float(g["tau_Z"]), float(g["rho"]), "approximate", 100)
+        _check(out, g, "angles", nmse_tol=1e-6 if name == "proposed_refnative" else 2e-6)
+
+
+def test_batched_equals_single_through_split_f16(force_h2):
+    import torch
+    import jstsp19_amd as J
+    g = load_golden("proposed_refnative")
+    args = lambda b: (np.stack([g["subY"]] * b), np.stack([g["Omega"]] * b), g["A"], np.stack([g["B"]] * b), 30,
+                      [float(g["tau_Y"])] * b, [float(g["tau_Z"])] * b, [float(g["rho"])] * b, "approximate")
+    S1, Y1, ce1 = J.proposed_algorithm(*args(1))
+    S9, Y9, ce9 = J.proposed_algorithm(*args(9))
+    for t in range(9):
+        assert np.array_equal(S9[t], S1[0]) and np.array_equal(Y9[t], Y1[0])
