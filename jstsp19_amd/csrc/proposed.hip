@@ -199,16 +199,19 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     const Mat GAm{w.GA, strideA ? (long long)Gr * Gr : 0, Gr}, GBm{w.GB, strideB ? (long long)G2 * G2 : 0, G2};
     // G_A = A^H A (Gr x Gr), G_B = B B^H (G2 x G2):  R = K2'*K2 = G_B^T (x) G_A
     JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
+    if (w.h2) {
+        // pack the dictionary first: G_B = B B^H is itself "a = B, b = conj(B)^T" on the split-f16 path
+        JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
+        JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M));
+        HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, w.GB,
+                     (long long)G2 * G2, G2, G2, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
+        JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
+    } else
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
 
     if (w.h2g && approx)
         JSTSP_TRY(hgemm_pack(ctx, w.GBp, ctx->arena, w.GB, strideB ? (long long)G2 * G2 : 0, 1, G2, 0, G2, G2, nB,
                              (long long)G2 * G2));
-    if (w.h2) {
-        JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
-        JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M));
-    }
-
     if (!approx) {
         // 'std': v = U\(L\k) (:29,:53) = vec(G_A^-1 A^H K B^H G_B^-1): invert the two factor Grams once
         // (into P1 / RV-sized scratch is too small for G_B: use the arena), then keep them in GA / GB.
