@@ -32,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0              # same guide: HBM3E peak (6.3 TB/s measured achievable)
 IMAX = 100
 
 
@@ -132,26 +133,43 @@ def main():
     n_l, ms = ctx.get_profile("correlate")
     n_s, ms_s = ctx.get_profile("synthesize")
     ctx.set_profiling(False)
-    flops_per_launch = 8.0 * N * M * G2 * a.batch              # K * B^H, 8 real flops per complex MAC
-    # HBM traffic of the same kernel from the committed PMC measurement (separate rocprofv3 --pmc passes,
+    # Dominant kernel: hgemm_kernel<EPI_UPDATE_C> = Xs = (A S) B on the split-f16 matrix pipe with the C / V2 update
+    # in its epilogue (proposed_algorithm.m:58,:61,:65).  It is HBM-bound: algorithmic bytes per launch =
+    #   packed dictionary (4 f16 planes = 8 B per complex entry of B, read once)      G2*M*8 * nB
+    # + a operand A S                                                                   N*G2*8 * batch
+    # + epilogue: X read, V2 read + write, Xs write                                     4 * N*M*8 * batch
+    # (per trial at configs[1]: 16.0 MiB + 0.25 MiB + 8.0 MiB).
+    nB = a.batch                                                   # per-trial pilots in this workload
+    bytes_synth = 8.0 * G2 * M * nB + 8.0 * N * G2 * a.batch + 4 * 8.0 * N * M * a.batch
+    bytes_corr = 8.0 * G2 * M * nB + 8.0 * N * M * a.batch + 8.0 * N * G2 * a.batch     # K B^H: B pack + K + result
+    flops_per_launch = 8.0 * N * M * G2 * a.batch              # either contraction, 8 real flops per complex MAC
+    # HBM traffic of the same kernels from the committed PMC measurement (separate rocprofv3 --pmc passes,
     # FETCH_SIZE doubled as the microarch guide prescribes for gfx950); only valid for the profiled shape
-    traffic = None
+    traffic = traffic_c = None
     try:
         if not a.small and a.batch == 256:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["correlate"]["hbm_bytes_per_launch"]
+                pm = json.load(f)
+            traffic = pm["synthesize_update_c"]["hbm_bytes_per_launch"]
+            traffic_c = pm["correlate"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
-        traffic = None
+        traffic = traffic_c = None
     roofline = None
-    if n_l:
-        avg_ms = ms / n_l
-        ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "cgemm_kernel<64, CORRELATE, M64, M3> (K*B^H of A^H K B^H)",
-                    "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": n_l,
-                    "flops_per_launch": flops_per_launch,
-                    "synthesize_avg_launch_ms": round(ms_s / n_s, 4) if n_s else None}
+    if n_s:
+        avg_ms = ms_s / n_s
+        ach = bytes_synth / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "hgemm_kernel<EPI_UPDATE_C> ((A S) B + C/V2 update, split-f16 MFMA)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": n_s, "bytes_per_launch": bytes_synth,
+                    "algorithmic_tflops": round(flops_per_launch / (avg_ms * 1e-3) / 1e12, 1)}
+        if n_l:
+            avg_c = ms / n_l
+            roofline["correlate"] = {"kernel": "hgemm_kernel<EPI_NONE> (K B^H)", "avg_launch_ms": round(avg_c, 4),
+                                     "achieved": round(bytes_corr / (avg_c * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                     "frac": round(bytes_corr / (avg_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "bytes_per_launch": bytes_corr, "traffic": traffic_c,
+                                     "algorithmic_tflops": round(flops_per_launch / (avg_c * 1e-3) / 1e12, 1)}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, single-GPU runs only) -------------
     cpu = None
@@ -189,7 +207,7 @@ def main():
             "metric": "channel-estimates/sec (batched MC) at Nt=Nr=64,K=64; NMSE vs ref",
             "value": round(total / dt, 3), "unit": "channel-estimates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "c32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "c32 (storage and results fp32 complex; big contractions as split-f16 MFMA with fp32 accumulation, fp32-equivalent)", "data": "synthetic",
             "config": {"workload": workload, "trials_per_gpu_per_step": a.batch, "Imax": IMAX,
                        "outputs": "S,Y,convergence_error" if want_ce else "S,Y", "snr_db": a.snr_db,
                        "pilots": "per-trial (B per trial)", "parallelism": "trials sharded, dp%d" % world},
