@@ -11,9 +11,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=64)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--builder", default="hip", choices=["hip", "torch"])
+ap.add_argument("--config3", action="store_true", help="BASELINE configs[3]: Nt=Nr=64, Nrf=8, K=64, L=8, 10 SNR points")
 a = ap.parse_args()
 base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)              # plot_errorVSsnr.m:8-23
 snrs = list(range(-15, 16, 3))                                  # :24
+if a.config3:
+    base = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8)           # the configs[1] shape (N=64, M=4096, Gr=64, G2=512)
+    snrs = list(range(-15, 15, 3))                              # 10 points
 t0 = time.perf_counter()
 out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, numOfnz=100, builder=a.builder)
 torch.cuda.synchronize()
