@@ -217,6 +217,145 @@ __global__ __launch_bounds__(256) void omp_finish_kernel(int meas, int size_d, i
     }
 }
 
+// ---- OMP on the Kronecker dictionary entirely in the coefficient domain ("Batch-OMP") --------------------------
+// With Phi = kron(Bf.', Af) the Gram of the dictionary factorises,
+//   <atom(a', b'), atom(a, b)> = G_A[a', a] * G_B[b, b'],   G_A = Af^H Af,  G_B = Bf Bf^H,
+// so the correlation of the residual never needs the measurement space again after c0 = Phi^H v:
+//   Phi^H r = c0 - G(:, U) x_U,   x_U = argmin |v - Phi_U x| = (G_UU)^-1 c0_U  (Cholesky, grown by one row per atom).
+// One workgroup per problem runs ALL m iterations (OMP.m:16-24): argmax with first-index tie-break, duplicate
+// check (multiplicities, :18 never excludes an atom), Cholesky append in fp64, two triangular solves, and the
+// refresh of c (size_d x |U| complex MACs).  No per-iteration launches, no meas-sized traffic.
+template <int NT>
+__global__ __launch_bounds__(NT) void omp_gram_kernel(int size_d, int m, int Gr, int G2, const float2 *c0_, float2 *cw_,
+                                                      const float2 *GA_, long long sGA, const float2 *GB_, long long sGB,
+                                                      float2 *x_hat, int32_t *index_out)
+{
+    extern __shared__ double lds[];
+    // LDS: L (m*m double2, row-major lower), xu (m double2), cu (m double2), work (m double2), ia/ib/mult (3*m int)
+    double2 *L = reinterpret_cast<double2 *>(lds);
+    double2 *xu = L + (size_t)m * m, *cu = xu + m, *wk = cu + m;
+    int *ia = reinterpret_cast<int *>(wk + m), *ib = ia + m, *mult = ib + m;
+    __shared__ float shv[NT / 64];
+    __shared__ int shi[NT / 64];
+    __shared__ int s_nu, s_new;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const float2 *c0 = c0_ + (long long)t * size_d;
+    float2 *cw = cw_ + (long long)t * size_d;
+    const float2 *GA = GA_ + (long long)t * sGA, *GB = GB_ + (long long)t * sGB;
+    if (tid == 0) s_nu = 0;
+    for (int i = tid; i < size_d; i += NT) cw[i] = c0[i];
+    __syncthreads();
+    for (int it = 0; it < m; ++it) {
+        // ---- argmax |c| with first-index tie-break (MATLAB max)                                      OMP.m:17
+        float best = -1.f;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < size_d; i += NT) {
+            const float2 v = cw[i];
+            float a = sqrtf(v.x * v.x + v.y * v.y);
+            if (a != a) a = -1.f;
+            if (a > best) { best = a; bi = i; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if ((tid & 63) == 0) { shv[tid >> 6] = best; shi[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < NT / 64; ++k)
+                if (shv[k] > best || (shv[k] == best && shi[k] < bi)) { best = shv[k]; bi = shi[k]; }
+            if (bi == 0x7fffffff) bi = 0;
+            index_out[(long long)t * m + it] = bi + 1;                     // 1-based indexSet
+            const int a = bi % Gr, b = bi / Gr;
+            int dup = -1;
+            const int nu = s_nu;
+            for (int j = 0; j < nu; ++j)
+                if (ia[j] == a && ib[j] == b) { dup = j; break; }
+            s_new = 0;
+            if (dup >= 0) {
+                mult[dup] += 1;                                            // re-selected atom: span unchanged
+            } else {
+                // ---- append the atom to the Cholesky factor of G_UU (fp64)
+                const float2 gaa = GA[a + (long long)Gr * a], gbb = GB[b + (long long)G2 * b];
+                const double gnn = (double)gaa.x * gbb.x;
+                double w2 = 0;
+                for (int j = 0; j < nu; ++j) {
+                    // G[U_j, new] = G_A[ia_j, a] * G_B[b, ib_j]
+                    const float2 p = GA[ia[j] + (long long)Gr * a], q = GB[b + (long long)G2 * ib[j]];
+                    double gx = (double)p.x * q.x - (double)p.y * q.y, gy = (double)p.x * q.y + (double)p.y * q.x;
+                    for (int k = 0; k < j; ++k) {                          // forward substitution L w = g
+                        const double2 l = L[(size_t)j * m + k], wv = wk[k];
+                        gx -= l.x * wv.x - l.y * wv.y;
+                        gy -= l.x * wv.y + l.y * wv.x;
+                    }
+                    const double d = L[(size_t)j * m + j].x;
+                    wk[j] = make_double2(gx / d, gy / d);
+                    w2 += wk[j].x * wk[j].x + wk[j].y * wk[j].y;
+                }
+                const double d2 = gnn - w2;
+                if (d2 > 1e-12 * gnn) {                                    // else: numerically in the span, adds nothing
+                    for (int j = 0; j < nu; ++j) L[(size_t)nu * m + j] = make_double2(wk[j].x, -wk[j].y);   // row = w^H
+                    L[(size_t)nu * m + nu] = make_double2(sqrt(d2), 0.0);
+                    ia[nu] = a; ib[nu] = b; mult[nu] = 1;
+                    const float2 cv = c0[bi];
+                    cu[nu] = make_double2(cv.x, cv.y);
+                    s_nu = nu + 1;
+                    s_new = 1;
+                    // ---- x_U = (L L^H)^-1 c0_U                                                     OMP.m:20
+                    const int n = nu + 1;
+                    for (int i = 0; i < n; ++i) {                          // L y = c0_U
+                        double yx = cu[i].x, yy = cu[i].y;
+                        for (int k = 0; k < i; ++k) {
+                            const double2 l = L[(size_t)i * m + k], yv = wk[k];
+                            yx -= l.x * yv.x - l.y * yv.y;
+                            yy -= l.x * yv.y + l.y * yv.x;
+                        }
+                        const double d = L[(size_t)i * m + i].x;
+                        wk[i] = make_double2(yx / d, yy / d);
+                    }
+                    for (int i = n - 1; i >= 0; --i) {                     // L^H x = y
+                        double xx = wk[i].x, xy = wk[i].y;
+                        for (int k = i + 1; k < n; ++k) {
+                            const double2 l = L[(size_t)k * m + i], xv = xu[k];     // conj(L[k][i])
+                            xx -= l.x * xv.x + l.y * xv.y;
+                            xy -= l.x * xv.y - l.y * xv.x;
+                        }
+                        const double d = L[(size_t)i * m + i].x;
+                        xu[i] = make_double2(xx / d, xy / d);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!s_new) continue;                                             // nothing changed: same c, same argmax next time
+        // ---- c = c0 - sum_u x_u G_A[:, ia_u] (x) G_B[ib_u, :]                                       (= Phi^H r, :21-22)
+        const int nu = s_nu;
+        for (int i = tid; i < size_d; i += NT) {
+            const int a = i % Gr, b = i / Gr;
+            const float2 cv = c0[i];
+            double cx = cv.x, cy = cv.y;
+            for (int u = 0; u < nu; ++u) {
+                const float2 p = GA[a + (long long)Gr * ia[u]], q = GB[ib[u] + (long long)G2 * b];
+                const double gx = (double)p.x * q.x - (double)p.y * q.y, gy = (double)p.x * q.y + (double)p.y * q.x;
+                cx -= gx * xu[u].x - gy * xu[u].y;
+                cy -= gx * xu[u].y + gy * xu[u].x;
+            }
+            cw[i] = make_float2((float)cx, (float)cy);
+        }
+        __syncthreads();
+    }
+    // ---- x_hat(indexSet) = x  (a re-selected atom: pinv splits the coefficient equally, the last copy stays, :29-32)
+    for (int i = tid; i < size_d; i += NT) x_hat[(long long)t * size_d + i] = make_float2(0.f, 0.f);
+    __syncthreads();
+    if (tid == 0)
+        for (int j = 0; j < s_nu; ++j) {
+            const double mu = (double)mult[j];
+            x_hat[(long long)t * size_d + ia[j] + (long long)Gr * ib[j]] =
+                make_float2((float)(xu[j].x / mu), (float)(xu[j].y / mu));
+        }
+}
+
 static int omp_alloc(Arena &a, OmpState &s, int meas, int m, int batch)
 {
     s.Qb = a.get<float2>((size_t)batch * meas * m);
@@ -307,12 +446,80 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
     JSTSP_REQUIRE(m <= 1024, JSTSP_E_UNSUPPORTED, "omp_kron: m = %d > 1024", m);
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
     JSTSP_HIP(hipSetDevice(ctx->device));
+    {
+        // Coefficient-domain OMP (omp_gram_kernel): one correlation, the two factor Grams, one kernel for all m
+        // iterations.  JSTSP_OMP_GRAM=0 keeps the measurement-space Gram-Schmidt below (also used when the
+        // Cholesky factor does not fit in LDS).
+        const char *e = getenv("JSTSP_OMP_GRAM");
+        const size_t lds = (size_t)m * m * 16 + 3 * (size_t)m * 16 + 3 * (size_t)m * 4;
+        if ((!e || atoi(e) != 0) && lds <= 150 * 1024) {
+            const int size_d = Gr * G2, nA = strideA ? batch : 1, nB = strideB ? batch : 1;
+            const size_t nm = (size_t)N * M, ng = (size_t)N * G2, g = (size_t)size_d;
+            const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
+            const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
+            const bool h2 = use_hgemm(N, G2, M);
+            size_t need = 3 * rnd256(batch * g * sizeof(float2)) + rnd256(batch * ng * sizeof(float2)) +
+                          rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + rnd256((size_t)nB * G2 * G2 * sizeof(float2)) +
+                          rnd256((size_t)batch * m * sizeof(int32_t));
+            if (h2) need += hgemm_pack_bytes(M, G2, nB) + rnd256(batch * sizeof(uint32_t));
+            if (memspace == JSTSP_HOST)
+                need += rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2)) + rnd256(batch * nm * sizeof(float2));
+            JSTSP_TRY(ctx->arena.reserve(need));
+            ctx->arena.reset();
+            const float2 *Af, *Bf, *y;
+            JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Af_), szA, memspace, &Af));
+            JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Bf_), szB, memspace, &Bf));
+            JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(y_), batch * nm, memspace, &y));
+            Arena &ar = ctx->arena;
+            float2 *c0 = ar.get<float2>(batch * g), *cw = ar.get<float2>(batch * g), *xh = ar.get<float2>(batch * g);
+            float2 *Tc = ar.get<float2>(batch * ng);
+            float2 *GA = ar.get<float2>((size_t)nA * Gr * Gr), *GB = ar.get<float2>((size_t)nB * G2 * G2);
+            int32_t *io = ar.get<int32_t>((size_t)batch * m);
+            JSTSP_REQUIRE(c0 && cw && xh && Tc && GA && GB && io, JSTSP_E_NOMEM, "omp_kron: workspace exhausted");
+            const Mat Am{Af, strideA, N}, Bm{Bf, strideB, G2}, Ym{y, (long long)nm, N};
+            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, GA, (long long)Gr * Gr, Gr));                 // G_A = Af^H Af
+            if (h2) {
+                HPack pk;
+                JSTSP_TRY(hgemm_pack(ctx, pk, ar, Bf, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
+                HGemmDesc hb{Bf, strideB, G2, pk.bmax, pk.data, pk.st, pk.bmax, 1, pk.KS, pk.JT, GB,
+                             (long long)G2 * G2, G2, G2, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
+                JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));                                                      // G_B = Bf Bf^H
+                uint32_t *ymax = ar.get<uint32_t>(batch);
+                JSTSP_REQUIRE(ymax, JSTSP_E_NOMEM, "omp_kron: workspace exhausted");
+                JSTSP_TRY(hgemm_absmax(ctx, y, (long long)nm, (long long)nm, batch, ymax));
+                HGemmDesc hc{y, (long long)nm, N, ymax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS,
+                             pk.JT, Tc, (long long)ng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
+                JSTSP_TRY(launch_hgemm(ctx, hc, "correlate"));                                                  // Y Bf^H
+            } else {
+                JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, GB, (long long)G2 * G2, G2));
+                JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Ym, Bm, Tc, (long long)ng, N, 1.f, nullptr, 0, 0, 0.f,
+                               GEMM_CORRELATE));
+            }
+            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{Tc, (long long)ng, N}, c0, (long long)g, Gr));  // Phi^H v
+            static bool attr_set = false;
+            if (!attr_set) {
+                JSTSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(omp_gram_kernel<1024>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(omp_gram_kernel<1024>, dim3(batch), dim3(1024), lds, ctx->stream, size_d, m, Gr, G2, c0, cw,
+                               GA, strideA ? (long long)Gr * Gr : 0, GB, strideB ? (long long)G2 * G2 : 0, xh, io);
+            JSTSP_HIP(hipGetLastError());
+            JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(x_hat), xh, batch * g, memspace));
+            JSTSP_TRY(stage_out(ctx, index_out, io, (size_t)batch * m, memspace));
+            if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+            return 0;
+        }
+    }
     const int meas = N * M, size_d = Gr * G2;
     const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
     const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
     const size_t ng = (size_t)N * G2;
     size_t need = omp_bytes(meas, m, batch) + 2 * rnd256((size_t)batch * size_d * sizeof(float2)) +
                   rnd256((size_t)batch * ng * sizeof(float2)) + rnd256((size_t)batch * m * sizeof(int32_t));
+    const bool h2 = use_hgemm(N, G2, M);         // split-f16 correlation, dictionary factor packed once (hgemm.hip)
+    const int nB = strideB ? batch : 1;
+    if (h2) need += hgemm_pack_bytes(M, G2, nB) + rnd256(batch * sizeof(uint32_t));
     if (memspace == JSTSP_HOST)
         need += rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2)) + rnd256((size_t)batch * meas * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -332,8 +539,21 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
     JSTSP_HIP(hipMemcpyAsync(s.r, y, (size_t)batch * meas * sizeof(float2), hipMemcpyDeviceToDevice, st));
     JSTSP_HIP(hipMemsetAsync(s.nu, 0, batch * sizeof(int), st));
     JSTSP_HIP(hipMemsetAsync(s.Rm, 0, (size_t)batch * m * m * sizeof(float2), st));
+    HPack pk;
+    uint32_t *rmax = nullptr;
+    if (h2) {
+        JSTSP_TRY(hgemm_pack(ctx, pk, ctx->arena, Bf, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
+        rmax = ctx->arena.get<uint32_t>(batch);
+        JSTSP_REQUIRE(rmax, JSTSP_E_NOMEM, "omp_kron: workspace exhausted");
+    }
     for (int it = 0; it < m; ++it) {
         // Phi'*r = vec(Af^H R Bf^H) with R = reshape(r, N, M): the correlation kernel of the hot path
+        if (h2) {
+            JSTSP_TRY(hgemm_absmax(ctx, s.r, (long long)meas, (long long)meas, batch, rmax));
+            HGemmDesc hd{s.r, (long long)meas, N, rmax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS,
+                         pk.JT, Tc, (long long)ng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
+            JSTSP_TRY(launch_hgemm(ctx, hd, "correlate"));
+        } else
         JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{s.r, (long long)meas, N}, Mat{Bf, strideB, G2}, Tc,
                        (long long)ng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
         JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Mat{Af, strideA, N}, Mat{Tc, (long long)ng, N}, corr,

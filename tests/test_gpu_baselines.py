@@ -58,6 +58,41 @@ def test_omp_reselected_atom_and_batch():
         assert np.array_equal(idxp[t], io) and rel_err(xp[t], xo) < 1e-4
 
 
+def test_omp_kron_coefficient_domain_equals_measurement_domain_and_oracle():
+    """jstsp_omp_kron_c32 runs OMP in the coefficient domain (factor Grams + Cholesky, one kernel for all
+    iterations); JSTSP_OMP_GRAM=0 keeps the measurement-space Gram-Schmidt.  Same index sets, same x, per-trial
+    and shared dictionaries, and a re-selected atom (identity dictionary: pinv splits the coefficient)."""
+    import os
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(77)
+    N, M, Gr, G2, m, batch = 12, 40, 10, 18, 7, 6
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    Af, Bsh, Bpt = r(N, Gr), r(G2, M), r(batch, G2, M)
+    Y = r(batch, N, M)
+    y = Y.transpose(0, 2, 1).reshape(batch, -1)                       # column-major vec
+    old = os.environ.get("JSTSP_OMP_GRAM")
+    try:
+        for B in (Bsh, Bpt):
+            os.environ["JSTSP_OMP_GRAM"] = "1"
+            xg, ig = J.omp_kron(Af, B, y, m)
+            os.environ["JSTSP_OMP_GRAM"] = "0"
+            xm, im = J.omp_kron(Af, B, y, m)
+            assert np.array_equal(ig, im) and rel_err(xg, xm) < 1e-5
+            for t in range(batch):
+                Bt = B if B.ndim == 2 else B[t]
+                xo, io, _, _ = O.omp_literal(np.kron(Bt.T, Af), y[t], m)
+                assert np.array_equal(ig[t], io) and rel_err(xg[t], xo) < 1e-4
+        os.environ["JSTSP_OMP_GRAM"] = "1"
+        x, idx = J.omp_kron(np.eye(2, dtype=complex), np.eye(2, dtype=complex), np.array([3.0, 0, 0, 0], dtype=complex), 2)
+        assert list(idx) == [1, 1] and np.allclose(x, [1.5, 0, 0, 0])   # OMP.m:19,29-32
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_OMP_GRAM", None)
+        else:
+            os.environ["JSTSP_OMP_GRAM"] = old
+
+
 def test_omp_config1_kron_dictionary_1024():
     """BASELINE configs[0]: Nt=Nr=16, Nrf=4, K=16, L=4 — Phi = kron(B.', A) is 1024 x 1024,
     OMP(Phi, y, m=24); the HIP path never forms Phi."""
