@@ -2,6 +2,7 @@
 // (proposed_algorithm.m:35-69, proposed_algorithm_angles.m:36,68).  All HBM-bound: each
 // kernel makes one pass over its operands with 16-byte (two complex) accesses per lane.
 #include "common.h"
+#include <algorithm>
 
 namespace jstsp {
 
@@ -314,6 +315,24 @@ int launch_rank_from_index(jstsp_ctx *ctx, int g, int batch, const int32_t *indx
     JSTSP_HIP(hipGetLastError());
     return 0;
 }
+// P = I - Q for `count` n x n matrices (svt(Z) = Z - Q Z = P Z: one read of Z instead of two in the fused update)
+__global__ __launch_bounds__(256) void eye_minus_kernel(int n, long long total, const float2 *Q, float2 *P)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int r = (int)(e % ((long long)n * n));
+        const float2 q = Q[e];
+        P[e] = make_float2(((r % n) == (r / n) ? 1.f : 0.f) - q.x, -q.y);
+    }
+}
+int launch_eye_minus(jstsp_ctx *ctx, int n, int count, const float2 *Q, float2 *P)
+{
+    const long long total = (long long)count * n * n;
+    hipLaunchKernelGGL(eye_minus_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0,
+                       ctx->stream, n, total, Q, P);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_ce_ratio(jstsp_ctx *ctx, int batch, const float *lamV1, const float *lamV2, const float *lamX,
                     double *ce, int Imax, int it)
 {

@@ -201,6 +201,7 @@ int launch_soft(jstsp_ctx *ctx, int g, int batch, const float2 *V, float2 *S, co
 int launch_inv_d(jstsp_ctx *ctx, long long nm, int batch, const float *Omega, float scale2rho,
                  const TrialParams *prm, float *invD);
 int launch_rank_from_index(jstsp_ctx *ctx, int g, int batch, const int32_t *indx, int32_t *rank);
+int launch_eye_minus(jstsp_ctx *ctx, int n, int count, const float2 *Q, float2 *P);
 int launch_ce_ratio(jstsp_ctx *ctx, int batch, const float *lamV1, const float *lamV2,
                     const float *lamX, double *ce, int Imax, int it);
 

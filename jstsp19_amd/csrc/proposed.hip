@@ -262,8 +262,13 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gxv, 0));
         if (fz) {
             // Y = Z - Q Z with the X / K / V1 updates (and the next Z) applied to the tile in registers (:35-43,:64)
-            GemmDesc dq = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{Zc, snm, N}, w.Y,
-                                    snm, N, -1.f, Zc, snm, N, 1.f);
+            // Y = Z - Q Z as (I - Q) Z: the beta-term form reads the Z tile a second time from HBM (PMC: +0.5 GB)
+            static const bool pz = getenv("JSTSP_PZ") ? atoi(getenv("JSTSP_PZ")) != 0 : true;
+            if (pz) JSTSP_TRY(launch_eye_minus(ctx, N, batch, w.gz.Q, w.gz.Q));
+            GemmDesc dq = pz ? make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{Zc, snm, N},
+                                         w.Y, snm, N)
+                             : make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{Zc, snm, N},
+                                         w.Y, snm, N, -1.f, Zc, snm, N, 1.f);
             dq.epi = EPI_UPDATE_X; dq.prm = w.prm;
             dq.e_rw0 = w.V1; dq.e_w1 = w.X; dq.e_w2 = w.ZK;
             dq.e_r0 = w.V2; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
