@@ -66,7 +66,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # JSTSP_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL path on a 1-GPU box)
+    if world > 1 or os.environ.get("JSTSP_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
