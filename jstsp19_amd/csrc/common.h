@@ -155,8 +155,9 @@ struct HGemmDesc {
 };
 // Gram partials of a rows x cols matrix, rows <= 64 (same layout as the GEMM_GRAM split-K output):
 // Gpart[(t*nsplit + s)*rows*rows + i + rows*j];  amax[t] bounds max(|re|,|im|) of Z[t]
+// skip_prm != nullptr: problems with prm[t].tauY_rho <= 2^-27 amax[t] are skipped (see jacobi2_kernel)
 int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
-                 const uint32_t *amax, float2 *Gpart);
+                 const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm = nullptr);
 size_t hgemm_pack_bytes(int Kd, int J, int count);
 // amax[t] = max(|re|, |im|) over n contiguous elements of X[t*sXt ...]
 int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax);
@@ -180,7 +181,7 @@ bool eig_needs_global_v(int n);
 // Fast paths (eig2.hip): warm-started block Jacobi for n <= 64; tridiagonalisation + Sturm for lambda_max.
 int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
                     long long sGs, const TrialParams *prm, const float *tau, float2 *Q, float *lam_out,
-                    float2 *Uwarm, int warm);
+                    float2 *Uwarm, int warm, const uint32_t *skip_amax = nullptr);
 int eig_fast_ne(int n);           // padded order (32 or 64) of the warm-start basis
 int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
                 float *lam_out);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
                                                        int nsplit, long long sGs, const TrialParams *prm,
                                                        const float *tau, float2 *Q, float *lam_out,
                                                        float2 *Uwarm, int warm, float conv_tol, int max_sweeps,
-                                                       int *sweep_stat)
+                                                       int *sweep_stat, const uint32_t *skip_amax)
 {
     constexpr int LD = NE + 1;
     constexpr int H = NE / 2;
@@ -100,6 +100,16 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
     float *qv = red + 24;                                   // [NE]   (red: [0..3] scalars, [4..19] per-wave)
     const int t = blockIdx.x, tid = threadIdx.x;
     float2 *Uw = Uwarm ? Uwarm + (size_t)t * NE * NE : nullptr;
+    // Opt-in shortcut (JSTSP_SVT_SKIP=1): Z - svt(Z, tau) = U min(Sigma, tau) V^H has every singular value <= tau,
+    // hence every ENTRY of it is <= tau in magnitude.  When tau <= 2^-27 max|Z| the shrinkage is far below the fp32
+    // resolution of the data (half an ulp of max|Z| is 2^-25 max|Z|): Q = 0, i.e. Y = Z, is the fp32 answer.
+    if (skip_amax && mode == EIG_SVT_Q) {
+        const float thr = tau ? tau[t] : prm[t].tauY_rho;
+        if (thr <= ldexpf(__uint_as_float(skip_amax[t]), -27)) {
+            for (int e = tid; e < n * n; e += NT) Q[(size_t)t * n * n + e] = make_float2(0.f, 0.f);
+            return;
+        }
+    }
 
     // ---- load G (sum of split-K partials, zero padded), U (previous basis or identity) ------
     for (int e = tid; e < NE * NE; e += NT) {
@@ -443,7 +453,7 @@ template <int NE> static size_t lmax_smem()
 template <int NE, int NT>
 static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt,
                             int nsplit, long long sGs, const TrialParams *prm, const float *tau, float2 *Q,
-                            float *lam_out, float2 *Uwarm, int warm)
+                            float *lam_out, float2 *Uwarm, int warm, const uint32_t *skip_amax)
 {
     const size_t sh = jacobi2_smem<NE>();
     JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi2_kernel<NE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -453,7 +463,7 @@ static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const fl
     static int *stat = nullptr;
     if (getenv("JSTSP_JACOBI_STAT") && !stat) { (void)hipMalloc((void **)&stat, 4); (void)hipMemset(stat, 0, 4); }
     hipLaunchKernelGGL((jacobi2_kernel<NE, NT>), dim3(batch), dim3(NT), sh, ctx->stream, mode, n, Gpart, sGt, nsplit,
-                       sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, stat);
+                       sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, stat, skip_amax);
     if (stat) {
         static int calls = 0;
         if (++calls % 100 == 0) {
@@ -470,12 +480,14 @@ static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const fl
 // SVT projector with warm start; n <= 64.  Uwarm: batch * NE*NE float2 (NE = 32 or 64), or nullptr.
 int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
                     long long sGs, const TrialParams *prm, const float *tau, float2 *Q, float *lam_out,
-                    float2 *Uwarm, int warm)
+                    float2 *Uwarm, int warm, const uint32_t *skip_amax)
 {
     JSTSP_REQUIRE(n >= 1 && n <= 64, JSTSP_E_UNSUPPORTED, "launch_eig_fast: n = %d > 64", n);
     if (n <= 32)
-        return launch_jacobi2_t<32, 256>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
-    return launch_jacobi2_t<64, 1024>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm);
+        return launch_jacobi2_t<32, 256>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
+                                         skip_amax);
+    return launch_jacobi2_t<64, 1024>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
+                                      skip_amax);
 }
 
 int eig_fast_ne(int n) { return n <= 32 ? 32 : 64; }

@@ -288,11 +288,13 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
 //      arithmetic: ONE panel (64 rows x 32 k, split on the fly) feeds both MFMA operands,
 //        re G(i,j) = sum ar_i ar_j + ai_i ai_j,   im G(i,j) = sum ai_i ar_j - ar_i ai_j.
 __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long long sZt, int rows, int cols, int nsplit,
-                                                       const uint32_t *amax, float2 *Gpart, int batch)
+                                                       const uint32_t *amax, float2 *Gpart, int batch,
+                                                       const TrialParams *skip_prm)
 {
     __shared__ uint4 smem[2 * 1024];        // per stage: a blocks [it 2][ks 2][plane 4], 1 KiB each
     const int t = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
     if (t >= batch) return;
+    if (skip_prm && skip_prm[t].tauY_rho <= ldexpf(__uint_as_float(amax[t]), -27)) return;   // SVT below fp32 resolution
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
     const int ea = scale_exp(amax[t]);
@@ -452,13 +454,13 @@ int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long s
 }
 
 int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
-                 const uint32_t *amax, float2 *Gpart)
+                 const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm)
 {
     JSTSP_REQUIRE(rows > 0 && rows <= 64 && cols > 0 && count > 0 && nsplit > 0, JSTSP_E_SHAPE, "hgram: bad shape");
     const long long grid = (long long)count * nsplit;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgram grid too large");
     prof_begin(ctx, "gram");
-    hgram_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count);
+    hgram_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count, skip_prm);
     prof_end(ctx, "gram");
     JSTSP_HIP(hipGetLastError());
     return 0;

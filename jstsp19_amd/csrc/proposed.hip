@@ -253,6 +253,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         JSTSP_TRY(svt_prepare(ctx, w.gz, w.Zb, w.prm, nullptr, true));
     }
     const bool fz = fuse && w.gz.left;          // fused epilogues (need the Z - Q Z orientation)
+    // opt-in: problems whose threshold is below the fp32 resolution of Z skip the Gram + eigen-decomposition (Y = Z)
+    const bool svt_skip = getenv("JSTSP_SVT_SKIP") ? atoi(getenv("JSTSP_SVT_SKIP")) != 0 : false;
     const bool hmax = w.h2 && fz && N <= 64;    // the epilogues also deliver max|X|, |V1|, |V2|, |Znext|: split-f16 Grams
     float2 *Zbuf[2] = {w.Zb, w.Zb2};            // svt argument of iteration it lives in Zbuf[it & 1]
     for (int it = 0; it < Imax; ++it) {
@@ -290,7 +292,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
             StreamScope sc(ctx, s1);
             if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
-            JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr));
+            JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr, svt_skip));
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
         }
         if (want_ce) {              // s2: Gram of [X | V1]

@@ -190,11 +190,11 @@ int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZ
 }
 
 int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count,
-                        const uint32_t *amax)
+                        const uint32_t *amax, const TrialParams *skip_prm)
 {
     if (amax && w.left && w.n <= 64)       // split-f16 path: amax[t0 + i] bounds problem t0 + i
         return launch_hgram(ctx, Z + (long long)t0 * sZt, sZt, w.rows, w.cols, count, w.nsplit, amax + t0,
-                            w.Gpart + (long long)t0 * w.n * w.n * w.nsplit);
+                            w.Gpart + (long long)t0 * w.n * w.n * w.nsplit, skip_prm ? skip_prm + t0 : nullptr);
     const Mat Zm{Z + (long long)t0 * sZt, sZt, w.rows};
     const long long sG = (long long)w.n * w.n;
     float2 *G = w.Gpart + (long long)t0 * sG * w.nsplit;
@@ -212,15 +212,16 @@ int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam)
 }
 
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
-                bool sequence, const uint32_t *amax)
+                bool sequence, const uint32_t *amax, bool allow_skip)
 {
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
-    if (amax) JSTSP_TRY(gram_partials_range(ctx, w, Z, sZ, 0, w.batch, amax));
+    const bool skip = allow_skip && amax && prm && !tau && w.left && w.n <= 64;
+    if (amax) JSTSP_TRY(gram_partials_range(ctx, w, Z, sZ, 0, w.batch, amax, skip ? prm : nullptr));
     else JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
     if (w.n <= 64) {
         JSTSP_TRY(launch_eig_fast(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau,
-                                  w.Q, nullptr, w.Uwarm, sequence ? w.warm : 0));
+                                  w.Q, nullptr, w.Uwarm, sequence ? w.warm : 0, skip ? amax : nullptr));
         w.warm = sequence ? 1 : 0;
         return 0;
     }

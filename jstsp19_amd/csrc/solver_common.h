@@ -44,11 +44,11 @@ int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
 // The two halves of svt_batched: Gram + eigen-decomposition -> projector Q; then Y = Z - Q Z.
 // amax != nullptr (per-problem bound on max(|re|,|im|) of Z): Gram on the split-f16 path when rows <= 64
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
-                bool sequence, const uint32_t *amax = nullptr);
+                bool sequence, const uint32_t *amax = nullptr, bool allow_skip = false);
 int svt_apply(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float2 *Y);
 // Gram partials of problems [t0, t0 + count) only (same workspace layout as gram_partials).
 int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count,
-                        const uint32_t *amax = nullptr);
+                        const uint32_t *amax = nullptr, const TrialParams *skip_prm = nullptr);
 // lam[t] = lambda_max of the Gram partials already in the workspace, all w.batch problems
 int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam);
 // Make sure the context's side streams / events exist.

@@ -103,3 +103,42 @@ def test_batched_equals_single_through_split_f16(force_h2):
     S9, Y9, ce9 = J.proposed_algorithm(*args(9))
     for t in range(9):
         assert np.array_equal(S9[t], S1[0]) and np.array_equal(Y9[t], Y1[0])
+
+
+def test_optional_svt_skip_is_exact_when_inactive_and_sub_roundoff_when_active():
+    """JSTSP_SVT_SKIP=1: a problem whose threshold tau_Y/rho is <= 2^-27 max|Z| skips the Gram + Jacobi (every entry
+    of Z - svt(Z, tau) is bounded by tau).  Where the SVT matters (reference-native fixture) nothing may change;
+    at the 64-antenna scale (threshold ~1e-10 of the data) the result moves by less than fp32 round-off."""
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    old = {k: os.environ.get(k) for k in ("JSTSP_SVT_SKIP", "JSTSP_H2")}
+    try:
+        os.environ["JSTSP_H2"] = "2"                       # the skip rides on the split-f16 path's max|Z|
+        g = load_golden("proposed_refnative")
+        args = (g["subY"], g["Omega"], g["A"], g["B"], int(g["Imax"]), float(g["tau_Y"]), float(g["tau_Z"]),
+                float(g["rho"]), "approximate")
+        os.environ["JSTSP_SVT_SKIP"] = "0"
+        S0, Y0, ce0 = J.proposed_algorithm(*args)
+        os.environ["JSTSP_SVT_SKIP"] = "1"
+        S1, Y1, ce1 = J.proposed_algorithm(*args)
+        assert np.array_equal(S0, S1) and np.array_equal(Y0, Y1)          # criterion never fires here
+        p = SweepParams(Nt=64, Nr=64, L=8, T=16, Mr=8, snr_db=5.0)         # N=64, M=1024, G2=512
+        inp = build_trials(p, 0, 4, seed=11)
+        run = lambda: J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], 40, inp["tau_Y"].numpy(),
+                                           inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate", want_ce=False)
+        os.environ["JSTSP_SVT_SKIP"] = "0"
+        Sa, Ya, _ = run()
+        os.environ["JSTSP_SVT_SKIP"] = "1"
+        Sb, Yb, _ = run()
+        torch.cuda.synchronize()
+        assert float((Sa - Sb).abs().max() / Sa.abs().max()) < 2e-6
+        assert float((Ya - Yb).abs().max() / Ya.abs().max()) < 2e-6
+        ea, eb = J.nmse_spectral(Sa, inp["Zbar"]), J.nmse_spectral(Sb, inp["Zbar"])
+        assert float((ea - eb).abs().max()) < 1e-6
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
