@@ -49,14 +49,18 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="BLAS threads for the host oracle (0 = min(32, host cores))")
+    ap.add_argument("--shared-pilots", action="store_true", help="one pilot set for all trials (B shared, stride 0)")
     ap.add_argument("--small", action="store_true", help="reference-native shape (plumbing check)")
     return ap.parse_args()
 
 
-def make_inputs(p, trial_ids, device):
+def make_inputs(p, trial_ids, device, shared_pilots=False):
     """The batch's solver inputs, built in HBM by the library's own kernels (jstsp_build_trials_c32)."""
+    from jstsp19_amd.solvers import colmajor
     from jstsp19_amd.system_model import build_trials
-    o = build_trials(p, trial_ids[0], len(trial_ids), device=device)
+    o = build_trials(p, trial_ids[0], len(trial_ids), device=device, shared_pilots=shared_pilots)
+    if shared_pilots:
+        o["B"] = colmajor(o["B"][0].clone())                   # 2-D => shared dictionary (strideB = 0)
     return dict(subY=o["subY"], Omega=o["Omega"], A=o["A"], B=o["B"], Zbar=o["Zbar"], tau_Y=o["tau_Y"].numpy(),
                 tau_Z=o["tau_Z"].numpy(), rho=o["rho"].numpy())
 
@@ -91,7 +95,7 @@ def main():
     want_ce = not a.no_ce
 
     ids = list(range(rank * a.batch, (rank + 1) * a.batch))
-    inp = make_inputs(p, ids, device)
+    inp = make_inputs(p, ids, device, a.shared_pilots)
     ctx = J.default_context(local)
 
     def step():
@@ -140,7 +144,7 @@ def main():
     # + a operand A S                                                                   N*G2*8 * batch
     # + epilogue: X read, V2 read + write, Xs write                                     4 * N*M*8 * batch
     # (per trial at configs[1]: 16.0 MiB + 0.25 MiB + 8.0 MiB).
-    nB = a.batch                                                   # per-trial pilots in this workload
+    nB = 1 if a.shared_pilots else a.batch                         # per-trial pilots in the headline workload
     bytes_synth = 8.0 * G2 * M * nB + 8.0 * N * G2 * a.batch + 4 * 8.0 * N * M * a.batch
     bytes_corr = 8.0 * G2 * M * nB + 8.0 * N * M * a.batch + 8.0 * N * G2 * a.batch     # K B^H: B pack + K + result
     flops_per_launch = 8.0 * N * M * G2 * a.batch              # either contraction, 8 real flops per complex MAC
@@ -178,7 +182,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.cpu_trials > 0:
         from oracle import solvers as O
         nt = min(a.cpu_trials, a.batch)
-        h = {k: inp[k][:nt].cpu().numpy() for k in ("subY", "Omega", "B", "Zbar")}
+        h = {k: inp[k][:nt].cpu().numpy() for k in ("subY", "Omega", "Zbar")}
+        Bh = inp["B"].cpu().numpy()
+        h["B"] = np.broadcast_to(Bh, (nt,) + Bh.shape) if Bh.ndim == 2 else Bh[:nt]
         A_h = inp["A"].cpu().numpy().astype(np.complex128)
         S_h = S[:nt].cpu().numpy().astype(np.complex128)
         from threadpoolctl import threadpool_limits
@@ -211,7 +217,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "c32 (storage and results fp32 complex; big contractions as split-f16 MFMA with fp32 accumulation, fp32-equivalent)", "data": "synthetic",
             "config": {"workload": workload, "trials_per_gpu_per_step": a.batch, "Imax": IMAX,
                        "outputs": "S,Y,convergence_error" if want_ce else "S,Y", "snr_db": a.snr_db,
-                       "pilots": "per-trial (B per trial)", "parallelism": "trials sharded, dp%d" % world},
+                       "pilots": "shared (one B)" if a.shared_pilots else "per-trial (B per trial)", "parallelism": "trials sharded, dp%d" % world},
             "mean_nmse": mean_nmse, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         print(json.dumps(line), flush=True)

@@ -185,6 +185,7 @@ typedef struct jstsp_model {
     int Gr, Gt;             /* dictionary sizes                                      :13-14                  */
     int clusters, rays;     /* total_num_of_clusters, total_num_of_rays              :18-19                  */
     int T_hbf;              /* training length of the conventional HBF baseline (0 = not wanted) :22         */
+    int shared_pilots;      /* 0: new pilots every trial (plot_errorVSsnr.m:63-67); 1: one pilot set per sweep point */
     double noise_var;       /* 10^(-snr_db/10)                                       :49                     */
 } jstsp_model;
 

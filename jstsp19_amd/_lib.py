@@ -21,7 +21,7 @@ c_void_p, c_int, c_ll, c_dp, c_ip = C.c_void_p, C.c_int, C.c_longlong, C.POINTER
 class Model(C.Structure):
     """struct jstsp_model (include/jstsp.h)."""
     _fields_ = [(n, c_int) for n in ("Nt", "Nr", "L", "T_prop", "Mr", "Mr_e", "Gr", "Gt", "clusters", "rays",
-                                     "T_hbf")] + [("noise_var", C.c_double)]
+                                     "T_hbf", "shared_pilots")] + [("noise_var", C.c_double)]
 
 
 class Trials(C.Structure):

@@ -79,10 +79,11 @@ __global__ void draw_small_kernel(Model m, uint64_t seed, uint64_t sweep, long l
 
 // noise = randn + 1j*randn (plot_errorVSsnr.m:60, unscaled) and the 4-QAM symbol indices (qam4mod.m:8)
 __global__ __launch_bounds__(256) void draw_noise_qam_kernel(Model m, uint64_t seed, uint64_t sweep, long long trial0,
-                                                             float2 *noise, uint8_t *qam)
+                                                             float2 *noise, uint8_t *qam, int shared_pilots)
 {
     const int t = blockIdx.y;
     const uint64_t key = mix_key(seed, sweep, (uint64_t)(trial0 + t));
+    const uint64_t qkey = shared_pilots ? mix_key(seed, sweep, ~0ull) : key;     // one pilot set per sweep point
     const long long nn = (long long)m.Nr * m.Tp, nq = (long long)m.Nt * m.Tp;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nn; i += stride) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void draw_noise_qam_kernel(Model m, uint64_t s
         noise[(size_t)t * nn + i] = normal2(w.x, w.y);
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += stride)
-        qam[(size_t)t * nq + i] = (uint8_t)(philox((uint64_t)i, ST_QAM, key).x & 3u);
+        qam[(size_t)t * nq + i] = (uint8_t)(philox((uint64_t)i, ST_QAM, qkey).x & 3u);
 }
 
 // Omega(:, j): ones on the Mr rows with the smallest of Mr_e uniform keys (= randperm(Mr_e)(1:Mr), proposed_hbf.m:37-40)
@@ -356,7 +357,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     // ---- draws ------------------------------------------------------------------------------
     draw_small_kernel<<<batch, 64, 0, st>>>(m, seed, sw, trial0, gains, u_r, u_t);
     draw_noise_qam_kernel<<<dim3(grid_for((long long)std::max(nR, nQ), 1024), batch), 256, 0, st>>>(m, seed, sw, trial0,
-                                                                                                      noise, qam);
+                                                                                                      noise, qam, mp->shared_pilots);
     omega_kernel<<<dim3(m.Tp, batch), 256, (size_t)m.Mr_e * 4, st>>>(m, seed, sw, trial0, Omega);
     // ---- dictionaries -------------------------------------------------------------------------
     dict_kernel<<<grid_for((long long)m.Nr * m.Gr), 256, 0, st>>>(m.Nr, m.Gr, 0, Dr);

@@ -188,11 +188,12 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=Fals
 
 
 def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, device=None, with_hbf=False,
-                 want_draws=False, want_H=False, ctx=None):
+                 want_draws=False, want_H=False, shared_pilots=False, ctx=None):
     """plot_errorVSsnr.m:57-136 for trials [trial0, trial0 + batch) on the HIP path
     (``jstsp_build_trials_c32``, csrc/inputgen.hip): draws, channel, pilots, measurement, A, B,
     hyper-parameters and indx_S are produced by the library's own kernels — nothing but the output
     allocation goes through torch.  Same dict as ``build_inputs`` (Zbar complex64, column-major);
+    ``shared_pilots``: one pilot set for the whole sweep point (``B`` identical for every trial: pass ``B[0]``).
     ``want_draws`` adds the raw draws (gains, u_r, u_t, noise, qam_idx) for checking against a CPU
     restatement.  The Philox streams are keyed by (seed, sweep_idx, global trial index).
     """
@@ -208,7 +209,8 @@ def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, d
     N, M, Gr, G2 = p.solver_shape
     Np = p.clusters * p.rays
     Th = p.T_hbf if with_hbf else 0
-    model = _lib.Model(p.Nt, p.Nr, p.L, p.T_prop, p.Mr, p.Mr_e, p.Gr, p.Gt, p.clusters, p.rays, Th, p.noise_var)
+    model = _lib.Model(p.Nt, p.Nr, p.L, p.T_prop, p.Mr, p.Mr_e, p.Gr, p.Gt, p.clusters, p.rays, Th,
+                       1 if shared_pilots else 0, p.noise_var)
     c64, f32 = torch.complex64, torch.float32
     out = dict(subY=empty_colmajor(batch, N, M, c64, device), Omega=empty_colmajor(batch, N, M, f32, device),
                A=empty_colmajor(1, N, Gr, c64, device)[0], B=empty_colmajor(batch, G2, M, c64, device),
