@@ -152,6 +152,8 @@ struct HGemmDesc {
     const float2 *e_r0;
     float2 *e_rw0;
     uint32_t *amax_v2;          // EPI_UPDATE_C: optional [batch] atomicMax of max(|re|,|im|) of the new V2
+    // optional: the a operand packed like b (hgemm_pack with j = i): then A is not read, amax = the pack's bmax
+    const uint4 *Ap; long long sApt; int aKS;
 };
 // Gram partials of a rows x cols matrix, rows <= 64 (same layout as the GEMM_GRAM split-K output):
 // Gpart[(t*nsplit + s)*rows*rows + i + rows*j];  amax[t] bounds max(|re|,|im|) of Z[t]
@@ -164,6 +166,8 @@ int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, in
 // b(kk, j) = B[t*sBt + kk*sBk + j*sBj] (conjugated if conj), kk < Kd, j < J; each B[t] spans n_contig contiguous elements
 int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long sBt, long long sBk, long long sBj,
                int conj, int Kd, int J, int count, long long n_contig);
+int hgemm_repack(jstsp_ctx *ctx, const HPack &p, const float2 *B, long long sBt, long long sBk, long long sBj, int conj,
+                 int Kd, int J, const uint32_t *bmax);
 int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name = nullptr);
 bool use_hgemm(long long m, long long n, long long k);   // policy (env JSTSP_H2), read at every call
 

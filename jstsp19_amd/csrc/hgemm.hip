@@ -20,6 +20,7 @@
 // fp32 accumulators are folded into second-level fp32 sums every FLUSH stages (256 k), which keeps
 // the accumulation noise of a 4096-term chain at the level of the fp64-master path of cgemm.hip.
 #include "solver_common.h"
+#include <type_traits>
 
 namespace jstsp {
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ half8 neg_half8(uint4 u)
 
 // 64 x 64 output tile per 256-thread workgroup (2 x 2 waves of 32 x 32), two workgroups per CU.
 // LDS stage: a blocks [it 2][ks 2][plane 4] then b blocks [jt 2][ks 2][plane 4], 1 KiB each.
-template <int EPI>
+template <int EPI, bool APACK>
 __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i, int tiles_j)
 {
     // ONE LDS object indexed at run time: the compiler must then keep the stores that fill the next buffer behind
@@ -138,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
     // and zeroed at the split (no branches around the loads: a branch would carry its own vmcnt(0))
     const int ai = tid & 63, akg = tid >> 6;
     const bool arow = (i0 + ai) < d.m;
-    const float2 *abase = d.A + (long long)t * d.sAt;
-    const float2 *pa = abase + (arow ? (i0 + ai) : 0) + (long long)(8 * akg) * d.sAk;
+    const float2 *abase = APACK ? nullptr : d.A + (long long)t * d.sAt;
+    const float2 *pa = APACK ? nullptr : abase + (arow ? (i0 + ai) : 0) + (long long)(8 * akg) * d.sAk;
     const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
     // b loader: wave -> 4 fragment blocks of the stage (block q = wave*4 + r: jt = q>>3, ks = (q>>2)&1, plane = q&3)
     const uint4 *pb = d.Bp + (long long)t * d.sPt + ((long long)(tj * 2) * d.KS) * 256 + lane;
@@ -149,8 +150,15 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
     // Register staging of one stage's panels.  Two sets alternate so that the loads of stage s+2 are issued
     // before the MFMAs of stage s (prefetch distance 2: with distance 1 every stage waited ~2 us for HBM).
     // (b as four named registers, not an array: the array form was promoted to LDS by the compiler.)
-    struct Stg { float2 a[8]; uint4 b0, b1, b2, b3; };
+    // APACK: the a operand arrives packed like b (d.Ap: [i-tile of 32][k-step][plane][lane]): no split here at all
+    struct StgF { float2 a[8]; uint4 b0, b1, b2, b3; };          // a as fp32 (split here)
+    struct StgP { u32x4 a0, a1, a2, a3; uint4 b0, b1, b2, b3; };  // a already packed (native vectors: uint4 members
+                                                                  // were promoted to LDS / scratch by the compiler)
+    using Stg = typename std::conditional<APACK, StgP, StgF>::type;
     const uint4 *pbw = pb + ((long long)(wave >> 1) * d.KS + (wave & 1)) * 256;   // this wave's j-tile / k-step
+    const uint4 *paw = APACK ? d.Ap + (long long)t * d.sApt + lane +
+                                   ((long long)(ti * 2 + (wave >> 1)) * d.KS + (wave & 1)) * 256
+                             : nullptr;
     const float sa_m = arow ? sa : 0.f;     // rows outside the product contribute zeros
     auto load = [&](int s, Stg &R) {
         const uint4 *g = pbw + (long long)(2 * s) * 256;
@@ -159,35 +167,45 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
                     x2 = __builtin_nontemporal_load(gn + 128), x3 = __builtin_nontemporal_load(gn + 192);
         R.b0 = make_uint4(x0.x, x0.y, x0.z, x0.w); R.b1 = make_uint4(x1.x, x1.y, x1.z, x1.w);
         R.b2 = make_uint4(x2.x, x2.y, x2.z, x2.w); R.b3 = make_uint4(x3.x, x3.y, x3.z, x3.w);
-        if (s < kfull) {
-#pragma unroll
-            for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
+        if constexpr (APACK) {
+            const u32x4 *ga = reinterpret_cast<const u32x4 *>(paw + (long long)(2 * s) * 256);
+            R.a0 = ga[0]; R.a1 = ga[64]; R.a2 = ga[128]; R.a3 = ga[192];
         } else {
-            const int kbase = s * HBK + 8 * akg;
+            if (s < kfull) {
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
-                const bool ok = kbase + v < d.k;
-                const float2 *p = ok ? pa + (long long)(s * HBK + v) * d.sAk : abase;
-                const float2 x = *p;
-                R.a[v] = ok ? x : make_float2(0.f, 0.f);
+                for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
+            } else {
+                const int kbase = s * HBK + 8 * akg;
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const bool ok = kbase + v < d.k;
+                    const float2 *p = ok ? pa + (long long)(s * HBK + v) * d.sAk : abase;
+                    const float2 x = *p;
+                    R.a[v] = ok ? x : make_float2(0.f, 0.f);
+                }
             }
         }
     };
     auto store = [&](const Stg &R, uint4 *buf) {
         uint4 *o = buf + 1024 + wave * 256 + lane;
         o[0] = R.b0; o[64] = R.b1; o[128] = R.b2; o[192] = R.b3;
-        half8 rh, rl, ih, il;
+        if constexpr (APACK) {
+            u32x4 *q = reinterpret_cast<u32x4 *>(buf + wave * 256 + lane);
+            q[0] = R.a0; q[64] = R.a1; q[128] = R.a2; q[192] = R.a3;
+        } else {
+            half8 rh, rl, ih, il;
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            _Float16 h, l;
-            split2(R.a[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
-            split2(R.a[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
+            for (int v = 0; v < 8; ++v) {
+                _Float16 h, l;
+                split2(R.a[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
+                split2(R.a[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
+            }
+            uint4 *q = buf + a_slot;
+            q[0] = *reinterpret_cast<uint4 *>(&rh);
+            q[64] = *reinterpret_cast<uint4 *>(&rl);
+            q[128] = *reinterpret_cast<uint4 *>(&ih);
+            q[192] = *reinterpret_cast<uint4 *>(&il);
         }
-        uint4 *q = buf + a_slot;
-        q[0] = *reinterpret_cast<uint4 *>(&rh);
-        q[64] = *reinterpret_cast<uint4 *>(&rl);
-        q[128] = *reinterpret_cast<uint4 *>(&ih);
-        q[192] = *reinterpret_cast<uint4 *>(&il);
     };
 
     f32x16 re_h = {0}, re_l = {0}, im_h = {0}, im_l = {0};
@@ -453,6 +471,17 @@ int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long s
     return 0;
 }
 
+// Re-pack into an existing HPack (same shape) with operand maxima that are already on the device.
+int hgemm_repack(jstsp_ctx *ctx, const HPack &p, const float2 *B, long long sBt, long long sBk, long long sBj, int conj,
+                 int Kd, int J, const uint32_t *bmax)
+{
+    const long long slots = (long long)p.JT * p.KS * 64;
+    pack_b_kernel<<<dim3((unsigned)((slots + 255) / 256), p.count), 256, 0, ctx->stream>>>(B, sBt, sBk, sBj, conj, Kd, J,
+                                                                                           p.KS, p.JT, bmax, p.data);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
                  const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm)
 {
@@ -476,10 +505,16 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
     const long long grid = groups * 8 * tiles_i * tiles_j;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
     if (prof_name) prof_begin(ctx, prof_name);
-    if (d.epi == EPI_UPDATE_C)
-        hgemm_kernel<EPI_UPDATE_C><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+    if (d.Ap) {
+        JSTSP_REQUIRE(d.aKS == d.KS, JSTSP_E_ARG, "hgemm: packed a and b operands disagree on the k padding");
+        if (d.epi == EPI_UPDATE_C)
+            hgemm_kernel<EPI_UPDATE_C, true><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+        else
+            hgemm_kernel<EPI_NONE, true><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+    } else if (d.epi == EPI_UPDATE_C)
+        hgemm_kernel<EPI_UPDATE_C, false><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     else
-        hgemm_kernel<EPI_NONE><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+        hgemm_kernel<EPI_NONE, false><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     if (prof_name) prof_end(ctx, prof_name);
     JSTSP_HIP(hipGetLastError());
     return 0;

@@ -35,6 +35,7 @@ struct ProposedWS {
     uint32_t *nmax = nullptr, *zmax = nullptr;   // [X | V1 | V2] (3*batch, contiguous after kmax) and Znext maxima
     bool h2g = false;      // the two (G_A V) G_B applies of the gradient step on the same path
     HPack GBp;             // b(k, j) = G_B[k + G2 j]
+    HPack Wp;              // the synthesis' a operand A S, re-packed every iteration (64 j-tiles would each split it)
     uint32_t *pmax = nullptr;
 };
 
@@ -55,7 +56,8 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     b += GramWS::bytes(N, M, batch, true);
     if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false);
     if (use_hgemm(N, G2, M))
-        b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(5 * batch * sizeof(uint32_t));
+        b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(5 * batch * sizeof(uint32_t)) +
+             hgemm_pack_bytes(G2, N, batch);
     if (use_hgemm(Gr, G2, G2)) b += hgemm_pack_bytes(G2, G2, nB) + rnd256(batch * sizeof(uint32_t));
     return b;
 }
@@ -92,6 +94,11 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
         w.kmax = a.get<uint32_t>(5 * (size_t)batch); w.wmax = a.get<uint32_t>(batch);   // kmax | X | V1 | V2 | Znext
         JSTSP_REQUIRE(w.kmax && w.wmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
         w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch;
+        w.Wp.KS = 2 * ((G2 + 31) / 32); w.Wp.JT = 2 * ((N + 63) / 64); w.Wp.count = batch;
+        w.Wp.st = (long long)w.Wp.JT * w.Wp.KS * 256;
+        w.Wp.data = a.get<uint4>((size_t)batch * w.Wp.st);
+        w.Wp.bmax = w.wmax;
+        JSTSP_REQUIRE(w.Wp.data, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     }
     w.h2g = use_hgemm(Gr, G2, G2);
     if (w.h2g) {
@@ -352,9 +359,12 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
         if (w.h2) {
+            static const bool apack = getenv("JSTSP_H2_APACK") ? atoi(getenv("JSTSP_H2_APACK")) != 0 : true;
+            if (apack)      // a(i, k = g) = W[i + N g] in fragment order, once per iteration instead of once per j-tile
+                JSTSP_TRY(hgemm_repack(ctx, w.Wp, w.W, sng, N, 1, 0, G2, N, w.wmax));
             HGemmDesc hs{w.W, sng, N, w.wmax, w.Bs.data, strideB ? w.Bs.st : 0, w.Bs.bmax, strideB ? 1 : 0, w.Bs.KS,
                          w.Bs.JT, w.Xs, snm, N, N, M, G2, batch, fz ? EPI_UPDATE_C : EPI_NONE, w.prm, w.X, w.V2,
-                         hmax ? w.nmax + 2 * (size_t)batch : nullptr};
+                         hmax ? w.nmax + 2 * (size_t)batch : nullptr, apack ? w.Wp.data : nullptr, w.Wp.st, w.Wp.KS};
             JSTSP_TRY(launch_hgemm(ctx, hs, "synthesize"));
             if (!fz) JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
         } else if (fz) {
