@@ -56,9 +56,9 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     b += GramWS::bytes(N, M, batch, true);
     if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false);
     if (use_hgemm(N, G2, M))
-        b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(5 * batch * sizeof(uint32_t)) +
+        b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(8 * batch * sizeof(uint32_t)) +
              hgemm_pack_bytes(G2, N, batch);
-    if (use_hgemm(Gr, G2, G2)) b += hgemm_pack_bytes(G2, G2, nB) + rnd256(batch * sizeof(uint32_t));
+    if (use_hgemm(Gr, G2, G2)) b += hgemm_pack_bytes(G2, G2, nB) + rnd256(2 * batch * sizeof(uint32_t));
     return b;
 }
 
@@ -91,9 +91,11 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false));
     w.h2 = use_hgemm(N, G2, M);
     if (w.h2) {
-        w.kmax = a.get<uint32_t>(5 * (size_t)batch); w.wmax = a.get<uint32_t>(batch);   // kmax | X | V1 | V2 | Znext
-        JSTSP_REQUIRE(w.kmax && w.wmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
-        w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch;
+        // operand maxima of one iteration, one block zeroed once per iteration: kmax | X | V1 | V2 | Znext | wmax | pmax x2
+        w.kmax = a.get<uint32_t>(8 * (size_t)batch);
+        JSTSP_REQUIRE(w.kmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
+        w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch; w.wmax = w.kmax + 5 * (size_t)batch;
+        w.pmax = w.kmax + 6 * (size_t)batch;
         w.Wp.KS = 2 * ((G2 + 31) / 32); w.Wp.JT = 2 * ((N + 63) / 64); w.Wp.count = batch;
         w.Wp.st = (long long)w.Wp.JT * w.Wp.KS * 256;
         w.Wp.data = a.get<uint4>((size_t)batch * w.Wp.st);
@@ -101,8 +103,8 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
         JSTSP_REQUIRE(w.Wp.data, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     }
     w.h2g = use_hgemm(Gr, G2, G2);
-    if (w.h2g) {
-        w.pmax = a.get<uint32_t>(batch);
+    if (w.h2g && !w.pmax) {
+        w.pmax = a.get<uint32_t>(2 * (size_t)batch);
         JSTSP_REQUIRE(w.pmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     }
     return 0;
@@ -266,6 +268,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     float2 *Zbuf[2] = {w.Zb, w.Zb2};            // svt argument of iteration it lives in Zbuf[it & 1]
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
+        // every operand maximum of this iteration starts from zero (one memset instead of four)
+        if (w.h2) JSTSP_HIP(hipMemsetAsync(w.kmax, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
+        else if (w.h2g) JSTSP_HIP(hipMemsetAsync(w.pmax, 0, 2 * (size_t)batch * sizeof(uint32_t), sm));
+        int apply_no = 0;
         // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho) = Z - Q Z                                 (:35)
         if (it > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gxv, 0));
@@ -284,7 +290,6 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             dq.e_w3 = (it + 1 < Imax) ? Zn : nullptr;
             dq.epi_store_c = (it + 1 == Imax);          // Y itself is only an output of the last iteration
             if (w.h2) {                                 // max|K| for the split-f16 correlation, from the same epilogue
-                JSTSP_HIP(hipMemsetAsync(w.kmax, 0, 5 * (size_t)batch * sizeof(uint32_t), sm));
                 dq.amax_out = w.kmax;
                 if (N <= 64) { dq.amax_x = w.nmax; dq.amax_v1 = w.nmax + batch; dq.amax_z = w.zmax; }
             }
@@ -326,10 +331,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                 return gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, out, sg, Gr);
             }
             GemmDesc dp = make_gemm('N', 'N', Gr, G2, Gr, batch, GAm, Mat{Xin, sg, Gr}, w.P1, sg, Gr);
-            JSTSP_HIP(hipMemsetAsync(w.pmax, 0, batch * sizeof(uint32_t), sm));
-            dp.amax_out = w.pmax;
+            uint32_t *pm = w.pmax + (size_t)(apply_no++ & 1) * batch;      // two applies per iteration, one slot each
+            dp.amax_out = pm;
             JSTSP_TRY(launch_cgemm(ctx, dp, GEMM_MISC));
-            HGemmDesc hg{w.P1, sg, Gr, w.pmax, w.GBp.data, strideB ? w.GBp.st : 0, w.GBp.bmax, strideB ? 1 : 0,
+            HGemmDesc hg{w.P1, sg, Gr, pm, w.GBp.data, strideB ? w.GBp.st : 0, w.GBp.bmax, strideB ? 1 : 0,
                          w.GBp.KS, w.GBp.JT, out, sg, Gr, Gr, G2, G2, batch, EPI_NONE, nullptr, nullptr, nullptr};
             return launch_hgemm(ctx, hg, nullptr);
         };
@@ -352,7 +357,6 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         // -- Xs = A S B                                                                      (:58)
         if (w.h2) {
             GemmDesc dw = make_gemm('N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N);
-            JSTSP_HIP(hipMemsetAsync(w.wmax, 0, batch * sizeof(uint32_t), sm));
             dw.amax_out = w.wmax;                       // max|A S| for the split-f16 synthesis
             JSTSP_TRY(launch_cgemm(ctx, dw, GEMM_MISC));
         } else
