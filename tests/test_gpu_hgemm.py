@@ -142,3 +142,19 @@ def test_optional_svt_skip_is_exact_when_inactive_and_sub_roundoff_when_active()
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_std_type_through_split_f16_matches_oracle(force_h2):
+    """'std' (Alg. 1: v = U\\(L\\k) as G_A^-1 (A^H K B^H) G_B^-1) with G_B = B B^H and both big contractions on the
+    split-f16 kernels."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(3)
+    N, M, Gr, G2 = 40, 96, 24, 64
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    A, B = r(N, Gr) / np.sqrt(N), r(G2, M) / np.sqrt(M)
+    Om = (rng.random((N, M)) < 0.5).astype(float)
+    args = (Om * r(N, M), Om, A, B, 15, 0.02, 0.01, 0.4, "std")
+    So, Yo, _ = O.proposed_algorithm(*args)
+    S, Y, _ = J.proposed_algorithm(*args)
+    assert rel_err(S, So) < 1e-4 and rel_err(Y, Yo) < 1e-4
