@@ -158,3 +158,20 @@ def test_std_type_through_split_f16_matches_oracle(force_h2):
     So, Yo, _ = O.proposed_algorithm(*args)
     S, Y, _ = J.proposed_algorithm(*args)
     assert rel_err(S, So) < 1e-4 and rel_err(Y, Yo) < 1e-4
+
+
+def test_split_f16_random_shapes(force_h2):
+    """Random small shapes (including 1-sized dimensions) through both orientations of the packed operand."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(2024)
+    for _ in range(24):
+        N, M, Gr, G2 = (int(rng.integers(1, 90)), int(rng.integers(1, 150)), int(rng.integers(1, 70)), int(rng.integers(1, 140)))
+        batch, shared = int(rng.integers(1, 10)), bool(rng.integers(0, 2))
+        K, S = _rand(rng, batch, N, M), _rand(rng, batch, Gr, G2)
+        A = _rand(rng, N, Gr)
+        B = _rand(rng, G2, M) if shared else _rand(rng, batch, G2, M)
+        Bb = np.broadcast_to(B, (batch, G2, M))
+        ref_c = np.conj(A.T)[None] @ K @ np.conj(np.swapaxes(Bb, 1, 2))
+        ref_s = A[None] @ S @ Bb
+        assert rel_err(J.correlate(K, A, B), ref_c) < 5e-6, (N, M, Gr, G2, batch, shared)
+        assert rel_err(J.synthesize(S, A, B), ref_s) < 5e-6, (N, M, Gr, G2, batch, shared)
