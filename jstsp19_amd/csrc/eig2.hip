@@ -458,7 +458,11 @@ static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const fl
     const size_t sh = jacobi2_smem<NE>();
     JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi2_kernel<NE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh));
-    static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 3e-7f;
+    // Stop rule: `worst` is the largest relative off-diagonal met BEFORE its rotation during a sweep.  Cyclic Jacobi
+    // converges quadratically, so a sweep that started below 1e-4 leaves off-diagonals of order 1e-8 — under the
+    // fp32 resolution — and the confirming sweep a 3e-7 threshold would cost (one of ~4 with a warm start) buys
+    // nothing: identical parity (|dNMSE| 1e-7 at both shapes), +12 % at the reference-native shape.
+    static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 1e-4f;
     static const int maxsw = getenv("JSTSP_JACOBI_SWEEPS") ? atoi(getenv("JSTSP_JACOBI_SWEEPS")) : 14;
     static int *stat = nullptr;
     if (getenv("JSTSP_JACOBI_STAT") && !stat) { (void)hipMalloc((void **)&stat, 4); (void)hipMemset(stat, 0, 4); }
