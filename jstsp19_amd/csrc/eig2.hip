@@ -461,7 +461,8 @@ static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const fl
     // Stop rule: `worst` is the largest relative off-diagonal met BEFORE its rotation during a sweep.  Cyclic Jacobi
     // converges quadratically, so a sweep that started below 1e-4 leaves off-diagonals of order 1e-8 — under the
     // fp32 resolution — and the confirming sweep a 3e-7 threshold would cost (one of ~4 with a warm start) buys
-    // nothing: identical parity (|dNMSE| 1e-7 at both shapes), +12 % at the reference-native shape.
+    // nothing: 3.4 instead of 4.3 sweeps per warm-started call at BASELINE configs[1], parity unchanged
+    // (|dNMSE| 1e-7 at both benchmark shapes).
     static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 1e-4f;
     static const int maxsw = getenv("JSTSP_JACOBI_SWEEPS") ? atoi(getenv("JSTSP_JACOBI_SWEEPS")) : 14;
     static int *stat = nullptr;
