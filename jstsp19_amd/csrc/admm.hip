@@ -162,32 +162,46 @@ __device__ __forceinline__ float soft1(float v, float t)
 // ---- steepest-descent step of the 'approximate' branch + soft threshold (:48-56) ---------
 // One workgroup per problem: alpha = <res,res> / <res, R res> by wave64 shuffle reductions
 // (fp64 accumulation), then v += alpha res, ce(i,3) = |dv|^2/|v_prev|^2, s = soft(v) (.* mask).
-__global__ __launch_bounds__(256) void step_v_kernel(int g, const float2 *Res, const float2 *RRes,
-                                                     float2 *V, float2 *S, const int32_t *rank,
-                                                     int cnt, const TrialParams *prm, double *ce3,
-                                                     int Imax, int it)
+// (NT = 1024 for long vectors: one 256-thread workgroup per problem keeps too few loads in flight for 256 KiB arrays)
+template <int NT>
+__device__ __forceinline__ double block_sum_nt(double v, double *sh)
 {
-    __shared__ double sh[4];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) s += sh[w];
+    return s;
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void step_v_kernel(int g, const float2 *Res, const float2 *RRes,
+                                                    float2 *V, float2 *S, const int32_t *rank,
+                                                    int cnt, const TrialParams *prm, double *ce3,
+                                                    int Imax, int it)
+{
+    __shared__ double sh[NT / 64];
     const int t = blockIdx.x;
     const long long base = (long long)t * g;
     double num = 0, den_re = 0, den_im = 0, vprev = 0;
-    for (int i = threadIdx.x; i < g; i += 256) {
+    for (int i = threadIdx.x; i < g; i += NT) {
         const float2 r = Res[base + i], rr = RRes[base + i], v = V[base + i];
         num += (double)r.x * r.x + (double)r.y * r.y;
         den_re += (double)r.x * rr.x + (double)r.y * rr.y;      // Re(conj(r) * rr)
         den_im += (double)r.x * rr.y - (double)r.y * rr.x;      // Im(conj(r) * rr)
         vprev += (double)v.x * v.x + (double)v.y * v.y;
     }
-    num = block_sum(num, sh);
-    den_re = block_sum(den_re, sh);
-    den_im = block_sum(den_im, sh);
-    vprev = block_sum(vprev, sh);
+    num = block_sum_nt<NT>(num, sh);
+    den_re = block_sum_nt<NT>(den_re, sh);
+    den_im = block_sum_nt<NT>(den_im, sh);
+    vprev = block_sum_nt<NT>(vprev, sh);
     // alpha = num / (den_re + i den_im): complex scalar exactly as `res'*res/(res'*R*res)` (:48)
     const double dd = den_re * den_re + den_im * den_im;
     const float ax = (float)(num * den_re / dd);
     const float ay = (float)(-num * den_im / dd);
     const float thr = prm[t].tauS_rho;
-    for (int i = threadIdx.x; i < g; i += 256) {
+    for (int i = threadIdx.x; i < g; i += NT) {
         const float2 r = Res[base + i];
         float2 v = V[base + i];
         v.x += ax * r.x - ay * r.y;
@@ -284,8 +298,12 @@ int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const flo
                   float2 *S, const int32_t *rank, int cnt, const TrialParams *prm, double *ce3,
                   int Imax, int it)
 {
-    hipLaunchKernelGGL(step_v_kernel, dim3(batch), dim3(256), 0, ctx->stream, g, Res, RRes, V, S, rank,
-                       cnt, prm, ce3, Imax, it);
+    if (g >= 8192)
+        hipLaunchKernelGGL(step_v_kernel<1024>, dim3(batch), dim3(1024), 0, ctx->stream, g, Res, RRes, V, S, rank,
+                           cnt, prm, ce3, Imax, it);
+    else
+        hipLaunchKernelGGL(step_v_kernel<256>, dim3(batch), dim3(256), 0, ctx->stream, g, Res, RRes, V, S, rank,
+                           cnt, prm, ce3, Imax, it);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }
