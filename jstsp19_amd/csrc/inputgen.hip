@@ -313,12 +313,12 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     const size_t nH = (size_t)m.Nr * m.NtL, nPsi = (size_t)m.NtL * m.Tp, nR = (size_t)m.Nr * m.Tp, nY = (size_t)N * M,
                  nB = (size_t)m.G2 * M, nZ = (size_t)m.Gr * m.G2, nA = (size_t)N * m.Gr, nQ = (size_t)m.Nt * m.Tp;
     // ---- workspace -------------------------------------------------------------------------
+    JSTSP_REQUIRE(b * nZ < (1ull << 31), JSTSP_E_UNSUPPORTED, "build_trials: batch * Gr * G2 exceeds 2^31");
     size_t sort_tmp = 0;
     if (out->indx_S)
         JSTSP_HIP(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, sort_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr,
                                                    (int)(b * nZ), batch, (const int *)nullptr,
                                                    (const int *)nullptr, 0, 64, ctx->stream));
-    JSTSP_REQUIRE(b * nZ < (1ull << 31), JSTSP_E_UNSUPPORTED, "build_trials: batch * Gr * G2 exceeds 2^31");
     size_t need = 0;
     auto acc = [&](size_t bytes) { need += rnd256(bytes); };
     acc(b * m.L * m.Np * 8); acc(b * m.Np * 4); acc(b * m.Np * 4); acc(b * nR * 8); acc(b * nQ);       // draws
