@@ -112,12 +112,17 @@ __device__ __forceinline__ half8 neg_half8(uint4 u)
 
 // 64 x 64 output tile per 256-thread workgroup (2 x 2 waves of 32 x 32), two workgroups per CU.
 // LDS stage: a blocks [it 2][ks 2][plane 4] then b blocks [jt 2][ks 2][plane 4], 1 KiB each.
-template <int EPI, bool APACK>
-__global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i, int tiles_j)
+// WJ = waves along j: 2 (64 x 64 tile, 256 threads, two workgroups per CU) or 4 (64 x 128 tile, 512 threads, one
+// workgroup per CU: half as many workgroups split the same a panel).
+template <int EPI, bool APACK, int WJ>
+__global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmDesc d, int tiles_i, int tiles_j)
 {
+    constexpr int NT = 128 * WJ;                  // threads
+    constexpr int STG = 1024 + 512 * WJ;          // uint4 per LDS stage: 16 a blocks + 8 WJ b blocks of 64
+    constexpr int NA = (WJ == 2) ? 8 : 4;         // fp32 a elements per thread per stage
     // ONE LDS object indexed at run time: the compiler must then keep the stores that fill the next buffer behind
     // the fragment reads of the current one (with two objects it hoists them — and their vmcnt waits — above the MFMAs)
-    __shared__ uint4 smem[2 * 2048];
+    __shared__ uint4 smem[2 * STG];
 
     const int tiles = tiles_i * tiles_j;
     const int bid = blockIdx.x;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
     if (t >= d.batch) return;
     const int rem = slot % tiles;
     const int ti = rem % tiles_i, tj = rem / tiles_i;
-    const int i0 = ti * 64, j0 = tj * 64;
+    const int i0 = ti * 64, j0 = tj * 32 * WJ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
@@ -137,13 +142,15 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
 
     // a loader: thread -> (row i, run of 8 k); out-of-range elements are read from a valid dummy address
     // and zeroed at the split (no branches around the loads: a branch would carry its own vmcnt(0))
+    // WJ == 2: thread -> 8 consecutive k (one 16-byte fragment slot); WJ == 4: 4 consecutive k (half a slot)
     const int ai = tid & 63, akg = tid >> 6;
     const bool arow = (i0 + ai) < d.m;
     const float2 *abase = APACK ? nullptr : d.A + (long long)t * d.sAt;
-    const float2 *pa = APACK ? nullptr : abase + (arow ? (i0 + ai) : 0) + (long long)(8 * akg) * d.sAk;
-    const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
+    const float2 *pa = APACK ? nullptr : abase + (arow ? (i0 + ai) : 0) + (long long)(NA * akg) * d.sAk;
+    const int a_slot = (WJ == 2) ? ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31)
+                                 : ((((ai >> 5) * 2 + (akg >> 2)) * 4) * 64) + ((akg >> 1) & 1) * 32 + (ai & 31);
     // b loader: wave -> 4 fragment blocks of the stage (block q = wave*4 + r: jt = q>>3, ks = (q>>2)&1, plane = q&3)
-    const uint4 *pb = d.Bp + (long long)t * d.sPt + ((long long)(tj * 2) * d.KS) * 256 + lane;
+    const uint4 *pb = d.Bp + (long long)t * d.sPt + ((long long)(tj * WJ) * d.KS) * 256 + lane;
     const int nst = d.KS / 2;
     const int kfull = d.k / HBK;            // stages whose 32 k are all inside the product
 
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
     // before the MFMAs of stage s (prefetch distance 2: with distance 1 every stage waited ~2 us for HBM).
     // (b as four named registers, not an array: the array form was promoted to LDS by the compiler.)
     // APACK: the a operand arrives packed like b (d.Ap: [i-tile of 32][k-step][plane][lane]): no split here at all
-    struct StgF { float2 a[8]; uint4 b0, b1, b2, b3; };          // a as fp32 (split here)
+    struct StgF { float2 a[NA]; uint4 b0, b1, b2, b3; };         // a as fp32 (split here)
     struct StgP { u32x4 a0, a1, a2, a3; uint4 b0, b1, b2, b3; };  // a already packed (native vectors: uint4 members
                                                                   // were promoted to LDS / scratch by the compiler)
     using Stg = typename std::conditional<APACK, StgP, StgF>::type;
@@ -173,11 +180,11 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
         } else {
             if (s < kfull) {
 #pragma unroll
-                for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
+                for (int v = 0; v < NA; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
             } else {
-                const int kbase = s * HBK + 8 * akg;
+                const int kbase = s * HBK + NA * akg;
 #pragma unroll
-                for (int v = 0; v < 8; ++v) {
+                for (int v = 0; v < NA; ++v) {
                     const bool ok = kbase + v < d.k;
                     const float2 *p = ok ? pa + (long long)(s * HBK + v) * d.sAk : abase;
                     const float2 x = *p;
@@ -193,18 +200,26 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
             u32x4 *q = reinterpret_cast<u32x4 *>(buf + wave * 256 + lane);
             q[0] = R.a0; q[64] = R.a1; q[128] = R.a2; q[192] = R.a3;
         } else {
-            half8 rh, rl, ih, il;
+            half8 rh = {0}, rl = {0}, ih = {0}, il = {0};
 #pragma unroll
-            for (int v = 0; v < 8; ++v) {
+            for (int v = 0; v < NA; ++v) {
                 _Float16 h, l;
                 split2(R.a[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
                 split2(R.a[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
             }
-            uint4 *q = buf + a_slot;
-            q[0] = *reinterpret_cast<uint4 *>(&rh);
-            q[64] = *reinterpret_cast<uint4 *>(&rl);
-            q[128] = *reinterpret_cast<uint4 *>(&ih);
-            q[192] = *reinterpret_cast<uint4 *>(&il);
+            if constexpr (WJ == 2) {
+                uint4 *q = buf + a_slot;
+                q[0] = *reinterpret_cast<uint4 *>(&rh);
+                q[64] = *reinterpret_cast<uint4 *>(&rl);
+                q[128] = *reinterpret_cast<uint4 *>(&ih);
+                q[192] = *reinterpret_cast<uint4 *>(&il);
+            } else {            // 4 halves = the lower or upper 8 bytes of the 16-byte slot
+                uint2 *q = reinterpret_cast<uint2 *>(buf + a_slot) + (akg & 1);
+                q[0] = *reinterpret_cast<uint2 *>(&rh);
+                q[2 * 64] = *reinterpret_cast<uint2 *>(&rl);
+                q[2 * 128] = *reinterpret_cast<uint2 *>(&ih);
+                q[2 * 192] = *reinterpret_cast<uint2 *>(&il);
+            }
         }
     };
 
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void hgemm_kernel(HGemmDesc d, int tiles_i,
 
     // ---- prologue
     Stg R0, R1;
-    uint4 *buf0 = smem, *buf1 = smem + 2048;
+    uint4 *buf0 = smem, *buf1 = smem + STG;
     load(0, R0);
     if (nst > 1) load(1, R1);
     store(R0, buf0);
@@ -440,7 +455,7 @@ bool use_hgemm(long long m, long long n, long long k)
 
 size_t hgemm_pack_bytes(int Kd, int J, int count)
 {
-    const size_t KS = 2 * (size_t)((Kd + 31) / 32), JT = 2 * (size_t)((J + 63) / 64);
+    const size_t KS = 2 * (size_t)((Kd + 31) / 32), JT = 4 * (size_t)((J + 127) / 128);
     return rnd256((size_t)count * JT * KS * 4096) + rnd256((size_t)count * sizeof(uint32_t));
 }
 
@@ -457,7 +472,7 @@ int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long s
                int conj, int Kd, int J, int count, long long n_contig)
 {
     p.KS = 2 * ((Kd + 31) / 32);
-    p.JT = 2 * ((J + 63) / 64);
+    p.JT = 4 * ((J + 127) / 128);          // j padded to the 128-wide tile of the 8-wave kernel
     p.count = count;
     p.st = (long long)p.JT * p.KS * 256;
     p.data = ar.get<uint4>((size_t)count * p.st);
@@ -500,21 +515,26 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
     JSTSP_REQUIRE(d.m > 0 && d.n > 0 && d.k > 0 && d.batch > 0, JSTSP_E_SHAPE, "hgemm: bad shape");
     JSTSP_REQUIRE(d.KS >= 2 * ((d.k + 31) / 32) && d.JT >= 2 * ((d.n + 63) / 64), JSTSP_E_ARG,
                   "hgemm: packed operand smaller than the product");
-    const int tiles_i = (d.m + 63) / 64, tiles_j = (d.n + 63) / 64;
+    // 64 x 128 tiles (8 waves) for long contractions whose a operand is split in the kernel: half as many splits
+    static const int wj_env = getenv("JSTSP_H2_WJ") ? atoi(getenv("JSTSP_H2_WJ")) : 4;
+    const bool wide = wj_env == 4 && !d.Ap && d.epi == EPI_NONE && d.n >= 128 && d.JT * 32 >= ((d.n + 127) / 128) * 128;
+    const int tiles_i = (d.m + 63) / 64, tiles_j = wide ? (d.n + 127) / 128 : (d.n + 63) / 64;
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_i * tiles_j;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
     if (prof_name) prof_begin(ctx, prof_name);
-    if (d.Ap) {
+    if (wide) {
+        hgemm_kernel<EPI_NONE, false, 4><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+    } else if (d.Ap) {
         JSTSP_REQUIRE(d.aKS == d.KS, JSTSP_E_ARG, "hgemm: packed a and b operands disagree on the k padding");
         if (d.epi == EPI_UPDATE_C)
-            hgemm_kernel<EPI_UPDATE_C, true><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+            hgemm_kernel<EPI_UPDATE_C, true, 2><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
         else
-            hgemm_kernel<EPI_NONE, true><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+            hgemm_kernel<EPI_NONE, true, 2><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     } else if (d.epi == EPI_UPDATE_C)
-        hgemm_kernel<EPI_UPDATE_C, false><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+        hgemm_kernel<EPI_UPDATE_C, false, 2><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     else
-        hgemm_kernel<EPI_NONE, false><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+        hgemm_kernel<EPI_NONE, false, 2><<<(unsigned)grid, 256, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     if (prof_name) prof_end(ctx, prof_name);
     JSTSP_HIP(hipGetLastError());
     return 0;
