@@ -45,7 +45,9 @@ enum {
     JSTSP_E_SHAPE = -2,     /* non-positive / inconsistent dimensions        */
     JSTSP_E_UNSUPPORTED = -3, /* shape outside what the kernels implement    */
     JSTSP_E_ARG = -4,       /* bad enum / flag value                         */
-    JSTSP_E_NOMEM = -5      /* workspace allocation failed                   */
+    JSTSP_E_NOMEM = -5,     /* workspace allocation failed                   */
+    JSTSP_E_ILLCOND = -6    /* a factor Gram is too ill-conditioned for the fp32 Gram-inverse path (JSTSP_HOST calls;
+                               JSTSP_DEVICE calls are asynchronous: query jstsp_last_conditioning) */
 };
 
 /* type argument of proposed_algorithm: 'approximate' vs anything else ('std')
@@ -108,11 +110,29 @@ int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
                                  jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out,
                                  int memspace);
 
-/* S_ls = pinv(A)*Y*pinv(B)   — the LS baseline of the drivers (plot_errorVSsnr.m:83) for full-rank factors
- * (N >= Gr, M >= G2).  Y: N x M x batch; S_out: Gr x G2 x batch. */
+/* S_ls = pinv(A)*Y*pinv(B)   — the LS baseline of the drivers (plot_errorVSsnr.m:83).
+ * Factors that fit the in-LDS float64 pinv kernel (see jstsp_pinv_c32; every shape the reference's drivers use)
+ * get MATLAB's SVD-based pinv, any rank, any aspect ratio.  Larger factors take the fp32 Gram-inverse route
+ * G_A^-1 A^H Y B^H G_B^-1, which needs full rank (N >= Gr, M >= G2, else JSTSP_E_UNSUPPORTED) and loses
+ * cond(G) * 6e-8 of relative accuracy: eigenvalues below n*eps*lambda_max are dropped as pinv would, and a
+ * JSTSP_HOST call returns JSTSP_E_ILLCOND when lambda_min/lambda_max < 1e-6 (JSTSP_DEVICE: jstsp_last_conditioning).
+ * Y: N x M x batch; S_out: Gr x G2 x batch. */
 int jstsp_ls_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *Y,
                  const jstsp_c32 *A, long long strideA, const jstsp_c32 *B, long long strideB,
                  jstsp_c32 *S_out, int memspace);
+
+/* P = pinv(A)   — MATLAB's pinv as the drivers call it (plot_errorVSsnr.m:83): SVD-based (one-sided Jacobi in
+ * float64 on the device), singular values <= max(size(A))*eps(norm(A)) dropped.  A: rows x cols x batch,
+ * P: cols x rows x batch.  The matrix must fit the in-LDS kernel: (max*min + min^2) * 16 B <= 156 KiB
+ * (e.g. 64 x 64, 140 x 16, 512 x 16), else JSTSP_E_UNSUPPORTED. */
+int jstsp_pinv_c32(jstsp_ctx *ctx, int rows, int cols, int batch, const jstsp_c32 *A, jstsp_c32 *P, int memspace);
+
+/* Conditioning of the last call on this context that (pseudo-)inverted a dictionary factor (jstsp_ls_c32,
+ * jstsp_pinv_c32, proposed_algorithm 'std'): *rcond_min = the smallest sigma_min/sigma_max of a factor (for the fp32
+ * Gram-inverse path of factors too large for the pinv kernel: sqrt(lambda_min/lambda_max) of the Gram, and the
+ * relative accuracy of that path is about 6e-8 / rcond^2); *ns_residual_max = the largest max|I - G X| left by the Newton-Schulz
+ * inverse of Grams of order > 128 (0 if none ran).  Synchronises the context's stream.  Either pointer may be NULL. */
+int jstsp_last_conditioning(jstsp_ctx *ctx, double *rcond_min, double *ns_residual_max);
 
 /* X = svt(Y, tau)   benchmark_algorithms/svt.m:1-15.   Y, X: Mr x Mt x batch; tau host double[batch]. */
 int jstsp_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Y,

@@ -50,6 +50,8 @@ SIGNATURES = {
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "jstsp_ls_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
                              c_void_p, c_int]),
+    "jstsp_pinv_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
+    "jstsp_last_conditioning": (c_int, [c_void_p, c_dp, c_dp]),
     "jstsp_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_dp, c_void_p, c_int]),
     "jstsp_omp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p,
                               c_void_p, c_void_p, c_int]),
@@ -150,6 +152,12 @@ class Context:
         check(self._lib.jstsp_get_profile(self.handle, kernel.encode(), C.byref(n), C.byref(ms)),
               "jstsp_get_profile")
         return n.value, ms.value
+
+    def last_conditioning(self):
+        """(rcond_min, ns_residual_max) of the last call that (pseudo-)inverted a dictionary factor."""
+        rc, res = C.c_double(1.0), C.c_double(0.0)
+        check(self._lib.jstsp_last_conditioning(self.handle, C.byref(rc), C.byref(res)), "jstsp_last_conditioning")
+        return rc.value, res.value
 
     def close(self):
         if self._h is not None:

@@ -74,7 +74,6 @@ static int check_common(jstsp_ctx *ctx, int memspace)
 {
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
-    JSTSP_HIP(hipSetDevice(ctx->device));
     return 0;
 }
 
@@ -103,6 +102,7 @@ int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
                         jstsp_c32 *out, int memspace)
 {
     JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(K_ && A_ && B_ && out, JSTSP_E_NULL, "correlate: NULL array argument");
     JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0, JSTSP_E_SHAPE, "correlate: bad shape");
     const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
@@ -149,6 +149,7 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
                          jstsp_c32 *out, int memspace)
 {
     JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(S_ && A_ && B_ && out, JSTSP_E_NULL, "synthesize: NULL array argument");
     JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0, JSTSP_E_SHAPE, "synthesize: bad shape");
     const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
@@ -192,21 +193,26 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
 int jstsp_ls_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *Y_, const jstsp_c32 *A_,
                  long long strideA, const jstsp_c32 *B_, long long strideB, jstsp_c32 *S_out, int memspace)
 {
-    // S_ls = pinv(A)*Y*pinv(B) (plot_errorVSsnr.m:83) for full-rank factors:
-    //   pinv(A) = (A^H A)^-1 A^H (N >= Gr),  pinv(B) = B^H (B B^H)^-1 (M >= G2)
-    //   => S = G_A^-1 (A^H Y B^H) G_B^-1 : the correlation kernel + two small Hermitian inverses.
+    // S_ls = pinv(A)*Y*pinv(B) (plot_errorVSsnr.m:83).  Per factor:
+    //   fits the in-LDS float64 kernel (pinv.hip; every shape of the reference's drivers): SVD-based pinv as MATLAB's;
+    //   larger: pinv(A) = (A^H A)^-1 A^H (N >= Gr), pinv(B) = B^H (B B^H)^-1 (M >= G2) through the fp32 Gram inverse
+    //           (hinv.hip), conditioning recorded / checked.
     JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(Y_ && A_ && B_ && S_out, JSTSP_E_NULL, "ls: NULL array argument");
     JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0, JSTSP_E_SHAPE, "ls: bad shape");
-    JSTSP_REQUIRE(N >= Gr && M >= G2, JSTSP_E_UNSUPPORTED,
-                  "ls: pinv is implemented for full column rank A (N >= Gr) and full row rank B (M >= G2)");
+    const bool pA = pinv_fits(N, Gr), pB = pinv_fits(G2, M);
+    JSTSP_REQUIRE((pA || N >= Gr) && (pB || M >= G2), JSTSP_E_UNSUPPORTED,
+                  "ls: a factor too large for the float64 pinv kernel must have full rank (A: N >= Gr, B: M >= G2)");
     const size_t nm = (size_t)N * M, g = (size_t)Gr * G2, ng = (size_t)N * G2;
     const int nA = strideA ? batch : 1, nB = strideB ? batch : 1;
     const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
     const size_t szB = strideB ? (size_t)strideB * (batch - 1) + (size_t)G2 * M : (size_t)G2 * M;
-    size_t need = rnd256(batch * ng * sizeof(float2)) + 3 * rnd256(batch * g * sizeof(float2)) +
-                  2 * rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + 2 * rnd256((size_t)nB * G2 * G2 * sizeof(float2)) +
-                  std::max(hinv_bytes(Gr, nA), hinv_bytes(G2, nB));
+    size_t need = 2 * rnd256(batch * ng * sizeof(float2)) + 3 * rnd256(batch * g * sizeof(float2));
+    need += pA ? rnd256((size_t)nA * Gr * N * sizeof(float2))
+               : 2 * rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + hinv_bytes(Gr, nA);
+    need += pB ? rnd256((size_t)nB * M * G2 * sizeof(float2))
+               : 2 * rnd256((size_t)nB * G2 * G2 * sizeof(float2)) + hinv_bytes(G2, nB);
     if (memspace == JSTSP_HOST)
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -216,27 +222,80 @@ int jstsp_ls_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const 
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Y_), batch * nm, memspace, &Y));
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(B_), szB, memspace, &B));
-    float2 *Tc = a.get<float2>(batch * ng), *R1 = a.get<float2>(batch * g), *R2 = a.get<float2>(batch * g),
+    JSTSP_TRY(diag_reset(ctx));
+    float2 *Tc = a.get<float2>(batch * ng), *Tc2 = a.get<float2>(batch * ng), *R1 = a.get<float2>(batch * g),
            *S = a.get<float2>(batch * g);
-    float2 *GA = a.get<float2>((size_t)nA * Gr * Gr), *GAi = a.get<float2>((size_t)nA * Gr * Gr);
-    float2 *GB = a.get<float2>((size_t)nB * G2 * G2), *GBi = a.get<float2>((size_t)nB * G2 * G2);
-    JSTSP_REQUIRE(Tc && R1 && R2 && S && GA && GAi && GB && GBi, JSTSP_E_NOMEM, "ls: workspace exhausted");
+    JSTSP_REQUIRE(Tc && Tc2 && R1 && S, JSTSP_E_NOMEM, "ls: workspace exhausted");
     const Mat Am{A, strideA, N}, Bm{B, strideB, G2};
-    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, GA, (long long)Gr * Gr, Gr));
-    JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, GB, (long long)G2 * G2, G2));
-    const size_t mark = a.off;
-    JSTSP_TRY(hermitian_inverse(ctx, Gr, nA, GA, GAi));
-    a.off = mark;
-    JSTSP_TRY(hermitian_inverse(ctx, G2, nB, GB, GBi));
-    a.off = mark;
     const long long sg = (long long)g, sng = (long long)ng;
-    JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{Y, (long long)nm, N}, Bm, Tc, sng, N, 1.f, nullptr, 0, 0, 0.f,
-                   GEMM_CORRELATE));
-    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{Tc, sng, N}, R1, sg, Gr));
-    JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, Mat{GAi, strideA ? (long long)Gr * Gr : 0, Gr}, Mat{R1, sg, Gr}, R2, sg, Gr));
-    JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{R2, sg, Gr}, Mat{GBi, strideB ? (long long)G2 * G2 : 0, G2}, S, sg, Gr));
+    // ---- B side: Tc = Y pinv(B)   (N x G2)
+    if (pB) {
+        float2 *PB = a.get<float2>((size_t)nB * M * G2);
+        JSTSP_REQUIRE(PB, JSTSP_E_NOMEM, "ls: workspace exhausted");
+        JSTSP_TRY(launch_pinv(ctx, G2, M, nB, B, strideB, G2, PB, (long long)M * G2, M));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, M, batch, Mat{Y, (long long)nm, N}, Mat{PB, strideB ? (long long)M * G2 : 0, M},
+                       Tc, sng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
+    } else {
+        float2 *GB = a.get<float2>((size_t)nB * G2 * G2), *GBi = a.get<float2>((size_t)nB * G2 * G2);
+        JSTSP_REQUIRE(GB && GBi, JSTSP_E_NOMEM, "ls: workspace exhausted");
+        JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, GB, (long long)G2 * G2, G2));
+        const size_t mark = a.off;
+        JSTSP_TRY(hermitian_inverse(ctx, G2, nB, GB, GBi));
+        a.off = mark;
+        JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{Y, (long long)nm, N}, Bm, Tc2, sng, N, 1.f, nullptr, 0, 0, 0.f,
+                       GEMM_CORRELATE));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, G2, batch, Mat{Tc2, sng, N}, Mat{GBi, strideB ? (long long)G2 * G2 : 0, G2},
+                       Tc, sng, N));
+    }
+    // ---- A side: S = pinv(A) Tc   (Gr x G2)
+    if (pA) {
+        float2 *PA = a.get<float2>((size_t)nA * Gr * N);
+        JSTSP_REQUIRE(PA, JSTSP_E_NOMEM, "ls: workspace exhausted");
+        JSTSP_TRY(launch_pinv(ctx, N, Gr, nA, A, strideA, N, PA, (long long)Gr * N, Gr));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, N, batch, Mat{PA, strideA ? (long long)Gr * N : 0, Gr}, Mat{Tc, sng, N}, S, sg,
+                       Gr));
+    } else {
+        float2 *GA = a.get<float2>((size_t)nA * Gr * Gr), *GAi = a.get<float2>((size_t)nA * Gr * Gr);
+        JSTSP_REQUIRE(GA && GAi, JSTSP_E_NOMEM, "ls: workspace exhausted");
+        JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, GA, (long long)Gr * Gr, Gr));
+        const size_t mark = a.off;
+        JSTSP_TRY(hermitian_inverse(ctx, Gr, nA, GA, GAi));
+        a.off = mark;
+        JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{Tc, sng, N}, R1, sg, Gr));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, Mat{GAi, strideA ? (long long)Gr * Gr : 0, Gr}, Mat{R1, sg, Gr}, S,
+                       sg, Gr));
+    }
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), S, batch * g, memspace));
-    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    if (memspace == JSTSP_HOST) {
+        JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+        JSTSP_TRY(diag_check_host(ctx, "ls"));
+    }
+    return 0;
+}
+
+int jstsp_pinv_c32(jstsp_ctx *ctx, int rows, int cols, int batch, const jstsp_c32 *A_, jstsp_c32 *P_, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
+    JSTSP_REQUIRE(A_ && P_, JSTSP_E_NULL, "pinv: NULL array argument");
+    JSTSP_REQUIRE(rows > 0 && cols > 0 && batch > 0, JSTSP_E_SHAPE, "pinv: bad shape");
+    JSTSP_REQUIRE(pinv_fits(rows, cols), JSTSP_E_UNSUPPORTED,
+                  "pinv: %d x %d does not fit the in-LDS float64 kernel ((max*min + min^2) * 16 B <= 156 KiB)", rows, cols);
+    const size_t n = (size_t)rows * cols;
+    size_t need = rnd256(batch * n * sizeof(float2));
+    if (memspace == JSTSP_HOST) need += rnd256(batch * n * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *A;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), batch * n, memspace, &A));
+    float2 *P = memspace == JSTSP_DEVICE ? reinterpret_cast<float2 *>(P_) : ctx->arena.get<float2>(batch * n);
+    JSTSP_REQUIRE(P, JSTSP_E_NOMEM, "pinv: workspace exhausted");
+    JSTSP_TRY(diag_reset(ctx));
+    JSTSP_TRY(launch_pinv(ctx, rows, cols, batch, A, (long long)n, rows, P, (long long)n, cols));
+    if (memspace == JSTSP_HOST) {
+        JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(P_), P, batch * n, memspace));
+        JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return 0;
 }
 
@@ -244,6 +303,7 @@ int jstsp_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Y_
                   jstsp_c32 *X_, int memspace)
 {
     JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(Y_ && tau && X_, JSTSP_E_NULL, "svt: NULL argument");
     JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0, JSTSP_E_SHAPE, "svt: bad shape");
     JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "svt: min(Mr, Mt) = %d > 128",
@@ -272,6 +332,7 @@ int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp
                             const jstsp_c32 *Zbar_, double *nmse, int memspace)
 {
     JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(S_ && Zbar_ && nmse, JSTSP_E_NULL, "nmse: NULL argument");
     JSTSP_REQUIRE(R > 0 && C > 0 && batch > 0, JSTSP_E_SHAPE, "nmse: bad shape");
     JSTSP_REQUIRE(std::min(R, C) <= 128, JSTSP_E_UNSUPPORTED, "nmse: min(R, C) = %d > 128", std::min(R, C));
@@ -307,6 +368,7 @@ int jstsp_mc_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 
                      int Imax, const double *tau, const double *rho, jstsp_c32 *X_out, int memspace)
 {
     JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(OH_ && Omega_ && tau && rho && X_out, JSTSP_E_NULL, "mc_svt: NULL argument");
     JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0 && Imax >= 0, JSTSP_E_SHAPE, "mc_svt: bad shape");
     JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "mc_svt: min(Mr, Mt) = %d > 128",
@@ -345,6 +407,7 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
                       const double *rho, jstsp_c32 *X_out, double *ce_out, int memspace)
 {
     JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(OH_ && Omega_ && tau && rho && X_out, JSTSP_E_NULL, "mc_admm: NULL argument");
     JSTSP_REQUIRE(!ce_out || Htrue_, JSTSP_E_NULL, "mc_admm: convergence_error needs Htrue");
     JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0 && Imax >= 0, JSTSP_E_SHAPE, "mc_admm: bad shape");

@@ -37,6 +37,28 @@ void set_error(const char *fmt, ...);
         }                                                                                \
     } while (0)
 
+// Makes the context's device current for the duration of an API call and restores the caller's current device on
+// every exit path (a caller that keeps its tensors on another GPU must not find its current device changed).
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = (err == hipSuccess);
+        }
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+#define JSTSP_ENTER(ctx)                                                                 \
+    jstsp::DeviceScope dev_scope_((ctx)->device);                                        \
+    JSTSP_HIP(dev_scope_.err)
+
 // Per-problem scalars of the ADMM solvers, resident on the device.
 struct TrialParams {
     float rho, irho;        // rho, 1/rho
@@ -86,6 +108,10 @@ struct jstsp_ctx {
     bool pinned_pending = false;
     // side streams + events used by the ADMM driver to run the next iteration's SVT preparation
     // and the convergence-error norms concurrently with the MFMA-bound GEMMs of the main stream
+    // conditioning record of the last call that (pseudo-)inverted something (pinv.hip / hinv.hip), device memory:
+    // float bits of [0] the smallest sigma_min/sigma_max met by the float64 pinv kernel, [1] the largest Newton-Schulz
+    // residual max|I - G X|, [2] the smallest lambda_min/lambda_max of an eigen-inverted factor Gram
+    uint32_t *diag = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -9,9 +9,11 @@
 // proposed_algorithm.m:67,69 (`norm(V1)^2/norm(X)^2` = lambda_max ratio).
 //
 // Guard of svt.m:8-12: the reference zeroes the output when any singular value is exactly 0
-// (0/0 = NaN in :7).  On the path this happens for the all-zero input of iteration 1; here
-// an all-zero G gives Q = I, i.e. Z - Q Z = 0 — the same result (see DESIGN.md for the
-// rank-deficient non-zero case, where LAPACK's exact zeros are platform-dependent).
+// (0/0 = NaN in :7).  Reproduced for the one input whose zero is exact in every LAPACK, the
+// all-zero matrix (the svt argument of iteration 1): all-zero Gram => Q = I, i.e. Z - Q Z = 0.
+// For rank-deficient non-zero inputs LAPACK's zeros are only sometimes exact (a zero LAST row
+// gives 0.0, a zero first or middle row 4e-16 with numpy's gesdd — DESIGN.md §5); such singular
+// values are treated as <= tau (component removed), which is what the oracle computes then.
 #include "common.h"
 
 namespace jstsp {
@@ -80,6 +82,20 @@ __global__ __launch_bounds__(256) void jacobi_kernel(int mode, int n, int batch,
         }
     }
     __syncthreads();
+
+    // Guard of svt.m:7-12 (see jacobi2_kernel in eig2.hip): all-zero Gram = all-zero svt argument => output 0, i.e. Q = I.
+    if (WITH_V && mode == EIG_SVT_Q) {
+        if (tid == 0) red[2] = 0.f;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256)
+            if (G[i + ld * i].x != 0.f) red[2] = 1.f;
+        __syncthreads();
+        if (red[2] == 0.f) {
+            for (int e = tid; e < n * n; e += 256)
+                Q[(size_t)t * n * n + e] = make_float2((e % n == e / n) ? 1.f : 0.f, 0.f);
+            return;
+        }
+    }
 
     // dmax = largest diagonal entry: the absolute scale of the convergence test
     {

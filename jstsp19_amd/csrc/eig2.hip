@@ -126,6 +126,25 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
         U[i + LD * j] = (warm && Uw) ? Uw[e] : make_float2(i == j ? 1.f : 0.f, 0.f);
     }
     __syncthreads();
+    // Guard of svt.m:7-12: a singular value that is exactly 0 makes softThres NaN and the reference returns the ZERO
+    // matrix.  The one input for which LAPACK's zero is exact on every platform is the all-zero matrix (the svt
+    // argument of the first ADMM iteration): all-zero Gram => Q = I, i.e. Y = Z - Q Z = 0, without any sweep.
+    // (A zero row in the middle of the input gives sigma_min ~ 1e-16, not 0, in LAPACK's gesdd — see DESIGN.md; such
+    // components are simply removed by the threshold, as the oracle does.)
+    if (mode == EIG_SVT_Q) {
+        if (tid == 0) red[2] = 0.f;
+        __syncthreads();
+        for (int i = tid; i < n; i += NT)
+            if (G[i + LD * i].x != 0.f) red[2] = 1.f;
+        __syncthreads();
+        if (red[2] == 0.f) {
+            for (int e = tid; e < n * n; e += NT)
+                Q[(size_t)t * n * n + e] = make_float2((e % n == e / n) ? 1.f : 0.f, 0.f);
+            if (Uw && !warm)        // the caller treats the basis as valid from now on
+                for (int e = tid; e < NE * NE; e += NT) Uw[e] = make_float2((e % NE == e / NE) ? 1.f : 0.f, 0.f);
+            return;
+        }
+    }
     if (warm && Uw) {
         // G' = U^H (G U)
         lds_cgemm<NE, false, false>(G, 1, LD, U, 1, LD, T, LD, nullptr, 0, NE);

@@ -288,7 +288,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "build_trials: NULL context");
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "build_trials: bad memspace");
     JSTSP_REQUIRE(mp && out, JSTSP_E_NULL, "build_trials: NULL argument");
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     Model m;
     m.Nt = mp->Nt; m.Nr = mp->Nr; m.L = mp->L; m.Tp = mp->T_prop; m.Mr = mp->Mr; m.Mr_e = mp->Mr_e;
     m.Gr = mp->Gr; m.Gt = mp->Gt; m.clusters = mp->clusters; m.rays = mp->rays;

@@ -394,7 +394,7 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
     JSTSP_REQUIRE(m <= 1024, JSTSP_E_UNSUPPORTED, "OMP: m = %d > 1024", m);
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
     JSTSP_REQUIRE(strideA == 0 || strideA >= (long long)meas * size_d, JSTSP_E_SHAPE, "strideA too small");
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)meas * size_d : (size_t)meas * size_d;
     size_t need = omp_bytes(meas, m, batch) + rnd256((size_t)batch * size_d * sizeof(float2)) * 2 +
                   rnd256((size_t)batch * m * sizeof(int32_t)) + rnd256((size_t)batch * meas * m * sizeof(float2));
@@ -445,7 +445,7 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
     JSTSP_REQUIRE(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0 && m > 0, JSTSP_E_SHAPE, "omp_kron: bad shape");
     JSTSP_REQUIRE(m <= 1024, JSTSP_E_UNSUPPORTED, "omp_kron: m = %d > 1024", m);
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     {
         // Coefficient-domain OMP (omp_gram_kernel): one correlation, the two factor Grams, one kernel for all m
         // iterations.  JSTSP_OMP_GRAM=0 keeps the measurement-space Gram-Schmidt below (also used when the
@@ -496,12 +496,9 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
                                GEMM_CORRELATE));
             }
             JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{Tc, (long long)ng, N}, c0, (long long)g, Gr));  // Phi^H v
-            static bool attr_set = false;
-            if (!attr_set) {
-                JSTSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(omp_gram_kernel<1024>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                attr_set = true;
-            }
+            // per launch, like every other kernel: the attribute is per device and a process may hold contexts on several
+            JSTSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(omp_gram_kernel<1024>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             hipLaunchKernelGGL(omp_gram_kernel<1024>, dim3(batch), dim3(1024), lds, ctx->stream, size_d, m, Gr, G2, c0, cw,
                                GA, strideA ? (long long)Gr * Gr : 0, GB, strideB ? (long long)G2 * G2 : 0, xh, io);
             JSTSP_HIP(hipGetLastError());

@@ -91,8 +91,10 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false));
     w.h2 = use_hgemm(N, G2, M);
     if (w.h2) {
-        // operand maxima of one iteration, one block zeroed once per iteration: kmax | X | V1 | V2 | Znext | wmax | pmax x2
-        w.kmax = a.get<uint32_t>(8 * (size_t)batch);
+        // operand maxima of one iteration, one block zeroed once per iteration: kmax | X | V1 | V2 | Znext | wmax | pmax x2.
+        // TWO blocks, used by even / odd iterations: with JSTSP_OVERLAP=1 the side-stream Grams of iteration i still
+        // read their maxima while the main stream starts iteration i+1, whose memset must not touch those words.
+        w.kmax = a.get<uint32_t>(16 * (size_t)batch);
         JSTSP_REQUIRE(w.kmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
         w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch; w.wmax = w.kmax + 5 * (size_t)batch;
         w.pmax = w.kmax + 6 * (size_t)batch;
@@ -140,7 +142,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_REQUIRE(approx || (N >= Gr && M >= G2), JSTSP_E_UNSUPPORTED,
                   "proposed_algorithm 'std': K2 = kron(B.', A) must have full column rank (N >= Gr, M >= G2); the "
                   "under-determined U\\(L\\k) of the reference returns a basic, not least-squares, solution");
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
 
     const bool angles = indx_S_ != nullptr;
     const bool want_ce = ce_out != nullptr;
@@ -151,8 +153,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
 
     size_t need = proposed_bytes(N, M, Gr, G2, batch, nA, nB, angles, want_ce, std::max(Imax, 1));
     if (!approx)
-        need += rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + rnd256((size_t)nB * G2 * G2 * sizeof(float2)) +
-                std::max(hinv_bytes(Gr, nA), hinv_bytes(G2, nB));
+        need += (pinv_fits(N, Gr) ? rnd256((size_t)nA * Gr * N * sizeof(float2))
+                                  : rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + hinv_bytes(Gr, nA)) +
+                (pinv_fits(G2, M) ? rnd256((size_t)nB * M * G2 * sizeof(float2))
+                                  : rnd256((size_t)nB * G2 * G2 * sizeof(float2)) + hinv_bytes(G2, nB));
     if (memspace == JSTSP_HOST) {
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
                 rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
@@ -221,18 +225,37 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     if (w.h2g && approx)
         JSTSP_TRY(hgemm_pack(ctx, w.GBp, ctx->arena, w.GB, strideB ? (long long)G2 * G2 : 0, 1, G2, 0, G2, G2, nB,
                              (long long)G2 * G2));
+    // 'std': v = U\(L\k) (:29,:53) is the least-squares solution K2^+ k = vec(pinv(A) K pinv(B)) for K2 = kron(B.', A)
+    // of full column rank.  Factors that fit the in-LDS float64 kernel get a true SVD-based pinv (pinv.hip: every shape
+    // of the reference's drivers); larger ones the fp32 Gram inverse G^-1 (hinv.hip), kept in GA / GB, with its
+    // conditioning recorded (JSTSP_E_ILLCOND / jstsp_last_conditioning).
+    float2 *PA = nullptr, *PB = nullptr;          // pinv(A): Gr x N per problem;  pinv(B): M x G2 per problem
     if (!approx) {
-        // 'std': v = U\(L\k) (:29,:53) = vec(G_A^-1 A^H K B^H G_B^-1): invert the two factor Grams once
-        // (into P1 / RV-sized scratch is too small for G_B: use the arena), then keep them in GA / GB.
-        float2 *GAi = ctx->arena.get<float2>((size_t)nA * Gr * Gr), *GBi = ctx->arena.get<float2>((size_t)nB * G2 * G2);
-        JSTSP_REQUIRE(GAi && GBi, JSTSP_E_NOMEM, "proposed_algorithm 'std': workspace exhausted");
+        JSTSP_TRY(diag_reset(ctx));
+        if (pinv_fits(N, Gr)) {
+            PA = ctx->arena.get<float2>((size_t)nA * Gr * N);
+            JSTSP_REQUIRE(PA, JSTSP_E_NOMEM, "proposed_algorithm 'std': workspace exhausted");
+            JSTSP_TRY(launch_pinv(ctx, N, Gr, nA, A, strideA, N, PA, (long long)Gr * N, Gr));
+        }
+        if (pinv_fits(G2, M)) {
+            PB = ctx->arena.get<float2>((size_t)nB * M * G2);
+            JSTSP_REQUIRE(PB, JSTSP_E_NOMEM, "proposed_algorithm 'std': workspace exhausted");
+            JSTSP_TRY(launch_pinv(ctx, G2, M, nB, B, strideB, G2, PB, (long long)M * G2, M));
+        }
+        float2 *GAi = PA ? nullptr : ctx->arena.get<float2>((size_t)nA * Gr * Gr);
+        float2 *GBi = PB ? nullptr : ctx->arena.get<float2>((size_t)nB * G2 * G2);
+        JSTSP_REQUIRE((PA || GAi) && (PB || GBi), JSTSP_E_NOMEM, "proposed_algorithm 'std': workspace exhausted");
         const size_t mark = ctx->arena.off;
-        JSTSP_TRY(hermitian_inverse(ctx, Gr, nA, w.GA, GAi));
-        ctx->arena.off = mark;
-        JSTSP_TRY(hermitian_inverse(ctx, G2, nB, w.GB, GBi));
-        ctx->arena.off = mark;
-        JSTSP_HIP(hipMemcpyAsync(w.GA, GAi, (size_t)nA * Gr * Gr * sizeof(float2), hipMemcpyDeviceToDevice, st));
-        JSTSP_HIP(hipMemcpyAsync(w.GB, GBi, (size_t)nB * G2 * G2 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        if (!PA) {
+            JSTSP_TRY(hermitian_inverse(ctx, Gr, nA, w.GA, GAi));
+            ctx->arena.off = mark;
+            JSTSP_HIP(hipMemcpyAsync(w.GA, GAi, (size_t)nA * Gr * Gr * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        }
+        if (!PB) {
+            JSTSP_TRY(hermitian_inverse(ctx, G2, nB, w.GB, GBi));
+            ctx->arena.off = mark;
+            JSTSP_HIP(hipMemcpyAsync(w.GB, GBi, (size_t)nB * G2 * G2 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        }
     }
     const long long snm = (long long)nm, sg = (long long)g, sng = (long long)ng;
     // Streams.  The critical path of an iteration is MFMA-bound
@@ -245,13 +268,16 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     //       V2 after update_c, then lambda_max of all three.
     // Buffer hazards are closed by events: update_x(i+1) waits for s1 (needs Q) and for s2's Gram of
     // [X | V1] (reads what update_x overwrites); update_c(i+1) waits for s2's Gram of V2.
+    // The per-iteration memset of the operand maxima is double-buffered by iteration parity for the same reason.
     // Default: everything on the context's stream (same kernels, same arithmetic, identical
     // results).  JSTSP_OVERLAP=1 enables the side streams: measured +3 % channel-estimates/s at
     // BASELINE configs[1], but co-running kernels stretch each other (the K B^H launch goes from
     // 2.66 to 4.26 ms), which muddles per-kernel accounting — off until the side chains are
     // lighter than the MFMA-bound Grams they currently contain.
-    static const bool fuse = getenv("JSTSP_FUSE") ? atoi(getenv("JSTSP_FUSE")) != 0 : true;
-    static const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0 : false;
+    // (read at every call, not cached in statics: tests switch them inside one process)
+    const bool fuse = getenv("JSTSP_FUSE") ? atoi(getenv("JSTSP_FUSE")) != 0 : true;
+    const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0 : false;
+    uint32_t *const kmax0 = w.kmax;
     JSTSP_TRY(ensure_side_streams(ctx));
     hipStream_t sm = ctx->stream, s1 = overlap ? ctx->side[0] : sm, s2 = overlap ? ctx->side[1] : sm;
     hipEvent_t ev_x = ctx->ev[0], ev_svt = ctx->ev[1], ev_gxv = ctx->ev[2], ev_c = ctx->ev[3], ev_gv2 = ctx->ev[4],
@@ -269,8 +295,14 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
         // every operand maximum of this iteration starts from zero (one memset instead of four)
-        if (w.h2) JSTSP_HIP(hipMemsetAsync(w.kmax, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
-        else if (w.h2g) JSTSP_HIP(hipMemsetAsync(w.pmax, 0, 2 * (size_t)batch * sizeof(uint32_t), sm));
+        // (block it & 1; every consumer of the same block from iteration it-2 has been waited for by the main stream
+        //  during iteration it-1: ev_svt, ev_gxv, ev_gv2)
+        if (w.h2) {
+            const size_t boff = (size_t)(it & 1) * 8 * (size_t)batch;
+            w.kmax = kmax0 + boff; w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch;
+            w.wmax = w.kmax + 5 * (size_t)batch; w.pmax = w.kmax + 6 * (size_t)batch;
+            JSTSP_HIP(hipMemsetAsync(w.kmax, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
+        } else if (w.h2g) JSTSP_HIP(hipMemsetAsync(w.pmax, 0, 2 * (size_t)batch * sizeof(uint32_t), sm));
         int apply_no = 0;
         // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho) = Z - Q Z                                 (:35)
         if (it > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));
@@ -315,7 +347,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
         //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
-        if (w.h2) {
+        if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
+            JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, M, batch, Mat{w.ZK, snm, N}, Mat{PB, strideB ? (long long)M * G2 : 0, M},
+                           w.Tc, sng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
+        } else if (w.h2) {
             if (!fz) JSTSP_TRY(hgemm_absmax(ctx, w.ZK, snm, snm, batch, w.kmax));
             HGemmDesc hc{w.ZK, snm, N, w.kmax, w.Bc.data, strideB ? w.Bc.st : 0, w.Bc.bmax, strideB ? 1 : 0, w.Bc.KS,
                          w.Bc.JT, w.Tc, sng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
@@ -348,10 +383,16 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
                                     Imax, it));
         } else {
-            //    v = U\(L\k) = G_A^-1 (A^H Tc) G_B^-1   (GA / GB hold the inverses)          (:53)
-            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr));
-            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.Res, sg, Gr}, w.P1, sg, Gr));
-            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.V, sg, Gr));
+            //    v = U\(L\k) = pinv(A) K pinv(B)   [ = G_A^-1 (A^H Tc) G_B^-1 on the Gram route: GA / GB hold the inverses ]  (:53)
+            float2 *left = PB ? w.V : w.P1;        // result of the A side; the B side (if any) finishes into V
+            if (PA)
+                JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, N, batch, Mat{PA, strideA ? (long long)Gr * N : 0, Gr},
+                               Mat{w.Tc, sng, N}, left, sg, Gr));
+            else {
+                JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr));
+                JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{w.Res, sg, Gr}, left, sg, Gr));
+            }
+            if (!PB) JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, w.V, sg, Gr));
             JSTSP_TRY(launch_soft(ctx, (int)g, batch, w.V, w.S, w.rank, (int)cnt_ll, w.prm));     // (:56)
         }
         // -- Xs = A S B                                                                      (:58)
@@ -400,6 +441,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), w.S, batch * g, memspace));
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), w.Y, batch * nm, memspace));
     if (want_ce && Imax > 0) JSTSP_TRY(stage_out(ctx, ce_out, w.ce, (size_t)batch * 3 * Imax, memspace));
-    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(st));
+    if (memspace == JSTSP_HOST) {
+        JSTSP_HIP(hipStreamSynchronize(st));
+        if (!approx) JSTSP_TRY(diag_check_host(ctx, "proposed_algorithm 'std'"));
+    }
     return 0;
 }

@@ -2,6 +2,7 @@
 // helpers (GEMM shorthands, batched SVT / spectral norm) of libjstsp_mi355x.so.
 #include "solver_common.h"
 #include <cstring>
+#include <cmath>
 #include <cstdlib>
 #include <algorithm>
 
@@ -257,6 +258,51 @@ int ensure_side_streams(jstsp_ctx *ctx)
     return 0;
 }
 
+// ---- conditioning record ------------------------------------------------------------------------
+static const uint32_t DIAG_INIT[3] = {0x7f800000u /* +inf: no pinv yet */, 0u, 0x7f800000u /* no Gram inverse yet */};
+
+int ensure_diag(jstsp_ctx *ctx)
+{
+    if (ctx->diag) return 0;
+    JSTSP_HIP(hipMalloc((void **)&ctx->diag, sizeof(DIAG_INIT)));
+    return upload(ctx, ctx->diag, DIAG_INIT, sizeof(DIAG_INIT));
+}
+
+int diag_reset(jstsp_ctx *ctx)
+{
+    if (!ctx->diag) return ensure_diag(ctx);
+    return upload(ctx, ctx->diag, DIAG_INIT, sizeof(DIAG_INIT));
+}
+
+static int diag_read(jstsp_ctx *ctx, double *rcond_min, double *res_max, double *gram_ratio = nullptr)
+{
+    uint32_t h[3] = {DIAG_INIT[0], DIAG_INIT[1], DIAG_INIT[2]};
+    if (ctx->diag) JSTSP_HIP(hipMemcpy(h, ctx->diag, sizeof(h), hipMemcpyDeviceToHost));
+    float f0, f1, f2;
+    memcpy(&f0, &h[0], 4); memcpy(&f1, &h[1], 4); memcpy(&f2, &h[2], 4);
+    // one scale for both routes: sigma_min/sigma_max of the factor (= sqrt of the Gram's eigenvalue ratio)
+    double rc = 1.0;
+    if (h[0] != DIAG_INIT[0]) rc = std::min(rc, (double)f0);
+    if (h[2] != DIAG_INIT[2]) rc = std::min(rc, std::sqrt((double)f2));
+    if (rcond_min) *rcond_min = rc;
+    if (res_max) *res_max = (double)f1;
+    if (gram_ratio) *gram_ratio = (h[2] == DIAG_INIT[2]) ? 1.0 : (double)f2;
+    return 0;
+}
+
+int diag_check_host(jstsp_ctx *ctx, const char *what)
+{
+    double rc = 1.0, res = 0.0, gr = 1.0;
+    JSTSP_TRY(diag_read(ctx, &rc, &res, &gr));
+    JSTSP_REQUIRE(gr >= 1e-6, JSTSP_E_ILLCOND,
+                  "%s: a factor Gram has lambda_min/lambda_max = %.3g < 1e-6: its fp32 inverse (factors too large for "
+                  "the float64 pinv kernel) would carry no correct digit", what, gr);
+    JSTSP_REQUIRE(res < 1e-2, JSTSP_E_ILLCOND,
+                  "%s: the Newton-Schulz inverse of a factor Gram of order > 128 did not converge (max|I - G X| = %.3g): "
+                  "the factor is rank-deficient or too ill-conditioned for fp32", what, res);
+    return 0;
+}
+
 int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam)
 {
     const long long sZ = (long long)w.rows * w.cols;
@@ -316,7 +362,8 @@ int jstsp_create(int device_id, jstsp_ctx **out)
     }
     JSTSP_REQUIRE(device_id >= 0 && device_id < ndev, JSTSP_E_ARG, "jstsp_create: device %d of %d", device_id,
                   ndev);
-    JSTSP_HIP(hipSetDevice(device_id));
+    DeviceScope dev_scope_(device_id);          // the caller's current device is restored on return
+    JSTSP_HIP(dev_scope_.err);
     jstsp_ctx *c = new (std::nothrow) jstsp_ctx();
     JSTSP_REQUIRE(c, JSTSP_E_NOMEM, "jstsp_create: out of host memory");
     c->device = device_id;
@@ -336,7 +383,7 @@ int jstsp_create(int device_id, jstsp_ctx **out)
 int jstsp_destroy(jstsp_ctx *ctx)
 {
     if (!ctx) return 0;
-    (void)hipSetDevice(ctx->device);
+    DeviceScope dev_scope_(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -344,6 +391,7 @@ int jstsp_destroy(jstsp_ctx *ctx)
     for (int i = 0; i < 2; ++i) if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
     for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->diag) (void)hipFree(ctx->diag);
     ctx->arena.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -356,7 +404,7 @@ int jstsp_set_stream(jstsp_ctx *ctx, void *hip_stream)
     // is unless the caller opened a stream context.  The library's work must be ordered on the SAME stream
     // as the caller's producers / consumers of the device arrays, so it is taken literally.
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     if (ctx->stream == (hipStream_t)hip_stream && !ctx->own_stream) return 0;
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -368,7 +416,7 @@ int jstsp_set_stream(jstsp_ctx *ctx, void *hip_stream)
 int jstsp_use_own_stream(jstsp_ctx *ctx)
 {
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     if (ctx->own_stream) return 0;
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     JSTSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -379,9 +427,17 @@ int jstsp_use_own_stream(jstsp_ctx *ctx)
 int jstsp_synchronize(jstsp_ctx *ctx)
 {
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+int jstsp_last_conditioning(jstsp_ctx *ctx, double *rcond_min, double *ns_residual_max)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_ENTER(ctx);
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return diag_read(ctx, rcond_min, ns_residual_max);
 }
 
 size_t jstsp_workspace_bytes(const jstsp_ctx *ctx) { return ctx ? ctx->arena.cap : 0; }
@@ -389,6 +445,7 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx) { return ctx ? ctx->arena.cap
 int jstsp_set_profiling(jstsp_ctx *ctx, int enable)
 {
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_ENTER(ctx);
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     ctx->profiling = enable != 0;
@@ -399,6 +456,7 @@ int jstsp_set_profiling(jstsp_ctx *ctx, int enable)
 int jstsp_get_profile(jstsp_ctx *ctx, const char *kernel, int *launches, double *total_ms)
 {
     JSTSP_REQUIRE(ctx && kernel, JSTSP_E_NULL, "ctx/kernel is NULL");
+    JSTSP_ENTER(ctx);
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     prof_collect(ctx);
     auto it = ctx->prof.find(kernel);

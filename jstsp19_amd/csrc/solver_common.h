@@ -66,6 +66,16 @@ int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam);
 size_t hinv_bytes(int n, int count);
 int hermitian_inverse(jstsp_ctx *ctx, int n, int count, const float2 *G, float2 *Ginv);
 
+// pinv of small matrices in float64 (pinv.hip): P[t] (cols x rows) = pinv(A[t]) (rows x cols) when the matrix fits in LDS
+bool pinv_fits(int rows, int cols);
+int launch_pinv(jstsp_ctx *ctx, int rows, int cols, int count, const float2 *A, long long sAt, int lda, float2 *P,
+                long long sPt, int ldp, float *rcond_out = nullptr);
+// The context's conditioning record (common.h: jstsp_ctx::diag): allocate on first use / reset at the start of a call.
+int ensure_diag(jstsp_ctx *ctx);
+int diag_reset(jstsp_ctx *ctx);
+// After the stream has been synchronised: JSTSP_E_ILLCOND when a Gram inverse of the call lost all its fp32 digits.
+int diag_check_host(jstsp_ctx *ctx, const char *what);
+
 // Host -> device scalar block.
 int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes);
 

@@ -96,7 +96,7 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
     JSTSP_REQUIRE(std::max(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED,
                   "sparse_admm: max(Mr, Mt) = %d > 128 (order of the factor-Gram eigenproblems)", std::max(Mr, Mt));
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     const bool want_ce = ce_out != nullptr;
     const size_t nm = (size_t)Mr * Mt;
     const float rho = 0.01f, tau_s = 0.0001f;                                 // :12-13

@@ -280,7 +280,7 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
     JSTSP_REQUIRE(Na <= Gr, JSTSP_E_UNSUPPORTED,
                   "vamp: only the M <= N branch of VampGlmEst.m:399-403 is implemented (Na = %d > Gr = %d)", Na, Gr);
     JSTSP_REQUIRE(sigma > 0 && Lnz > 0 && Lnz < 2.0 * Gr * G2, JSTSP_E_ARG, "vamp: need sigma > 0 and 0 < L < nx");
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     const int nA = strideA ? batch : 1, nG = strideG ? batch : 1;
     const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)Na * Gr : (size_t)Na * Gr;
     const size_t szG = strideG ? (size_t)strideG * (batch - 1) + (size_t)G2 * G2 : (size_t)G2 * G2;
@@ -308,7 +308,7 @@ int jstsp_vamp_c32(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c32 *y, 
 {
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
-    JSTSP_HIP(hipSetDevice(ctx->device));
+    JSTSP_ENTER(ctx);
     static const jstsp_c32 one_h = {1.f, 0.f};
     if (memspace == JSTSP_HOST)
         return jstsp_vamp_kron_c32(ctx, M, N, 1, batch, y, A, strideA, &one_h, 0, sigma, Lnz, nit, x_out, memspace);

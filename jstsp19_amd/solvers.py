@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import DEVICE, HOST, JstspError, check
 
 __all__ = ["proposed_algorithm", "proposed_algorithm_angles", "svt", "mc_svt", "mc_admm", "OMP", "omp_kron",
-           "sparse_admm", "vamp", "vamp_kron", "ls_estimate", "correlate", "synthesize", "nmse_spectral", "colmajor",
+           "sparse_admm", "vamp", "vamp_kron", "ls_estimate", "pinv", "correlate", "synthesize", "nmse_spectral", "colmajor",
            "empty_colmajor"]
 
 
@@ -217,7 +217,8 @@ def synthesize(S, A, B, *, ctx=None):
 
 
 def ls_estimate(Y, A, B, *, ctx=None):
-    """``pinv(A)*Y*pinv(B)`` — the LS baseline of plot_errorVSsnr.m:83 (full-rank factors)."""
+    """``pinv(A)*Y*pinv(B)`` — the LS baseline of plot_errorVSsnr.m:83 (SVD-based float64 pinv of every factor that
+    fits the in-LDS kernel; the fp32 Gram inverse with a conditioning check for larger, full-rank factors)."""
     a_Y, a_A, a_B = _Arg(Y, np.complex64, "Y"), _Arg(A, np.complex64, "A"), _Arg(B, np.complex64, "B")
     batch, N, M, Gr, G2 = a_Y.batch, a_Y.R, a_Y.C, a_A.C, a_B.R
     if a_A.R != N or a_B.C != M:
@@ -227,6 +228,16 @@ def ls_estimate(Y, A, B, *, ctx=None):
     check(c._lib.jstsp_ls_c32(c.handle, N, M, Gr, G2, batch, a_Y.ptr, a_A.ptr, _shared_stride(a_A, N * Gr, batch, "A"),
                               a_B.ptr, _shared_stride(a_B, G2 * M, batch, "B"), p, mem), "jstsp_ls_c32")
     return f(not a_Y.batched)
+
+
+def pinv(A, *, ctx=None):
+    """MATLAB's ``pinv(A)`` as the drivers call it (plot_errorVSsnr.m:83): SVD-based, float64 on the device,
+    singular values below ``max(size(A))*eps(norm(A))`` dropped.  ``A``: (rows, cols) or (batch, rows, cols)."""
+    a_A = _Arg(A, np.complex64, "A")
+    c, mem, dev = _ctx_for([a_A], ctx)
+    p, f = _out(mem == DEVICE, a_A.batch, a_A.C, a_A.R, np.complex64, dev)
+    check(c._lib.jstsp_pinv_c32(c.handle, a_A.R, a_A.C, a_A.batch, a_A.ptr, p, mem), "jstsp_pinv_c32")
+    return f(not a_A.batched)
 
 
 def svt(Y, tau, *, ctx=None):

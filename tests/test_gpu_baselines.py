@@ -193,3 +193,73 @@ def test_ls_baseline_matches_pinv():
     for t in range(b):
         ref = np.linalg.pinv(A) @ Y[t] @ np.linalg.pinv(B[t])
         assert rel_err(S[t], ref) < 2e-3
+
+
+def test_pinv_matches_numpy_float64_including_rank_deficient_and_ill_conditioned():
+    """jstsp_pinv_c32 = MATLAB's SVD-based pinv (plot_errorVSsnr.m:83): one-sided Jacobi in float64 on the device.
+    Wide, tall, square, rank-deficient (pinv's tolerance drops the null directions) and cond = 1e6 inputs against
+    numpy's float64 pinv of the same complex64-rounded data."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(17)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    for (rows, cols) in [(32, 32), (16, 140), (140, 16), (64, 64), (5, 3), (1, 7), (33, 17)]:
+        A = r(3, rows, cols).astype(np.complex64)
+        P = J.pinv(A)
+        for t in range(3):
+            assert rel_err(P[t], np.linalg.pinv(A[t].astype(np.complex128))) < 2e-6, (rows, cols)
+    # rank 5 of 12: duplicated directions -> singular values ~1e-7 (complex64 rounding of the product) are NOT below
+    # pinv's float64 tolerance, exactly as in MATLAB: compare on the same rounded data
+    low = (r(20, 5) @ r(5, 12)).astype(np.complex64)
+    assert rel_err(J.pinv(low), np.linalg.pinv(low.astype(np.complex128))) < 1e-3
+    # exactly rank-deficient in the rounded data: two identical columns, a zero row
+    Z = r(10, 6).astype(np.complex64); Z[:, 4] = Z[:, 1]; Z[7] = 0
+    assert rel_err(J.pinv(Z), np.linalg.pinv(Z.astype(np.complex128))) < 2e-6
+    # cond = 1e6
+    U, _ = np.linalg.qr(r(24, 24)); V, _ = np.linalg.qr(r(24, 24))
+    C = ((U * np.logspace(0, -6, 24)) @ V.conj().T).astype(np.complex64)
+    assert rel_err(J.pinv(C), np.linalg.pinv(C.astype(np.complex128))) < 1e-4
+    rc, res = J.default_context(0).last_conditioning()
+    assert 3e-7 < rc < 3e-6 and res == 0.0
+
+
+def test_ls_baseline_square_ill_conditioned_pilot_factor():
+    """The drivers' LS baseline uses a SQUARE B_hbf (T_hbf == G2 == 16, plot_errorVSsnr.m:22,75-83), one per trial:
+    cond(B B^H) = cond(B)^2 reaches 1e8, where an fp32 Gram inverse has no digits.  The float64 pinv route keeps
+    the accuracy of applying pinv in fp32: eps32 * cond(B)."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(23)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    N, Gr, G2 = 32, 32, 16
+    A = (r(N, Gr) / np.sqrt(N)).astype(np.complex64)
+    Bs = []
+    for cond in (1e1, 1e3, 1e4):
+        U, _ = np.linalg.qr(r(G2, G2)); V, _ = np.linalg.qr(r(G2, G2))
+        Bs.append((U * np.logspace(0, -np.log10(cond), G2)) @ V.conj().T)
+    B = np.stack(Bs).astype(np.complex64)
+    S0 = r(3, Gr, G2)
+    Y = (A.astype(np.complex128) @ S0 @ B.astype(np.complex128)).astype(np.complex64)
+    S = J.ls_estimate(Y, A, B)
+    for t, tol in enumerate((2e-5, 2e-3, 2e-2)):
+        ref = np.linalg.pinv(A.astype(np.complex128)) @ Y[t].astype(np.complex128) @ np.linalg.pinv(B[t].astype(np.complex128))
+        assert rel_err(S[t], ref) < tol, t
+    rc, _ = J.default_context(0).last_conditioning()
+    assert 3e-5 < rc < 3e-4                          # sigma_min/sigma_max of the worst factor (cond 1e4)
+
+
+def test_ls_gram_route_reports_ill_conditioning_instead_of_garbage():
+    """Factors too large for the pinv kernel go through the fp32 Gram inverse; a Gram with lambda_min/lambda_max < 1e-6
+    makes a JSTSP_HOST call fail with JSTSP_E_ILLCOND (-6) rather than return digits that are not there."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(29)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    N, M, Gr, G2 = 32, 2000, 32, 100                 # B: 100 x 2000 does not fit the in-LDS kernel
+    A = r(N, Gr) / np.sqrt(N)
+    U, _ = np.linalg.qr(r(G2, G2))
+    Vh, _ = np.linalg.qr(r(M, G2))
+    good = (U * np.logspace(0, -1, G2)) @ Vh.conj().T
+    bad = (U * np.logspace(0, -4, G2)) @ Vh.conj().T           # cond(B B^H) = 1e8
+    Y = r(N, M)
+    S = J.ls_estimate(Y, A, good)
+    assert rel_err(S, np.linalg.pinv(A) @ Y @ np.linalg.pinv(good)) < 2e-3
+    with pytest.raises(J.JstspError, match="-6"):
+        J.ls_estimate(Y, A, bad)

@@ -194,3 +194,32 @@ def test_proposed_ragged_and_two_row_tiles_through_split_f16(force_h2, N, M, Gr,
     assert rel_err(S, So) < 2e-4 and rel_err(Y, Yo) < 2e-4
     np.testing.assert_allclose(ce[1:, 2], ceo[1:, 2], rtol=1e-3)
     np.testing.assert_allclose(ce[:, :2], ceo[:, :2], rtol=2e-3)
+
+
+def test_side_stream_overlap_is_bit_identical_through_the_split_f16_grams(force_h2):
+    """JSTSP_OVERLAP=1 runs the next SVT preparation and the norm chain on side streams.  Same kernels, same
+    arithmetic: the results must be bit-identical to the single-stream run, also when the side-stream Grams (which
+    read the per-iteration operand maxima) are still running while the main stream starts the next iteration —
+    the maxima are double-buffered by iteration parity for that."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(77)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    N, M, Gr, G2, b = 64, 768, 64, 128, 24
+    A, B = r(N, Gr) / np.sqrt(N), r(b, G2, M) / np.sqrt(G2)
+    Om = (rng.random((b, N, M)) < 0.3).astype(float)
+    S0 = np.zeros((b, Gr, G2), complex); S0[:, 3, 7] = 2 - 1j; S0[:, 40, 100] = 1j
+    subY = Om * (A @ S0 @ B + 0.05 * r(b, N, M))
+    args = (subY, Om, A, B, 25, 1e-3, 2e-2, 0.3, "approximate")
+    old = os.environ.get("JSTSP_OVERLAP")
+    try:
+        os.environ["JSTSP_OVERLAP"] = "0"
+        S_ref, Y_ref, ce_ref = J.proposed_algorithm(*args)
+        os.environ["JSTSP_OVERLAP"] = "1"
+        for _ in range(3):
+            S1, Y1, ce1 = J.proposed_algorithm(*args)
+            assert np.array_equal(S1, S_ref) and np.array_equal(Y1, Y_ref) and np.array_equal(ce1, ce_ref)
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_OVERLAP", None)
+        else:
+            os.environ["JSTSP_OVERLAP"] = old

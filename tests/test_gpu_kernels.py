@@ -123,3 +123,32 @@ def test_proposed_tall_measurement_matrix_unfused_path():
     S, Y, ce = J.proposed_algorithm(*args)
     assert rel_err(S, So) < 2e-4 and rel_err(Y, Yo) < 2e-4
     np.testing.assert_allclose(ce[:, :2], ceo[:, :2], rtol=2e-3)
+
+
+def test_svt_zero_row_follows_the_oracle_and_zero_matrix_hits_the_guard():
+    """svt.m:7-12 returns zeros when a singular value is EXACTLY 0.  Only the all-zero input is exact on every LAPACK
+    (numpy's gesdd gives 4e-16 for a zero first / middle row and 0.0 for a zero last row): the HIP path reproduces the
+    guard for the all-zero matrix and otherwise removes the null component, which is what the oracle computes for a
+    zero row in the middle."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(31)
+    for shape, kind in [((12, 40), "row"), ((40, 12), "col"), ((100, 130), "row"), ((64, 300), "row")]:
+        Y = _rand(rng, *shape)
+        if kind == "row":
+            Y[5] = 0
+        else:
+            Y[:, 3] = 0
+        ref = O.svt(Y, 0.7)
+        assert np.max(np.abs(ref)) > 0                       # the oracle's guard does not fire here
+        assert rel_err(J.svt(Y, 0.7), ref) < 3e-4, shape
+    for shape in [(6, 9), (9, 6), (70, 90), (64, 64)]:
+        assert np.all(J.svt(np.zeros(shape, complex), 0.5) == 0)
+    # mc_svt / mc_admm with a row that Omega never samples: the whole trajectory follows the oracle
+    OH = _rand(rng, 16, 16)
+    Om = (rng.random((16, 16)) < 0.5).astype(float); Om[4] = 0
+    assert rel_err(J.mc_svt(Om * OH, Om, 12, 0.5, 0.2), O.mc_svt(Om * OH, Om, 12, 0.5, 0.2)) < 2e-4
+    X, ce = J.mc_admm(OH, Om * OH, Om, 12, 0.5, 0.2)
+    Xo, ceo = O.mc_admm(OH, Om * OH, Om, 12, 0.5, 0.2)
+    assert rel_err(X, Xo) < 2e-4
+    np.testing.assert_allclose(ce, ceo, rtol=2e-3)
