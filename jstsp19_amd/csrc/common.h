@@ -214,7 +214,7 @@ int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gp
                     float2 *Uwarm, int warm, const uint32_t *skip_amax = nullptr);
 int eig_fast_ne(int n);           // padded order (32 or 64) of the warm-start basis
 int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
-                float *lam_out);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)
+                float *lam_out, bool lanczos = false);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)
 
 // ---- fused element-wise / reduction kernels (admm.hip) -----------------------------------
 int launch_form_z(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, const float2 *V1,

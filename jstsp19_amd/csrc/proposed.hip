@@ -431,7 +431,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             StreamScope sc(ctx, s2);
             JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gv2, s2));
-            JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam));
+            JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam, true));
             JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));
             JSTSP_HIP(hipEventRecord(ev_ce, s2));
         }

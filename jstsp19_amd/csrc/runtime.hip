@@ -206,10 +206,10 @@ int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long l
                 GEMM_GRAM, w.nsplit, sG);
 }
 
-int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam)
+int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos)
 {
     const long long sG = (long long)w.n * w.n;
-    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam);
+    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam, lanczos);
 }
 
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,

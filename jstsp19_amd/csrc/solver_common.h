@@ -50,7 +50,7 @@ int svt_apply(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float2 *Y);
 int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count,
                         const uint32_t *amax = nullptr, const TrialParams *skip_prm = nullptr);
 // lam[t] = lambda_max of the Gram partials already in the workspace, all w.batch problems
-int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam);
+int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos = false);
 // Make sure the context's side streams / events exist.
 int ensure_side_streams(jstsp_ctx *ctx);
 // Temporarily route the launch helpers (which use ctx->stream) to another stream.

@@ -184,3 +184,33 @@ def test_sweep_runner_on_hip_matches_oracle_per_point():
     full = run_sweep(base, [3], 4, Imax=100, batch=4, device=dev, baselines=True).numpy()
     assert full.shape == (1, 4) and np.all(np.isfinite(full)) and np.all(full > 0) and np.all(full <= 1)
     np.testing.assert_allclose(full[0, :2], run_sweep(base, [3], 4, Imax=100, batch=4, device=dev).numpy()[0], atol=1e-7)
+
+
+def test_lanczos_lambda_max_agrees_with_householder_sturm():
+    """convergence_error(:,1:2) takes lambda_max from the one-wave Lanczos kernel (JSTSP_LANCZOS=0 switches back to the
+    Householder + Sturm kernel): both must give the same ratios far inside the 2e-3 parity tolerance — Gram orders
+    32 (reference-native), 12, 64 and 100 (two rows per lane)."""
+    import os
+    import jstsp19_amd as J
+    rng = np.random.default_rng(41)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    g = load_golden("proposed_refnative")
+    cases = [(g["subY"], g["Omega"], g["A"], g["B"], 30, float(g["tau_Y"]), float(g["tau_Z"]), float(g["rho"]), "approximate")]
+    for (N, M, Gr, G2) in [(12, 40, 6, 10), (64, 300, 32, 40), (100, 160, 40, 30)]:
+        A, B = r(N, Gr) / np.sqrt(N), r(G2, M) / np.sqrt(G2)
+        Om = (rng.random((3, N, M)) < 0.5).astype(float)
+        cases.append((Om * r(3, N, M), Om, A, B, 15, 0.01, 0.02, 0.3, "approximate"))
+    old = os.environ.get("JSTSP_LANCZOS")
+    try:
+        for args in cases:
+            os.environ["JSTSP_LANCZOS"] = "0"
+            S0, Y0, ce0 = J.proposed_algorithm(*args)
+            os.environ["JSTSP_LANCZOS"] = "1"
+            S1, Y1, ce1 = J.proposed_algorithm(*args)
+            assert np.array_equal(S0, S1) and np.array_equal(Y0, Y1)          # the norms do not feed back
+            np.testing.assert_allclose(ce1[..., :2], ce0[..., :2], rtol=2e-5)
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_LANCZOS", None)
+        else:
+            os.environ["JSTSP_LANCZOS"] = old
