@@ -455,7 +455,7 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
         if (want_ce) {                                                                // :28
             hipLaunchKernelGGL(diff_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)),
                                dim3(256), 0, st, tot, X, Htrue, D);
-            JSTSP_TRY(sigma_max_sq(ctx, wn, D, num));
+            JSTSP_TRY(sigma_max_sq(ctx, wn, D, num, true));
             hipLaunchKernelGGL(ratio_cap_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, num, den,
                                ce, 0, (long long)Imax, (long long)it);
         }

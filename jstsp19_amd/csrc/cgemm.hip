@@ -268,7 +268,63 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     const int gi = m0 + wi * 32 + l31;
     float tmax = 0.f;           // max(|re|, |im|) of what this thread produces (d.amax_out)
     float xmax = 0.f, v1max = 0.f, zmax = 0.f;
-    if (gi < d.m) {
+    // EPI_UPDATE_X with 16-byte accesses: accumulator registers r, r+1 are two adjacent columns of one row; lanes 2q and
+    // 2q+1 (adjacent rows) swap one of them (DPP quad_perm [1,0,3,2]), after which the even lane owns rows (i, i+1) of
+    // column j_r and the odd lane rows (i-1, i) of column j_r+1 — five float4 loads + one float2 (invD) and four float4
+    // stores per register pair instead of twice as many 8-byte ones (the epilogue is memory-instruction-issue bound).
+    bool vec4 = false;
+    if constexpr (EPI == EPI_UPDATE_X && !M3 && !M64) {
+        vec4 = ((d.m & 1) == 0) && ((d.ldc & 1) == 0) && ((d.sCt & 1) == 0) && !Dp &&
+               ((((uintptr_t)d.C | (uintptr_t)d.e_rw0 | (uintptr_t)d.e_w1 | (uintptr_t)d.e_w2 | (uintptr_t)d.e_w3 |
+                  (uintptr_t)d.e_r0 | (uintptr_t)d.e_r2 | (uintptr_t)d.e_r3) & 15) == 0) && (((uintptr_t)d.e_f0 & 7) == 0);
+        if (vec4) {
+            auto swap1 = [](float x) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+            };
+            const bool odd = lane & 1;
+            const int gi2 = gi & ~1;
+            const float rho = d.prm[t].rho, ir = d.prm[t].irho;
+            const float omr = 1.f - rho, omir = 1.f - ir;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    const int r0 = 2 * rp, r1 = r0 + 1;
+                    const float2 o0 = make_float2(d.alpha * acc[nb][0][r0], d.alpha * acc[nb][1][r0]);
+                    const float2 o1 = make_float2(d.alpha * acc[nb][0][r1], d.alpha * acc[nb][1][r1]);
+                    const float2 snd = odd ? o0 : o1;
+                    const float2 rcv = make_float2(swap1(snd.x), swap1(snd.y));
+                    const float4 y = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
+                    const int gj = n0 + wj * (BN / 2) + nb * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi + (odd ? 1 : 0);
+                    if (gi2 >= d.m || gj >= d.n) continue;
+                    const long long ix = (long long)t * d.sCt + gi2 + (long long)gj * d.ldc;
+                    float4 v1 = *reinterpret_cast<const float4 *>(d.e_rw0 + ix);
+                    const float4 v2 = *reinterpret_cast<const float4 *>(d.e_r0 + ix);
+                    const float4 xs = *reinterpret_cast<const float4 *>(d.e_r2 + ix);
+                    const float4 sy = *reinterpret_cast<const float4 *>(d.e_r3 + ix);
+                    const float2 id = *reinterpret_cast<const float2 *>(d.e_f0 + ix);
+                    const float4 x = make_float4((v1.x + rho * y.x + sy.x + omr * v2.x + rho * xs.x) * id.x,
+                                                 (v1.y + rho * y.y + sy.y + omr * v2.y + rho * xs.y) * id.x,
+                                                 (v1.z + rho * y.z + sy.z + omr * v2.z + rho * xs.z) * id.y,
+                                                 (v1.w + rho * y.w + sy.w + omr * v2.w + rho * xs.w) * id.y);
+                    *reinterpret_cast<float4 *>(d.e_w1 + ix) = x;
+                    const float4 kk = make_float4(x.x + omir * v2.x, x.y + omir * v2.y, x.z + omir * v2.z, x.w + omir * v2.w);
+                    *reinterpret_cast<float4 *>(d.e_w2 + ix) = kk;
+                    tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(kk.x), fabsf(kk.y))), fmaxf(fabsf(kk.z), fabsf(kk.w)));
+                    v1 = make_float4(v1.x + rho * (y.x - x.x), v1.y + rho * (y.y - x.y), v1.z + rho * (y.z - x.z),
+                                     v1.w + rho * (y.w - x.w));
+                    *reinterpret_cast<float4 *>(d.e_rw0 + ix) = v1;
+                    const float4 zn = make_float4(x.x - ir * v1.x, x.y - ir * v1.y, x.z - ir * v1.z, x.w - ir * v1.w);
+                    if (d.e_w3) *reinterpret_cast<float4 *>(d.e_w3 + ix) = zn;
+                    xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
+                    v1max = fmaxf(fmaxf(v1max, fmaxf(fabsf(v1.x), fabsf(v1.y))), fmaxf(fabsf(v1.z), fabsf(v1.w)));
+                    zmax = fmaxf(fmaxf(zmax, fmaxf(fabsf(zn.x), fabsf(zn.y))), fmaxf(fabsf(zn.z), fabsf(zn.w)));
+                    if (d.epi_store_c) *reinterpret_cast<float4 *>(Cp + gi2 + (long long)gj * d.ldc) = y;
+                }
+            }
+        }
+    }
+    if (!vec4 && gi < d.m) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -401,8 +457,9 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     const int bn = variant == 1 ? 128 : 64;
     // 3M only where it pays and was validated: the two dominant contractions (JSTSP_M3=0 disables)
     static const int m3_mask = getenv("JSTSP_M3") ? atoi(getenv("JSTSP_M3")) : 15;
+    static const int m3_mink = getenv("JSTSP_M3_MINK") ? atoi(getenv("JSTSP_M3_MINK")) : 256;
     const bool m3 = (tag == GEMM_CORRELATE && (m3_mask & 1)) || (tag == GEMM_SYNTH && (m3_mask & 2)) ||
-                    (tag == GEMM_GRAM && (m3_mask & 4)) || (tag == GEMM_MISC && kper >= 256 && (m3_mask & 8));
+                    (tag == GEMM_GRAM && (m3_mask & 4)) || (tag == GEMM_MISC && kper >= m3_mink && (m3_mask & 8));
     const int tiles_n = (d.n + bn - 1) / bn;
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_m * tiles_n * d.splitk;

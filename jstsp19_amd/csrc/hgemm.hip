@@ -1,10 +1,10 @@
 // Complex GEMM with fp32-equivalent accuracy on the f16 matrix pipe (16x the fp32 MFMA rate).
 //
 // Every fp32 operand value x, scaled by a per-problem power of two s so that max|x s| < 2^14,
-// is split into two halves  x s = h + l 2^-11  (h = RN_f16(x s), l = RN_f16((x s - h) 2^11)):
-// h + l 2^-11 carries 22-23 significant bits and the residual x s - h is exact in fp32.
+// is split into two halves  x s = h + l  (h = RN_f16(x s), l = RN_f16(x s - h)):
+// h + l carries 22-23 significant bits and the residual x s - h is exact in fp32.
 // A real product sum is then three f16 MFMA streams with fp32 accumulation,
-//     sum a b = [ sum ah bh ] + 2^-11 [ sum ah bl + al bh ]      (dropped: al bl 2^-22, <= 2^-24 |a b|),
+//     sum a b = sum ah bh + ah bl + al bh      (dropped: al bl, <= 2^-24 |a b|),
 // every f16 x f16 product being exact in the fp32 accumulator.  A complex product is four real
 // ones (12 MFMAs per 32x32x16 block instead of 24 fp32 MFMAs per 32x32x16 with the 3M form, and
 // each at 1/2 the issue time: 4x less matrix-pipe time), so the big contractions of the ADMM
@@ -32,7 +32,12 @@ namespace {
 
 constexpr int HBK = 32;          // k per stage = 2 MFMA k-steps
 constexpr int FLUSH = 8;         // stages between folds of the fp32 accumulators
-constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+// The low half is the plain residual l = RN_f16(x s - h) (no extra scale): with max|x s| in [2^13, 2^14) it is a normal
+// f16 for every entry down to 2^-17 of the maximum and loses at most 2^-25 absolute (2^-38 of the maximum) below
+// that, so h + l still carries 22 bits wherever it matters — and all three product streams of a real sum,
+//     sum a b = sum ah bh + ah bl + al bh,
+// have the same weight and can share ONE fp32 accumulator (hgemm2_kernel below).
+constexpr float LO_SCALE = 1.f, LO_INV = 1.f;
 
 // e such that amax * 2^e lies in [2^13, 2^14)
 __device__ __host__ inline int scale_exp(uint32_t amax_bits)
@@ -317,6 +322,295 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
     }
 }
 
+// ---- v2 of the streaming contraction for m <= 64 (one row tile): every wave owns 32 output columns x all 64 rows
+//      (two 32 x 32 MFMA blocks).  Its b fragments are needed by nobody else, so they go straight from HBM to
+//      registers (1 KiB lane-linear blocks, 16 B per lane) with PD stages in flight per wave — no LDS round trip, no
+//      LDS capacity spent on the streamed operand, and 2 x 4 waves x PD x 8 KiB of HBM requests in flight per CU
+//      (192 KiB at PD = 3, against 64 KiB for the LDS-staged kernel above).  Only the a panel (64 rows x 32 k, shared
+//      by all waves) is staged through LDS.  One fp32 accumulator per real sum (see LO_SCALE above): 64 accumulator
+//      registers per wave instead of 128.
+template <int EPI, bool APACK, int NW, int PD, bool LONGK>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmDesc d, int tiles_j)
+{
+    constexpr int NT = 64 * NW;
+    constexpr int NA = 2048 / NT;                 // fp32 a elements per thread per stage (64 rows x 32 k)
+    constexpr int NAB = 16 / NW;                  // packed a blocks per wave per stage
+    __shared__ uint4 smem[2 * 1024];              // a panel, two stages: blocks [it 2][ks 2][plane 4], 1 KiB each
+
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int t = (slot / tiles_j) * 8 + xcd;
+    if (t >= d.batch) return;
+    const int tj = slot % tiles_j;
+    const int j0 = tj * 32 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int ea = scale_exp(d.amax[t]);
+    const int eb = scale_exp(d.bmax[(long long)t * d.sbmax]);
+    const float sa = ldexpf(1.f, ea);
+
+    // ---- a loader (fp32: thread -> row ai, NA consecutive k; packed: wave -> NAB blocks)
+    const int ai = tid & 63, akg = tid >> 6;
+    const bool arow = ai < d.m;
+    const float2 *abase = APACK ? nullptr : d.A + (long long)t * d.sAt;
+    const float2 *pa = APACK ? nullptr : abase + (arow ? ai : 0) + (long long)(NA * akg) * d.sAk;
+    const int a_slot = (NA == 8) ? ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31)
+                                 : ((((ai >> 5) * 2 + (akg >> 2)) * 4) * 64) + ((akg >> 1) & 1) * 32 + (ai & 31);
+    const float sa_m = arow ? sa : 0.f;
+    const int nst = d.KS / 2;
+    const int kfull = d.k / HBK;
+    // packed a: block q = wave * NAB + r of the stage: it = q >> 3, ks = (q >> 2) & 1, plane = q & 3
+    const uint4 *paw = nullptr;
+    if constexpr (APACK) {
+        const int q0 = wave * NAB;
+        paw = d.Ap + (long long)t * d.sApt + lane + ((long long)(q0 >> 3) * d.KS + ((q0 >> 2) & 1)) * 256 + (q0 & 3) * 64;
+    }
+    struct AF { float2 a[NA]; };
+    struct AP { u32x4 q[NAB]; };
+    using AStg = typename std::conditional<APACK, AP, AF>::type;
+    auto load_a = [&](int s, AStg &R) {
+        if constexpr (APACK) {
+            const u32x4 *g = reinterpret_cast<const u32x4 *>(paw + (long long)(2 * s) * 256);
+#pragma unroll
+            for (int r = 0; r < NAB; ++r) R.q[r] = g[r * 64];           // NAB <= 4 consecutive planes of one (it, ks)
+        } else {
+            if (s < kfull) {
+#pragma unroll
+                for (int v = 0; v < NA; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
+            } else {
+                const int kbase = s * HBK + NA * akg;
+#pragma unroll
+                for (int v = 0; v < NA; ++v) {
+                    const bool ok = kbase + v < d.k;
+                    const float2 *p = ok ? pa + (long long)(s * HBK + v) * d.sAk : abase;
+                    const float2 x = *p;
+                    R.a[v] = ok ? x : make_float2(0.f, 0.f);
+                }
+            }
+        }
+    };
+    auto store_a = [&](const AStg &R, uint4 *buf) {
+        if constexpr (APACK) {
+            u32x4 *q = reinterpret_cast<u32x4 *>(buf + wave * NAB * 64 + lane);
+#pragma unroll
+            for (int r = 0; r < NAB; ++r) q[r * 64] = R.q[r];
+        } else {
+            half8 rh = {0}, rl = {0}, ih = {0}, il = {0};
+#pragma unroll
+            for (int v = 0; v < NA; ++v) {
+                _Float16 h, l;
+                split2(R.a[v].x * sa_m, h, l); rh[v] = h; rl[v] = l;
+                split2(R.a[v].y * sa_m, h, l); ih[v] = h; il[v] = l;
+            }
+            if constexpr (NA == 8) {
+                uint4 *q = buf + a_slot;
+                q[0] = *reinterpret_cast<uint4 *>(&rh);
+                q[64] = *reinterpret_cast<uint4 *>(&rl);
+                q[128] = *reinterpret_cast<uint4 *>(&ih);
+                q[192] = *reinterpret_cast<uint4 *>(&il);
+            } else {
+                uint2 *q = reinterpret_cast<uint2 *>(buf + a_slot) + (akg & 1);
+                q[0] = *reinterpret_cast<uint2 *>(&rh);
+                q[2 * 64] = *reinterpret_cast<uint2 *>(&rl);
+                q[2 * 128] = *reinterpret_cast<uint2 *>(&ih);
+                q[2 * 192] = *reinterpret_cast<uint2 *>(&il);
+            }
+        }
+    };
+
+    // ---- b: this wave's j-tile, straight to registers.  Block (jt, ks, plane) at ((jt KS + ks) 4 + plane) 64 uint4.
+    const uint4 *pbw = d.Bp + (long long)t * d.sPt + ((long long)(tj * NW + wave) * d.KS) * 256 + lane;
+    struct BStg { u32x4 q[8]; };            // [ks 2][plane 4]
+    auto load_b_half = [&](int s, int ks, BStg &R) {
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(pbw + (long long)(2 * s + ks) * 256);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) R.q[ks * 4 + p] = __builtin_nontemporal_load(g + p * 64);
+    };
+
+    f32x16 re[2], im[2], Lre[LONGK ? 2 : 1], Lim[LONGK ? 2 : 1];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { re[it][r] = 0.f; im[it][r] = 0.f; }
+    if constexpr (LONGK) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { Lre[it][r] = 0.f; Lim[it][r] = 0.f; }
+    }
+    auto h8 = [](u32x4 u) { return *reinterpret_cast<half8 *>(&u); };
+    auto nh8 = [](u32x4 u) { u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+                             return *reinterpret_cast<half8 *>(&u); };
+    auto compute_half = [&](const uint4 *buf, int ks, const BStg &R) {
+        const half8 br_h = h8(R.q[ks * 4 + 0]), br_l = h8(R.q[ks * 4 + 1]), bi_h = h8(R.q[ks * 4 + 2]),
+                    bi_l = h8(R.q[ks * 4 + 3]);
+        const u32x4 *fa0 = reinterpret_cast<const u32x4 *>(buf + ((0 * 2 + ks) * 4) * 64 + lane);
+        const u32x4 *fa1 = reinterpret_cast<const u32x4 *>(buf + ((1 * 2 + ks) * 4) * 64 + lane);
+        const u32x4 u0r_h = fa0[0], u0r_l = fa0[64], u0i_h = fa0[128], u0i_l = fa0[192];
+        const u32x4 u1r_h = fa1[0], u1r_l = fa1[64], u1i_h = fa1[128], u1i_l = fa1[192];
+        const half8 a0r_h = h8(u0r_h), a0r_l = h8(u0r_l), a0i_h = h8(u0i_h), a0i_l = h8(u0i_l);
+        const half8 a1r_h = h8(u1r_h), a1r_l = h8(u1r_l), a1i_h = h8(u1i_h), a1i_l = h8(u1i_l);
+        const half8 n0i_h = nh8(u0i_h), n0i_l = nh8(u0i_l), n1i_h = nh8(u1i_h), n1i_l = nh8(u1i_l);
+        // rows of the MFMA tile = j (A operand = b fragment), columns = i (B operand = a fragment); four independent
+        // accumulators in rotation
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a0r_h, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, a0r_h, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a1r_h, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, a1r_h, im[1], 0, 0, 0);
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, n0i_h, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a0i_h, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, n1i_h, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a1i_h, im[1], 0, 0, 0);
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_l, a0r_h, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_l, a0r_h, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_l, a1r_h, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_l, a1r_h, im[1], 0, 0, 0);
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a0r_l, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, a0r_l, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a1r_l, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, a1r_l, im[1], 0, 0, 0);
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_l, n0i_h, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_l, a0i_h, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_l, n1i_h, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_l, a1i_h, im[1], 0, 0, 0);
+        re[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, n0i_l, re[0], 0, 0, 0);
+        im[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a0i_l, im[0], 0, 0, 0);
+        re[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, n1i_l, re[1], 0, 0, 0);
+        im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a1i_l, im[1], 0, 0, 0);
+    };
+    auto fold = [&]() {
+        if constexpr (LONGK) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    Lre[it][r] += re[it][r]; Lim[it][r] += im[it][r];
+                    re[it][r] = 0.f; im[it][r] = 0.f;
+                }
+        }
+    };
+
+    // One stage.  A wave's loads return IN ORDER (s_waitcnt vmcnt counts them in issue order), so the a panel and the b
+    // fragments of one stage are requested together, PD stages ahead: waiting for the a panel of stage s+1 at the end
+    // of stage s then leaves exactly the requests of stage s+2 ... in flight.  (With the a panel requested one stage
+    // ahead and b three, every wait for a also waited for the two younger b stages: the pipeline ran at one HBM round
+    // trip per stage.)
+    // Every load below is UNCONDITIONAL (past the end the stage index is clamped and the data ignored): a branch
+    // around a load makes hipcc forget how many requests are outstanding and drain the queue (vmcnt(0)) at the top of
+    // the loop.  The packs pad k to a multiple of 64, so the stage count is a multiple of PD = 2.
+    auto stage = [&](int s, BStg &R, AStg &RAnext) {
+        const uint4 *cur = smem + (s & 1) * 1024;
+        const int sb = min(s + PD, nst - 1), sa2 = min(s + 1 + PD, nst - 1);
+        compute_half(cur, 0, R);
+        load_b_half(sb, 0, R);
+        compute_half(cur, 1, R);
+        load_b_half(sb, 1, R);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(RAnext, smem + ((s + 1) & 1) * 1024);                      // a(s+1): requested PD stages ago
+        load_a(sa2, RAnext);                                               // its registers are free again
+        if (LONGK && ((s + 1) % FLUSH) == 0) fold();
+        __syncthreads();
+    };
+
+    // ---- prologue: stages 0 .. PD-1 of b and 0 .. PD of a requested in stage order
+    BStg RB[PD];
+    AStg RAr[PD];
+    AStg RA0;
+    load_a(0, RA0);
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+        load_b_half(min(p, nst - 1), 0, RB[p]); load_b_half(min(p, nst - 1), 1, RB[p]);
+        load_a(min(p + 1, nst - 1), RAr[p]);                               // RAr[p] holds a(s+1) for s = p (mod PD)
+    }
+    store_a(RA0, smem);
+    __syncthreads();
+    for (int s = 0; s < nst; s += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) stage(s + p, RB[p], RAr[p]);
+    }
+    if constexpr (LONGK) fold();
+
+    // ---- epilogue: C(i, j), i = it 32 + (lane & 31), j = j0 + wave 32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    // 16-byte accesses: accumulator registers r, r+1 are two adjacent columns of one row; lanes 2q and 2q+1 (adjacent
+    // rows) swap one of them (DPP quad_perm [1,0,3,2]), after which the even lane owns rows (i, i+1) of column j_r and the
+    // odd lane rows (i-1, i) of column j_r+1: every lane reads X / V2 and writes V2 / Xs as ONE float4 per register pair.
+    // (Measured at configs[1] by switching parts of the kernel off: dictionary + A S reads alone 0.75 ms = 5.45 TB/s;
+    // + the Xs store 0.97 ms; + X / V2 reads and the V2 store 1.29 ms — 1.39 ms with 8-byte accesses; the MFMAs are
+    // free, 0.03 ms.  What keeps the kernel from the read-stream rate is its read-modify-write tail.)
+    const float alpha = ldexpf(1.f, -(ea + eb));
+    float2 *Cp = d.C + (long long)t * d.sCt;
+    float vmax = 0.f;
+    const bool vec4 = ((d.m & 1) == 0) && ((d.ldc & 1) == 0) && ((d.sCt & 1) == 0) && (((uintptr_t)d.C & 15) == 0) &&
+                      (EPI != EPI_UPDATE_C || ((((uintptr_t)d.e_r0 | (uintptr_t)d.e_rw0) & 15) == 0));
+    const float rho = (EPI == EPI_UPDATE_C) ? d.prm[t].rho : 0.f, omc = (EPI == EPI_UPDATE_C) ? 1.f - d.prm[t].c_coef : 0.f;
+    auto swap1 = [](float x) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+    };
+    if (vec4) {
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int gi = it * 32 + (lane & 31);
+            const int gi2 = gi & ~1;
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const int r0 = 2 * rp, r1 = r0 + 1;
+                const float2 o0 = make_float2((LONGK ? Lre[LONGK ? it : 0][r0] : re[it][r0]) * alpha,
+                                              (LONGK ? Lim[LONGK ? it : 0][r0] : im[it][r0]) * alpha);
+                const float2 o1 = make_float2((LONGK ? Lre[LONGK ? it : 0][r1] : re[it][r1]) * alpha,
+                                              (LONGK ? Lim[LONGK ? it : 0][r1] : im[it][r1]) * alpha);
+                const float2 snd = odd ? o0 : o1;
+                const float2 rcv = make_float2(swap1(snd.x), swap1(snd.y));
+                float4 xs = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
+                const int gj = j0 + wave * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * (lane >> 5) + (odd ? 1 : 0);
+                if (gi2 >= d.m || gj >= d.n) continue;
+                const long long ix = (long long)t * d.sCt + gi2 + (long long)gj * d.ldc;
+                if (EPI == EPI_UPDATE_C) {
+                    // Xs in xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
+                    const float4 x = *reinterpret_cast<const float4 *>(d.e_r0 + ix);
+                    float4 v2 = *reinterpret_cast<const float4 *>(d.e_rw0 + ix);
+                    v2.x = omc * (v2.x - rho * (x.x - xs.x));
+                    v2.y = omc * (v2.y - rho * (x.y - xs.y));
+                    v2.z = omc * (v2.z - rho * (x.z - xs.z));
+                    v2.w = omc * (v2.w - rho * (x.w - xs.w));
+                    *reinterpret_cast<float4 *>(d.e_rw0 + ix) = v2;
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y))), fmaxf(fabsf(v2.z), fabsf(v2.w)));
+                }
+                *reinterpret_cast<float4 *>(Cp + gi2 + (long long)gj * d.ldc) = xs;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int gi = it * 32 + (lane & 31);
+            if (gi >= d.m) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gj = j0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gj >= d.n) continue;
+                const float vr = LONGK ? Lre[LONGK ? it : 0][r] : re[it][r], vi = LONGK ? Lim[LONGK ? it : 0][r] : im[it][r];
+                const float2 o = make_float2(vr * alpha, vi * alpha);
+                const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
+                if (EPI == EPI_UPDATE_C) {
+                    const float2 x = d.e_r0[ix];
+                    float2 v2 = d.e_rw0[ix];
+                    v2.x = omc * (v2.x - rho * (x.x - o.x));
+                    v2.y = omc * (v2.y - rho * (x.y - o.y));
+                    d.e_rw0[ix] = v2;
+                    vmax = fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y)));
+                }
+                Cp[gi + (long long)gj * d.ldc] = o;
+            }
+        }
+    }
+    if (EPI == EPI_UPDATE_C && d.amax_v2) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) atomicMax(&d.amax_v2[t], __float_as_uint(vmax));
+    }
+}
+
 // ---- Gram partials G_s = sum_{k in chunk s} z_k z_k^H of a rows x cols matrix (rows <= 64), same split-f16
 //      arithmetic: ONE panel (64 rows x 32 k, split on the fly) feeds both MFMA operands,
 //        re G(i,j) = sum ar_i ar_j + ai_i ai_j,   im G(i,j) = sum ai_i ar_j - ar_i ai_j.
@@ -455,7 +749,7 @@ bool use_hgemm(long long m, long long n, long long k)
 
 size_t hgemm_pack_bytes(int Kd, int J, int count)
 {
-    const size_t KS = 2 * (size_t)((Kd + 31) / 32), JT = 4 * (size_t)((J + 127) / 128);
+    const size_t KS = 4 * (size_t)((Kd + 63) / 64), JT = 4 * (size_t)((J + 127) / 128);
     return rnd256((size_t)count * JT * KS * 4096) + rnd256((size_t)count * sizeof(uint32_t));
 }
 
@@ -471,7 +765,7 @@ int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, in
 int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long sBt, long long sBk, long long sBj,
                int conj, int Kd, int J, int count, long long n_contig)
 {
-    p.KS = 2 * ((Kd + 31) / 32);
+    p.KS = 4 * ((Kd + 63) / 64);           // k padded to 64: an even number of 32-k stages (hgemm2_kernel, PD = 2)
     p.JT = 4 * ((J + 127) / 128);          // j padded to the 128-wide tile of the 8-wave kernel
     p.count = count;
     p.st = (long long)p.JT * p.KS * 256;
@@ -522,6 +816,22 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_i * tiles_j;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
+    // v2 (hgemm2_kernel): one row tile, b fragments straight to registers.  JSTSP_H2_V2: bit 0 packed-a products
+    // (the synthesis), bit 1 fp32-a products (K B^H, the G_B applies)
+    static const int v2_mask = getenv("JSTSP_H2_V2") ? atoi(getenv("JSTSP_H2_V2")) : 1;
+    const bool pack_ok = d.JT * 32 >= ((d.n + 127) / 128) * 128;       // j padded to 128 columns: 4 waves x 32
+    if (d.m <= 64 && pack_ok && d.Ap && (v2_mask & 1) && d.aKS == d.KS && (d.KS % 4) == 0) {
+        const int tj2 = (d.n + 127) / 128;
+        const long long grid2 = groups * 8 * tj2;
+        if (prof_name) prof_begin(ctx, prof_name);
+        if (d.epi == EPI_UPDATE_C)
+            hgemm2_kernel<EPI_UPDATE_C, true, 4, 2, false><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
+        else
+            hgemm2_kernel<EPI_NONE, true, 4, 2, false><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
+        if (prof_name) prof_end(ctx, prof_name);
+        JSTSP_HIP(hipGetLastError());
+        return 0;
+    }
     if (prof_name) prof_begin(ctx, prof_name);
     if (wide) {
         hgemm_kernel<EPI_NONE, false, 4><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);

@@ -303,12 +303,12 @@ int diag_check_host(jstsp_ctx *ctx, const char *what)
     return 0;
 }
 
-int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam)
+int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam, bool lanczos)
 {
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
     JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
-    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam);
+    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam, lanczos);
 }
 
 int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes)

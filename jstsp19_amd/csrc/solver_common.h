@@ -59,8 +59,8 @@ struct StreamScope {
     StreamScope(jstsp_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { c->stream = s; }
     ~StreamScope() { c->stream = saved; }
 };
-// lam[t] = sigma_max(Z_t)^2
-int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam);
+// lam[t] = sigma_max(Z_t)^2   (lanczos: the per-iteration convergence-error curves; Householder + Sturm otherwise)
+int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam, bool lanczos = false);
 
 // Ginv[t] = G[t]^-1 for `count` Hermitian PD n x n matrices (hinv.hip); workspace from ctx->arena.
 size_t hinv_bytes(int n, int count);

@@ -166,7 +166,7 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
             JSTSP_TRY(gemm(ctx, 'N', 'N', Mr, Mt, Mr, batch, Drm, Mat{S, snm, Mr}, P, snm, Mr));
             JSTSP_TRY(gemm(ctx, 'N', 'C', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Dtm, Dd, snm, Mr));
             hipLaunchKernelGGL(sadmm_diff_kernel, g1(tot), dim3(256), 0, st, tot, Dd, Htrue, Dd);
-            JSTSP_TRY(sigma_max_sq(ctx, wn, Dd, num));
+            JSTSP_TRY(sigma_max_sq(ctx, wn, Dd, num, true));
             hipLaunchKernelGGL(sadmm_ratio_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, num, den, ce,
                                Imax, it);
         }
