@@ -153,6 +153,17 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
                        long long strideB, const jstsp_c32 *y, int m,
                        jstsp_c32 *x_hat, int32_t *index_out, int memspace);
 
+/* Joint (MMV) OMP — the drivers' "OMP with MMV" baseline and the second stage of their TSSR recipe
+ *   spx.pursuit.joint.OrthogonalMatchingPursuit(A, K).solve(Y)  ->  .Z      plot_errorVSsnr.m:116-117, :158-162
+ * sparse-plex is not vendored and not version-pinned (README.md:9): this is the published simultaneous OMP
+ * (one support for all columns; atom = argmax_g ||A(:,g)' * R||_p, p = pnorm in {2, 1}; least squares on the support),
+ * stopping after K atoms, when all min(N, Gr) independent atoms are in, or when ||R||_F <= 1e-6 ||Y||_F.
+ * A: N x Gr (strideA 0 = shared); Y: N x S x batch; Z_out: Gr x S x batch; index_out: NULL or K x batch int32
+ * (1-based atoms in selection order, 0 beyond the count); count_out: NULL or batch int32 (atoms selected). */
+int jstsp_mmv_omp_c32(jstsp_ctx *ctx, int N, int Gr, int S, int batch, const jstsp_c32 *A, long long strideA,
+                      const jstsp_c32 *Y, int K, int pnorm, jstsp_c32 *Z_out, int32_t *index_out,
+                      int32_t *count_out, int memspace);
+
 /* [S, convergence_error] = sparse_admm(Htrue, OH, Dr, Dt, Imax)   benchmark_algorithms/sparse_admm.m:1-36
  * Htrue, OH: Mr x Mt x batch; Dr: Mr x Gr, Dt: Mt x Gt (shared by the batch; Gr*Gt == Mr*Mt
  * as the reference requires, :16).  S_out: Mr x Mt x batch; ce_out: NULL or Imax x batch double. */
@@ -190,6 +201,12 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
  *   plot_errorVSsnr.m:138-141.   S, Zbar: R x C x batch; nmse: batch doubles (same memspace). */
 int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S,
                             const jstsp_c32 *Zbar, double *nmse, int memspace);
+
+/* rate[t] = log2(real(det(eye(R) + 1/R * Zbar*Zbar' / (noise_var + norm(Zbar - S)^2/norm(Zbar)^2))))
+ *   plot_rateVSframelength.m:81,113,130,135 (spectral norms, NMSE not capped).  S, Zbar: R x C x batch, R <= 128;
+ * rate: batch doubles (same memspace). */
+int jstsp_rate_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S, const jstsp_c32 *Zbar,
+                   double noise_var, double *rate, int memspace);
 
 /* ---- device-side construction of the solver inputs (the caller side of the path) ------------
  * plot_errorVSsnr.m:57-136 for trials [trial0, trial0 + batch) of sweep point `sweep_idx`:

@@ -57,6 +57,9 @@ SIGNATURES = {
                               c_void_p, c_void_p, c_int]),
     "jstsp_omp_kron_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_ll,
                                    c_void_p, c_int, c_void_p, c_void_p, c_int]),
+    "jstsp_mmv_omp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_int]),
+    "jstsp_rate_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, C.c_double, c_void_p, c_int]),
     "jstsp_sparse_admm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int]),
     "jstsp_mc_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_dp, c_dp,

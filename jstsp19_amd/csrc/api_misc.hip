@@ -64,6 +64,19 @@ __global__ __launch_bounds__(256) void mc_admm_update_kernel(long long nm, float
     }
 }
 
+// rate[t] = sum_i log2(1 + lam_i / (R (noise_var + num/den)))   (plot_rateVSframelength.m:81: log2 det(I + Zbar Zbar'/(R (..))))
+__global__ __launch_bounds__(256) void rate_kernel(int batch, int n, int R, const float *lam, const float *num,
+                                                   const float *den, double noise_var, double *rate)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= batch) return;
+    const double e = (double)num[t] / (double)den[t];
+    const double c = 1.0 / ((double)R * (noise_var + e));
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += log2(1.0 + fmax((double)lam[(long long)t * n + i], 0.0) * c);
+    rate[t] = acc;
+}
+
 static dim3 grid2(long long n, int batch)
 {
     long long blocks = std::max<long long>(1, std::min<long long>((n + 255) / 256, (4096 + batch - 1) / batch));
@@ -360,6 +373,53 @@ int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp
                        o, 1, 1ll, 0ll);
     JSTSP_HIP(hipGetLastError());
     JSTSP_TRY(stage_out(ctx, nmse, o, (size_t)batch, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int jstsp_rate_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S_, const jstsp_c32 *Zbar_,
+                   double noise_var, double *rate, int memspace)
+{
+    // log2(real(det(eye(Nr) + 1/Nr*Zbar*Zbar'*1/(noise_var + norm(Zbar-S)^2/norm(Zbar)^2))))  (plot_rateVSframelength.m:81)
+    // = sum_i log2(1 + lambda_i(Zbar Zbar') / (Nr (noise_var + e))): the eigenvalues of the Gram of the smaller side
+    // (det(I + c Z Z') = det(I + c Z' Z)); the NMSE e is NOT capped in that script.
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
+    JSTSP_REQUIRE(S_ && Zbar_ && rate, JSTSP_E_NULL, "rate: NULL argument");
+    JSTSP_REQUIRE(R > 0 && C > 0 && batch > 0, JSTSP_E_SHAPE, "rate: bad shape");
+    JSTSP_REQUIRE(std::min(R, C) <= 128, JSTSP_E_UNSUPPORTED, "rate: min(R, C) = %d > 128", std::min(R, C));
+    const size_t n = (size_t)R * C;
+    const int ng = std::min(R, C), ne = (ng + 1) & ~1;
+    size_t need = GramWS::bytes(R, C, batch, false) + rnd256(batch * n * sizeof(float2)) +
+                  2 * rnd256(batch * sizeof(float)) + rnd256(batch * sizeof(double)) +
+                  rnd256((size_t)batch * ng * ng * sizeof(float2)) + rnd256((size_t)batch * ng * sizeof(float)) +
+                  rnd256((size_t)batch * ne * ne * sizeof(float2));
+    if (memspace == JSTSP_HOST) need += 2 * rnd256(batch * n * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *S, *Zb;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(S_), batch * n, memspace, &S));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Zbar_), batch * n, memspace, &Zb));
+    float2 *D = ctx->arena.get<float2>(batch * n);
+    float *num = ctx->arena.get<float>(batch), *den = ctx->arena.get<float>(batch);
+    double *o = ctx->arena.get<double>(batch);
+    float2 *U = ctx->arena.get<float2>((size_t)batch * ng * ng);
+    float *lam = ctx->arena.get<float>((size_t)batch * ng);
+    float2 *Vg = eig_needs_global_v(ng) ? ctx->arena.get<float2>((size_t)batch * ne * ne) : nullptr;
+    JSTSP_REQUIRE(D && num && den && o && U && lam && (!eig_needs_global_v(ng) || Vg), JSTSP_E_NOMEM, "rate: workspace exhausted");
+    GramWS w;
+    JSTSP_TRY(w.alloc(ctx->arena, R, C, batch, false));
+    const long long tot = (long long)batch * n;
+    hipLaunchKernelGGL(diff_kernel, dim3((unsigned)std::min<long long>((tot + 255) / 256, 4096)), dim3(256), 0,
+                       ctx->stream, tot, S, Zb, D);
+    JSTSP_TRY(sigma_max_sq(ctx, w, D, num));
+    JSTSP_TRY(sigma_max_sq(ctx, w, Zb, den));                     // leaves the Gram partials of Zbar in the workspace
+    const long long sG = (long long)w.n * w.n;
+    JSTSP_TRY(launch_eig(ctx, EIG_VECS, w.n, batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, nullptr, nullptr, U, lam, Vg));
+    hipLaunchKernelGGL(rate_kernel, dim3((batch + 255) / 256), dim3(256), 0, ctx->stream, batch, w.n, R, lam, num, den,
+                       noise_var, o);
+    JSTSP_HIP(hipGetLastError());
+    JSTSP_TRY(stage_out(ctx, rate, o, (size_t)batch, memspace));
     if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }

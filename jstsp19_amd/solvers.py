@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import DEVICE, HOST, JstspError, check
 
 __all__ = ["proposed_algorithm", "proposed_algorithm_angles", "svt", "mc_svt", "mc_admm", "OMP", "omp_kron",
-           "sparse_admm", "vamp", "vamp_kron", "ls_estimate", "pinv", "correlate", "synthesize", "nmse_spectral", "colmajor",
+           "sparse_admm", "vamp", "vamp_kron", "ls_estimate", "pinv", "mmv_omp", "tssr", "rate", "correlate", "synthesize", "nmse_spectral", "colmajor",
            "empty_colmajor"]
 
 
@@ -266,6 +266,57 @@ def nmse_spectral(S, Zbar, *, ctx=None):
     check(c._lib.jstsp_nmse_spectral_c32(c.handle, a_S.R, a_S.C, a_S.batch, a_S.ptr, a_Z.ptr, ptr, mem),
           "jstsp_nmse_spectral_c32")
     return out if a_S.batched else out[0]
+
+
+def rate(S, Zbar, noise_var, *, ctx=None):
+    """plot_rateVSframelength.m:81,113,130,135 — ``log2(real(det(eye(Nr) + 1/Nr*Zbar*Zbar'/(noise_var + nmse))))`` with
+    the (uncapped) spectral-norm NMSE of ``S``."""
+    a_S, a_Z = _Arg(S, np.complex64, "S"), _Arg(Zbar, np.complex64, "Zbar")
+    if (a_S.batch, a_S.R, a_S.C) != (a_Z.batch, a_Z.R, a_Z.C):
+        raise ValueError("S and Zbar must have the same shape")
+    c, mem, dev = _ctx_for([a_S, a_Z], ctx)
+    if mem == DEVICE:
+        import torch
+        out = torch.empty(a_S.batch, dtype=torch.float64, device=dev)
+        ptr = out.data_ptr()
+    else:
+        out = np.empty(a_S.batch, dtype=np.float64)
+        ptr = out.ctypes.data
+    check(c._lib.jstsp_rate_c32(c.handle, a_S.R, a_S.C, a_S.batch, a_S.ptr, a_Z.ptr, float(noise_var), ptr, mem),
+          "jstsp_rate_c32")
+    return out if a_S.batched else out[0]
+
+
+def mmv_omp(A, Y, K, *, norm="l2", ctx=None):
+    """Joint (MMV) OMP — ``spx.pursuit.joint.OrthogonalMatchingPursuit(A, K).solve(Y).Z`` of the drivers
+    (plot_errorVSsnr.m:116-117; sparse-plex is un-vendored and unpinned: the published simultaneous OMP, atom score
+    ``||A(:,g)'*R||_2`` or ``_1``).  ``A``: (N, Gr) or (batch, N, Gr); ``Y``: (N, S) or (batch, N, S).
+    Returns (Z (Gr, S), support (1-based atoms in selection order, 0 beyond the count), count)."""
+    a_A, a_Y = _Arg(A, np.complex64, "A"), _Arg(Y, np.complex64, "Y")
+    batch, N, S, Gr = a_Y.batch, a_Y.R, a_Y.C, a_A.C
+    if a_A.R != N:
+        raise ValueError("size(A,1) must equal size(Y,1)")
+    c, mem, dev = _ctx_for([a_A, a_Y], ctx)
+    pz, fz = _out(mem == DEVICE, batch, Gr, S, np.complex64, dev)
+    pi, fi = _out(mem == DEVICE, batch, int(K), 1, np.int32, dev)
+    pc, fc = _out(mem == DEVICE, batch, 1, 1, np.int32, dev)
+    check(c._lib.jstsp_mmv_omp_c32(c.handle, N, Gr, S, batch, a_A.ptr, _shared_stride(a_A, N * Gr, batch, "A"), a_Y.ptr,
+                                   int(K), 1 if norm == "l1" else 2, pz, pi, pc, mem), "jstsp_mmv_omp_c32")
+    sq = not a_Y.batched
+    return fz(sq), fi(sq)[..., 0], fc(sq)[..., 0, 0]
+
+
+def tssr(Y_prop, Omega, A, B, Imax, tau, rho, K, *, norm="l2", ctx=None):
+    """The drivers' two-stage TSSR baseline (plot_errorVSsnr.m:151,158-162, a commented recipe): matrix completion by
+    ``mc_svt`` followed by joint OMP on ``Y_svt*pinv(B)`` with the dictionary ``A``.  Returns (S_tssr, Y_svt)."""
+    Y_svt = mc_svt(Y_prop, Omega, Imax, tau, rho, ctx=ctx)
+    PB = pinv(B, ctx=ctx)
+    if _is_torch(Y_svt):
+        T = colmajor(Y_svt @ PB)
+    else:
+        T = Y_svt @ PB
+    Z, _, _ = mmv_omp(A, T, K, norm=norm, ctx=ctx)
+    return Z, Y_svt
 
 
 def mc_svt(OH, Omega, Imax, tau, rho, *, ctx=None):

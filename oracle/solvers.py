@@ -23,6 +23,7 @@ __all__ = [
     "proposed_algorithm_angles_literal", "proposed_algorithm_angles",
     "omp_literal", "omp", "sparse_admm_literal", "sparse_admm",
     "mc_svt", "mc_admm_literal", "mc_admm", "spectral_norm", "nmse_capped",
+    "mmv_omp", "tssr", "rate",
 ]
 
 
@@ -469,3 +470,57 @@ def mc_admm(Htrue, OH, Omega, Imax, tau, rho, want_ce=True):
         if want_ce:
             ce[i] = _div(spectral_norm(X - Htrue) ** 2, spectral_norm(Htrue) ** 2)
     return X, ce
+
+
+# --------------------------------------------------------------------------- joint (MMV) OMP, TSSR, rate
+def mmv_omp(A, Y, K, norm="l2"):
+    """Joint (simultaneous) OMP — what the drivers call through the UN-VENDORED, UNPINNED sparse-plex:
+    ``spx.pursuit.joint.OrthogonalMatchingPursuit(A, K).solve(Y).Z`` (plot_errorVSsnr.m:116-117, :158-162).
+    PARITY UNPINNED: sparse-plex is not in /root/reference and no version is recorded (README.md:9); this restates
+    the published algorithm (Tropp-Gilbert-Strauss 2006 with the l1 row score, Chen-Huo 2006 with l2): one support
+    for all columns, atom = argmax_g ||A(:,g)'*R||_p (first index on ties), least squares on the support; stops after
+    K atoms, when min(N, Gr) atoms are in, when the new atom depends on the support, or when
+    ||R||_F <= 1e-6 ||Y||_F.  Returns (Z (Gr x S), support (1-based, selection order))."""
+    A = np.asarray(A, dtype=np.complex128)
+    Y = np.asarray(Y, dtype=np.complex128)
+    N, Gr = A.shape
+    S = Y.shape[1]
+    R = Y.copy()
+    Z = np.zeros((Gr, S), complex)
+    support = []
+    y2 = np.linalg.norm(Y) ** 2
+    for _ in range(min(K, N, Gr)):
+        C = A.conj().T @ R
+        score = np.sum(np.abs(C), axis=1) if norm == "l1" else np.sum(np.abs(C) ** 2, axis=1)
+        score[support] = -1.0
+        g = int(np.argmax(score))                         # first index on ties
+        sub = A[:, support + [g]]
+        if np.linalg.matrix_rank(sub, tol=1e-5 * np.linalg.norm(A[:, g])) < sub.shape[1]:
+            break
+        support.append(g)
+        coef = np.linalg.lstsq(sub, Y, rcond=None)[0]
+        R = Y - sub @ coef
+        Z[:] = 0
+        Z[support, :] = coef
+        if np.linalg.norm(R) ** 2 <= 1e-12 * y2:
+            break
+    return Z, np.array(support, dtype=np.int64) + 1
+
+
+def tssr(Y_prop, Omega, A, B, Imax, tau, rho, K, norm="l2"):
+    """plot_errorVSsnr.m:151,158-162 (commented recipe): ``Y_svt = mc_svt(...)``; joint OMP of ``Y_svt*pinv(B)`` on ``A``."""
+    Y_svt = mc_svt(Y_prop, Omega, Imax, tau, rho)
+    Z, _ = mmv_omp(A, Y_svt @ np.linalg.pinv(np.asarray(B, dtype=np.complex128)), K, norm)
+    return Z, Y_svt
+
+
+def rate(S, Zbar, noise_var):
+    """plot_rateVSframelength.m:81,113,130,135 —
+    ``log2(real(det(eye(Nr) + 1/(Nr)*Zbar*Zbar'*1/(square_noise_variance+norm(Zbar-S)^2/norm(Zbar)^2))))``."""
+    S = np.asarray(S, dtype=np.complex128)
+    Zbar = np.asarray(Zbar, dtype=np.complex128)
+    Nr = Zbar.shape[0]
+    e = _div(spectral_norm(Zbar - S) ** 2, spectral_norm(Zbar) ** 2)
+    M = np.eye(Nr) + (1.0 / Nr) * (Zbar @ Zbar.conj().T) / (noise_var + e)
+    sign, logdet = np.linalg.slogdet(M)
+    return float(logdet / np.log(2.0))

@@ -263,3 +263,49 @@ def test_ls_gram_route_reports_ill_conditioning_instead_of_garbage():
     assert rel_err(S, np.linalg.pinv(A) @ Y @ np.linalg.pinv(good)) < 2e-3
     with pytest.raises(J.JstspError, match="-6"):
         J.ls_estimate(Y, A, bad)
+
+
+def test_mmv_omp_tssr_and_rate_match_the_oracle():
+    """Joint OMP (published simultaneous OMP; sparse-plex itself is unpinned), the TSSR recipe built on it
+    (plot_errorVSsnr.m:151,158-162) and the rate metric (plot_rateVSframelength.m:81)."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(43)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    # row-sparse ground truth + noise, per-problem dictionaries, both row scores; supports must agree exactly
+    N, Gr, S, b = 32, 32, 16, 5
+    A = r(b, N, Gr) / np.sqrt(N)
+    Z0 = np.zeros((b, Gr, S), complex)
+    for t in range(b):
+        Z0[t, rng.choice(Gr, 4, replace=False)] = 3 * r(4, S)
+    Y = A @ Z0 + 0.05 * r(b, N, S)
+    for norm in ("l2", "l1"):
+        Z, sup, cnt = J.mmv_omp(A, Y, 6, norm=norm)
+        for t in range(b):
+            Zo, so = O.mmv_omp(A[t], Y[t], 6, norm)
+            assert cnt[t] == len(so) and np.array_equal(sup[t, :cnt[t]], so), (norm, t)
+            assert rel_err(Z[t], Zo) < 1e-4
+    # K >= atoms of a square full-rank A: the LS estimate pinv(A)*Y, as in the drivers (numOfnz = 100 >= 32 atoms)
+    Z, sup, cnt = J.mmv_omp(A[0], Y[0], 100)
+    assert cnt == 32 and sorted(sup[:32].tolist()) == list(range(1, 33))
+    assert rel_err(Z, np.linalg.pinv(A[0]) @ Y[0]) < 2e-3
+    # wide dictionary shared by the batch, more columns than threads per atom group
+    A2 = r(24, 40) / np.sqrt(24)
+    Y2 = r(3, 24, 70)
+    Z, sup, cnt = J.mmv_omp(A2, Y2, 10)
+    for t in range(3):
+        Zo, so = O.mmv_omp(A2, Y2[t], 10)
+        assert np.array_equal(sup[t, :cnt[t]], so) and rel_err(Z[t], Zo) < 1e-4
+    # TSSR at the reference-native measurement shape
+    g = load_golden("proposed_refnative")
+    St, Ysvt = J.tssr(g["subY"], g["Omega"], g["A"], g["B"], 30, float(g["tau_Y"]), 0.1, 8)
+    So, Yo = O.tssr(g["subY"], g["Omega"], g["A"], g["B"], 30, float(g["tau_Y"]), 0.1, 8)
+    assert rel_err(Ysvt, Yo) < 2e-4 and rel_err(St, So) < 2e-3
+    # rate
+    Zb = r(4, 32, 16)
+    Sx = Zb + np.array([0.01, 0.1, 1.0, 5.0])[:, None, None] * r(4, 32, 16)
+    out = J.rate(Sx, Zb, 0.3)
+    ref = np.array([O.rate(Sx[t], Zb[t], 0.3) for t in range(4)])
+    np.testing.assert_allclose(out, ref, rtol=2e-5)
+    wide = r(2, 40, 12)                                        # Nr > columns: the Gram of the smaller side
+    np.testing.assert_allclose(J.rate(0.9 * wide, wide, 0.1), [O.rate(0.9 * wide[t], wide[t], 0.1) for t in range(2)], rtol=2e-5)

@@ -209,3 +209,29 @@ def test_vamp_denoiser_known_values():
     assert xh[0] == 0 and abs(xh[1] - 0.8 * 30) < 1e-6 and np.all(xv > 0)
     xh2, _ = V._bg_denoise(np.array([1e-3 + 0j]), np.array([1e-40]), 4.0, 0.1)   # rvar floored at eps (:96)
     assert np.isfinite(xh2[0])
+
+
+def test_mmv_omp_known_answers_and_rate_identity():
+    """Joint OMP (parity unpinned: sparse-plex is not vendored): exact recovery of a row-sparse matrix on a unitary
+    dictionary, K >= number of atoms of a square full-rank A gives pinv(A)*Y (what the drivers' numOfnz = 100 does,
+    plot_errorVSsnr.m:116-117), both row scores.  rate: log2 det through slogdet equals the eigenvalue form."""
+    from oracle import solvers as O
+    rng = np.random.default_rng(4)
+    n = 16
+    D = np.exp(-2j * np.pi * np.outer(np.arange(n), np.arange(n)) / n) / np.sqrt(n)
+    Z0 = np.zeros((n, 9), complex)
+    rows = [3, 7, 12]
+    Z0[rows] = rng.standard_normal((3, 9)) + 1j * rng.standard_normal((3, 9))
+    for norm in ("l2", "l1"):
+        Z, sup = O.mmv_omp(D, D @ Z0, 5, norm)
+        assert sorted(sup.tolist()) == [r + 1 for r in rows]          # stops at zero residual after 3 atoms
+        assert np.allclose(Z, Z0, atol=1e-12)
+    A = rng.standard_normal((8, 8)) + 1j * rng.standard_normal((8, 8))
+    Y = rng.standard_normal((8, 5)) + 1j * rng.standard_normal((8, 5))
+    Z, sup = O.mmv_omp(A, Y, 100)
+    assert len(sup) == 8 and np.allclose(Z, np.linalg.pinv(A) @ Y, atol=1e-9)
+    Zb = rng.standard_normal((6, 10)) + 1j * rng.standard_normal((6, 10))
+    S = Zb + 0.1 * (rng.standard_normal((6, 10)) + 1j * rng.standard_normal((6, 10)))
+    e = O.spectral_norm(Zb - S) ** 2 / O.spectral_norm(Zb) ** 2
+    lam = np.linalg.eigvalsh(Zb @ Zb.conj().T)
+    assert abs(O.rate(S, Zb, 0.3) - np.sum(np.log2(1 + lam / (6 * (0.3 + e))))) < 1e-10
