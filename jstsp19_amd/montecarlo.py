@@ -43,40 +43,64 @@ def sweep_points(base: SweepParams, name, values):
     return pts
 
 
-def _hip_baselines(inp, numOfnz):
-    """LS and VAMP baselines of plot_errorVSsnr.m:73-105 on the conventional-HBF measurement."""
+def _score(S, zb, metric, noise_var):
+    """Per-trial figure of merit: capped spectral NMSE (plot_errorVSsnr.m:138-141) or the rate of
+    plot_rateVSframelength.m:81,113,130,135."""
+    from . import solvers as J
+    return J.nmse_spectral(S, zb) if metric == "nmse" else J.rate(S, zb, noise_var)
+
+
+def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None):
+    """LS, VAMP and MMV-OMP baselines of plot_errorVSsnr.m:73-121 on the conventional-HBF measurement; with
+    ``tssr = (Imax, rho)`` also the commented TSSR recipe (:151,158-162) on the proposed scheme's measurement."""
     from . import solvers as J
     zb = J.colmajor(inp["Zbar"].to(torch.complex64))
     S_ls = J.ls_estimate(inp["Y_hbf"], inp["A_hbf"], inp["B_hbf"])                       # :83
-    out = {"ls": J.nmse_spectral(S_ls, zb)}
+    out = {"ls": _score(S_ls, zb, metric, noise_var)}
     G2 = inp["B_hbf"].shape[1]
+    Bh = inp["B_hbf"]
     if G2 <= 128 and inp["A_hbf"].shape[0] <= 128:
-        Bh = inp["B_hbf"]
         Gb = J.colmajor(Bh @ Bh.conj().transpose(1, 2))                                  # (B*B')  :79
         Ym = J.colmajor(inp["Y_hbf"] @ Bh.conj().transpose(1, 2))                        # Y_hbf*B' :80
-        out["vamp"] = J.nmse_spectral(J.vamp_kron(Ym, inp["A_hbf"], Gb, 1.0, numOfnz), zb)   # :100
+        out["vamp"] = _score(J.vamp_kron(Ym, inp["A_hbf"], Gb, 1.0, numOfnz), zb, metric, noise_var)   # :100
+    try:
+        PB = J.pinv(Bh)                                                                  # pinv(B)  :117
+    except J.JstspError:
+        PB = None                                                                        # factor too large for the pinv kernel
+    if PB is not None:
+        Z, _, _ = J.mmv_omp(inp["A_hbf"], J.colmajor(inp["Y_hbf"] @ PB), numOfnz)        # :116-117
+        out["omp_mmv"] = _score(Z, zb, metric, noise_var)
+    if tssr is not None:
+        try:
+            St, _ = J.tssr(inp["subY"], inp["Omega"], inp["A"], inp["B"], tssr[0], inp["tau_Y"].numpy(), tssr[1],
+                           2 * numOfnz)                                                  # :151,:160-161
+            out["tssr"] = _score(St, zb, metric, noise_var)
+        except J.JstspError:
+            pass
     return out
 
 
-def _hip_solvers(device):
+def _hip_solvers(device, metric="nmse"):
     """Default solver pair: the HIP path.  Raises if the library / GPU is missing."""
     from . import solvers as J
 
-    def solve(inp, Imax):
+    def solve(inp, Imax, noise_var=1.0):
         S, _, _ = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax, inp["tau_Y"].numpy(),
                                        inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate", want_ce=False)
         Sa, _, _ = J.proposed_algorithm_angles(inp["subY"], inp["Omega"], inp["indx_S"], inp["A"], inp["B"], Imax,
                                                inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy(),
                                                "approximate", None, want_ce=False)
         zb = J.colmajor(inp["Zbar"].to(torch.complex64))
-        return J.nmse_spectral(S, zb), J.nmse_spectral(Sa, zb)
+        return _score(S, zb, metric, noise_var), _score(Sa, zb, metric, noise_var)
 
     return solve
 
 
 def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=None, solve_fn=None, dist=None,
-               baselines=False, numOfnz=100, builder=None):
-    """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP]).
+               baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None):
+    """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP, MMV-OMP
+    [, TSSR]]).  ``metric="rate"``: the rate of plot_rateVSframelength.m:81 instead of the NMSE (HIP solvers only).
+    ``tssr=(Imax_svt, rho_svt)`` adds the commented TSSR recipe of plot_errorVSsnr.m:151,158-162 as a sixth column.
 
     ``solve_fn(inputs, Imax) -> (nmse, nmse_angles)`` (two tensors of per-trial NMSE) defaults to the HIP path.
     ``baselines=True`` adds the LS and VAMP columns of plot_errorVSsnr.m:83-105 (HIP path only; VAMP is NaN
@@ -94,10 +118,15 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
         builder = "hip" if solve_fn is None else "torch"
     if builder not in ("hip", "torch"):
         raise ValueError("builder must be 'hip' or 'torch'")
+    if metric not in ("nmse", "rate"):
+        raise ValueError("metric must be 'nmse' or 'rate'")
+    custom = solve_fn is not None
+    if custom and metric != "nmse":
+        raise ValueError("metric='rate' needs the HIP solvers (solve_fn=None)")
     if solve_fn is None:
-        solve_fn = _hip_solvers(device)
+        solve_fn = _hip_solvers(device, metric)
     n_pts = len(points)
-    ncol = 4 if baselines else 2
+    ncol = (6 if tssr is not None else 5) if baselines else 2
     lo, hi = partition(n_pts * n_trials, world, rank)
     acc = torch.zeros((n_pts, ncol + 1), dtype=torch.float64)   # sums per column, then the trial count
     item = lo
@@ -111,13 +140,13 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
         else:
             draws = draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
             inp = build_inputs(p, draws, with_hbf=baselines)
-        e, ea = solve_fn(inp, Imax)
+        e, ea = solve_fn(inp, Imax) if custom else solve_fn(inp, Imax, p.noise_var)
         acc[pt, 0] += float(torch.as_tensor(e).double().sum())
         acc[pt, 1] += float(torch.as_tensor(ea).double().sum())
         if baselines:
-            b = _hip_baselines(inp, numOfnz)
-            acc[pt, 2] += float(b["ls"].double().sum())
-            acc[pt, 3] += float(b["vamp"].double().sum()) if "vamp" in b else float("nan")
+            b = _hip_baselines(inp, numOfnz, metric, p.noise_var, tssr)
+            for col, key in enumerate(("ls", "vamp", "omp_mmv", "tssr")[:ncol - 2]):
+                acc[pt, 2 + col] += float(b[key].double().sum()) if key in b else float("nan")
         acc[pt, ncol] += t1 - t0
         item += t1 - t0
     if dist is not None:

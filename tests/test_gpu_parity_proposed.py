@@ -180,10 +180,16 @@ def test_sweep_runner_on_hip_matches_oracle_per_point():
     ref = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev, solve_fn=oracle_solve, builder="hip").numpy()
     np.testing.assert_allclose(hip, ref, atol=1e-6)
     assert hip.shape == (3, 2) and np.all(hip[:, 1] <= hip[:, 0] + 1e-3)      # angle information helps
-    # with the conventional-HBF baselines (LS, VAMP) as extra columns
-    full = run_sweep(base, [3], 4, Imax=100, batch=4, device=dev, baselines=True).numpy()
-    assert full.shape == (1, 4) and np.all(np.isfinite(full)) and np.all(full > 0) and np.all(full <= 1)
+    # with the conventional-HBF baselines (LS, VAMP, MMV-OMP) as extra columns, and the TSSR recipe
+    full = run_sweep(base, [3], 4, Imax=100, batch=4, device=dev, baselines=True, tssr=(30, 0.1)).numpy()
+    assert full.shape == (1, 6) and np.all(np.isfinite(full)) and np.all(full > 0) and np.all(full <= 1)
     np.testing.assert_allclose(full[0, :2], run_sweep(base, [3], 4, Imax=100, batch=4, device=dev).numpy()[0], atol=1e-7)
+    # numOfnz = 100 >= the 32 atoms of the square A: joint OMP ends at the LS estimate (the two curves of
+    # results/errorVSsnr_angles.fig coincide)
+    assert abs(full[0, 4] - full[0, 2]) < 1e-3
+    # the rate metric of plot_rateVSframelength.m:81 on the same trials: positive, angle information does not hurt
+    rt = run_sweep(base, [3], 4, Imax=100, batch=4, device=dev, metric="rate").numpy()
+    assert rt.shape == (1, 2) and np.all(rt > 0) and rt[0, 1] >= rt[0, 0] - 1e-3
 
 
 def test_lanczos_lambda_max_agrees_with_householder_sturm():

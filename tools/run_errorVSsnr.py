@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The plot_errorVSsnr.m sweep (reference-native parameters, :8-25) on the HIP path: proposed_algorithm,
-proposed_algorithm_angles, LS and VAMP baselines; prints the mean capped NMSE per SNR point."""
+proposed_algorithm_angles, LS, VAMP and MMV-OMP baselines (+ the commented TSSR recipe with --tssr); prints the mean
+capped NMSE per SNR point, or with --rate the rate of plot_rateVSframelength.m:81."""
 import argparse, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=64)
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--builder", default="hip", choices=["hip", "torch"])
+ap.add_argument("--rate", action="store_true", help="rate metric of plot_rateVSframelength.m instead of the NMSE")
+ap.add_argument("--tssr", action="store_true", help="add the TSSR recipe (mc_svt with rho = 0.1, then joint OMP)")
 ap.add_argument("--config3", action="store_true", help="BASELINE configs[3]: Nt=Nr=64, Nrf=8, K=64, L=8, 10 SNR points")
 a = ap.parse_args()
 base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)              # plot_errorVSsnr.m:8-23
@@ -19,9 +22,11 @@ if a.config3:
     base = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8)           # the configs[1] shape (N=64, M=4096, Gr=64, G2=512)
     snrs = list(range(-15, 15, 3))                              # 10 points
 t0 = time.perf_counter()
-out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, numOfnz=100, builder=a.builder)
+out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, numOfnz=100, builder=a.builder,
+                metric="rate" if a.rate else "nmse", tssr=(100, 0.1) if a.tssr else None)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print("SNR(dB)  proposed  proposed+angles  LS        VAMP      (%d trials/point, %s input builder, %.1f s)" % (a.trials, a.builder, dt))
+print("SNR(dB)  proposed  proposed+angles  LS        VAMP      MMV-OMP%s   (%s, %d trials/point, %s input builder, %.1f s)"
+      % ("   TSSR" if a.tssr else "", "rate [bit/s/Hz]" if a.rate else "capped NMSE", a.trials, a.builder, dt))
 for s, row in zip(snrs, out.tolist()):
-    print("%6d   %.5f   %.5f          %.5f   %.5f" % (s, *row))
+    print("%6d   %.5f   %.5f          " % (s, row[0], row[1]) + "   ".join("%.5f" % v for v in row[2:]))
