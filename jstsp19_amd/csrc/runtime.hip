@@ -146,7 +146,8 @@ size_t GramWS::bytes(int rows, int cols, int batch, bool need_q)
     if (need_q) {
         b += rnd256((size_t)batch * n * n * sizeof(float2));
         if (n <= 64) b += rnd256((size_t)batch * eig_fast_ne(n) * eig_fast_ne(n) * sizeof(float2));
-        else if (eig_needs_global_v(n)) {
+        else b += 2 * rnd256((size_t)batch * n * n * sizeof(float2));       // warm-start basis + transform temporary
+        if (n > 64 && eig_needs_global_v(n)) {
             const int ne = (n + 1) & ~1;
             b += rnd256((size_t)batch * ne * ne * sizeof(float2));
         }
@@ -162,14 +163,19 @@ int GramWS::alloc(Arena &a, int rows_, int cols_, int batch_, bool need_q)
     nsplit = pick_nsplit(n, std::max(rows, cols), batch);
     Gpart = a.get<float2>((size_t)batch * nsplit * n * n);
     JSTSP_REQUIRE(Gpart, JSTSP_E_NOMEM, "workspace exhausted (Gram partials)");
-    Q = nullptr; Vg = nullptr; Uwarm = nullptr; warm = 0;
+    Q = nullptr; Vg = nullptr; Uwarm = nullptr; Twarm = nullptr; warm = 0;
     if (need_q) {
         Q = a.get<float2>((size_t)batch * n * n);
         JSTSP_REQUIRE(Q, JSTSP_E_NOMEM, "workspace exhausted (SVT projector)");
         if (n <= 64) {
             Uwarm = a.get<float2>((size_t)batch * eig_fast_ne(n) * eig_fast_ne(n));
             JSTSP_REQUIRE(Uwarm, JSTSP_E_NOMEM, "workspace exhausted (warm-start basis)");
-        } else if (eig_needs_global_v(n)) {
+        } else {
+            Uwarm = a.get<float2>((size_t)batch * n * n);
+            Twarm = a.get<float2>((size_t)batch * n * n);
+            JSTSP_REQUIRE(Uwarm && Twarm, JSTSP_E_NOMEM, "workspace exhausted (warm-start basis)");
+        }
+        if (n > 64 && eig_needs_global_v(n)) {
             const int ne = (n + 1) & ~1;
             Vg = a.get<float2>((size_t)batch * ne * ne);
             JSTSP_REQUIRE(Vg, JSTSP_E_NOMEM, "workspace exhausted (eigenvectors)");
@@ -223,6 +229,22 @@ int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
     if (w.n <= 64) {
         JSTSP_TRY(launch_eig_fast(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau,
                                   w.Q, nullptr, w.Uwarm, sequence ? w.warm : 0, skip ? amax : nullptr));
+        w.warm = sequence ? 1 : 0;
+        return 0;
+    }
+    // orders 65..128: G in LDS, the eigenvector basis in registers (eig3.hip); JSTSP_EIG128=0: the general kernel with
+    // the basis in HBM (eig.hip)
+    const char *e128 = getenv("JSTSP_EIG128");
+    if (!e128 || atoi(e128) != 0) {
+        // warm start (successive calls of an ADMM loop): G <- Uw^H (G Uw) with the previous basis, two batched GEMMs
+        const int warm = (sequence && w.warm && w.nsplit == 1 && w.Uwarm && w.Twarm) ? 1 : 0;
+        if (warm) {
+            const Mat Gm{w.Gpart, sG, w.n}, Um{w.Uwarm, sG, w.n};
+            JSTSP_TRY(gemm(ctx, 'N', 'N', w.n, w.n, w.n, w.batch, Gm, Um, w.Twarm, sG, w.n));
+            JSTSP_TRY(gemm(ctx, 'C', 'N', w.n, w.n, w.n, w.batch, Um, Mat{w.Twarm, sG, w.n}, w.Gpart, sG, w.n));
+        }
+        JSTSP_TRY(launch_eig128(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau, w.Q,
+                                sequence ? w.Uwarm : nullptr, warm));
         w.warm = sequence ? 1 : 0;
         return 0;
     }

@@ -28,7 +28,8 @@ struct GramWS {
     float2 *Gpart = nullptr;   // batch * nsplit * n*n
     float2 *Q = nullptr;       // batch * n*n
     float2 *Vg = nullptr;      // eigenvectors in HBM when they do not fit in LDS
-    float2 *Uwarm = nullptr;   // n <= 64: eigenvector basis of the previous call (warm start)
+    float2 *Uwarm = nullptr;   // eigenvector basis of the previous call (warm start): NE x NE padded for n <= 64, n x n above
+    float2 *Twarm = nullptr;   // n > 64: temporary of the warm-start transform G <- Uw^H (G Uw)
     mutable int warm = 0;      // 1 once Uwarm holds a basis
     static size_t bytes(int rows, int cols, int batch, bool need_q);
     int alloc(Arena &a, int rows, int cols, int batch, bool need_q);

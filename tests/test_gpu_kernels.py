@@ -152,3 +152,37 @@ def test_svt_zero_row_follows_the_oracle_and_zero_matrix_hits_the_guard():
     Xo, ceo = O.mc_admm(OH, Om * OH, Om, 12, 0.5, 0.2)
     assert rel_err(X, Xo) < 2e-4
     np.testing.assert_allclose(ce, ceo, rtol=2e-3)
+
+
+def test_mc_svt_and_mc_admm_orders_above_64_warm_started_register_resident_jacobi():
+    """Gram orders 65..128 take jacobi128_kernel (csrc/eig3.hip: G in LDS, eigenvector basis in registers); inside the
+    mc_* loops the basis of the previous iteration warm-starts it (G <- U^H G U by two batched GEMMs).  Whole
+    trajectories against the float64 oracle, square / wide / tall, batched; JSTSP_EIG128=0 (basis in HBM) agrees."""
+    import os
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(52)
+    for (r, c) in [(72, 80), (128, 128), (100, 70)]:
+        low = _rand(rng, 2, r, 5) @ _rand(rng, 2, 5, c)
+        H = low + 0.05 * _rand(rng, 2, r, c)
+        Om = (rng.random((2, r, c)) < 0.6).astype(float)
+        tau, rho = 2.0, 0.3
+        X = J.mc_svt(Om * H, Om, 8, tau, rho)
+        X2, ce = J.mc_admm(H, Om * H, Om, 8, tau, rho)
+        for t in range(2):
+            assert rel_err(X[t], O.mc_svt(Om[t] * H[t], Om[t], 8, tau, rho)) < 5e-4, (r, c)
+            Xo, ceo = O.mc_admm(H[t], Om[t] * H[t], Om[t], 8, tau, rho)
+            assert rel_err(X2[t], Xo) < 5e-4, (r, c)
+            np.testing.assert_allclose(ce[t], ceo, rtol=2e-3)
+    old = os.environ.get("JSTSP_EIG128")
+    try:
+        Y = _rand(rng, 96, 150)
+        a = J.svt(Y, 3.0)
+        os.environ["JSTSP_EIG128"] = "0"
+        b = J.svt(Y, 3.0)
+        assert rel_err(a, b) < 1e-5
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_EIG128", None)
+        else:
+            os.environ["JSTSP_EIG128"] = old
