@@ -328,8 +328,8 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
 //      LDS capacity spent on the streamed operand, and 2 x 4 waves x PD x 8 KiB of HBM requests in flight per CU
 //      (192 KiB at PD = 3, against 64 KiB for the LDS-staged kernel above).  Only the a panel (64 rows x 32 k, shared
 //      by all waves) is staged through LDS.  One fp32 accumulator per real sum (see LO_SCALE above): 64 accumulator
-//      registers per wave instead of 128.
-template <int EPI, bool APACK, int NW, int PD, bool LONGK>
+//      registers per wave instead of 128.  Chains of up to 1024 terms: no second-level sums.
+template <int EPI, bool APACK, int NW, int PD>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmDesc d, int tiles_j)
 {
     constexpr int NT = 64 * NW;
@@ -353,12 +353,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
     const int ai = tid & 63, akg = tid >> 6;
     const bool arow = ai < d.m;
     const float2 *abase = APACK ? nullptr : d.A + (long long)t * d.sAt;
-    const float2 *pa = APACK ? nullptr : abase + (arow ? ai : 0) + (long long)(NA * akg) * d.sAk;
+    const float2 *arow_base = APACK ? nullptr : abase + (arow ? ai : 0);
     const int a_slot = (NA == 8) ? ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31)
                                  : ((((ai >> 5) * 2 + (akg >> 2)) * 4) * 64) + ((akg >> 1) & 1) * 32 + (ai & 31);
     const float sa_m = arow ? sa : 0.f;
     const int nst = d.KS / 2;
-    const int kfull = d.k / HBK;
     // packed a: block q = wave * NAB + r of the stage: it = q >> 3, ks = (q >> 2) & 1, plane = q & 3
     const uint4 *paw = nullptr;
     if constexpr (APACK) {
@@ -374,18 +373,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
 #pragma unroll
             for (int r = 0; r < NAB; ++r) R.q[r] = g[r * 64];           // NAB <= 4 consecutive planes of one (it, ks)
         } else {
-            if (s < kfull) {
+            // unconditional loads: k past the end is clamped (and zeroed), never branched around
+            const int kbase = s * HBK + NA * akg;
 #pragma unroll
-                for (int v = 0; v < NA; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
-            } else {
-                const int kbase = s * HBK + NA * akg;
-#pragma unroll
-                for (int v = 0; v < NA; ++v) {
-                    const bool ok = kbase + v < d.k;
-                    const float2 *p = ok ? pa + (long long)(s * HBK + v) * d.sAk : abase;
-                    const float2 x = *p;
-                    R.a[v] = ok ? x : make_float2(0.f, 0.f);
-                }
+            for (int v = 0; v < NA; ++v) {
+                const int kk = min(kbase + v, d.k - 1);
+                float2 x = arow_base[(long long)kk * d.sAk];
+                if (kbase + v >= d.k) x = make_float2(0.f, 0.f);
+                R.a[v] = x;
             }
         }
     };
@@ -421,23 +416,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
     // ---- b: this wave's j-tile, straight to registers.  Block (jt, ks, plane) at ((jt KS + ks) 4 + plane) 64 uint4.
     const uint4 *pbw = d.Bp + (long long)t * d.sPt + ((long long)(tj * NW + wave) * d.KS) * 256 + lane;
     struct BStg { u32x4 q[8]; };            // [ks 2][plane 4]
+    // (stages past the end are redirected — by a select on the pointer, not a branch — to blocks this workgroup has
+    //  already read and whose data is ignored: re-reading the LAST stage instead cost 7 % extra HBM traffic, PMC
+    //  FETCH_SIZE, because the non-temporal dictionary lines are not kept in L2)
+    const uint4 *pdummy = APACK ? d.Ap + (long long)t * d.sApt + lane : pbw;
     auto load_b_half = [&](int s, int ks, BStg &R) {
-        const u32x4 *g = reinterpret_cast<const u32x4 *>(pbw + (long long)(2 * s + ks) * 256);
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(s < nst ? pbw + (long long)(2 * s + ks) * 256 : pdummy);
 #pragma unroll
         for (int p = 0; p < 4; ++p) R.q[ks * 4 + p] = __builtin_nontemporal_load(g + p * 64);
     };
 
-    f32x16 re[2], im[2], Lre[LONGK ? 2 : 1], Lim[LONGK ? 2 : 1];
+    f32x16 re[2], im[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { re[it][r] = 0.f; im[it][r] = 0.f; }
-    if constexpr (LONGK) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { Lre[it][r] = 0.f; Lim[it][r] = 0.f; }
-    }
     auto h8 = [](u32x4 u) { return *reinterpret_cast<half8 *>(&u); };
     auto nh8 = [](u32x4 u) { u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
                              return *reinterpret_cast<half8 *>(&u); };
@@ -478,29 +471,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
         re[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bi_h, n1i_l, re[1], 0, 0, 0);
         im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a1i_l, im[1], 0, 0, 0);
     };
-    auto fold = [&]() {
-        if constexpr (LONGK) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    Lre[it][r] += re[it][r]; Lim[it][r] += im[it][r];
-                    re[it][r] = 0.f; im[it][r] = 0.f;
-                }
-        }
-    };
-
-    // One stage.  A wave's loads return IN ORDER (s_waitcnt vmcnt counts them in issue order), so the a panel and the b
-    // fragments of one stage are requested together, PD stages ahead: waiting for the a panel of stage s+1 at the end
-    // of stage s then leaves exactly the requests of stage s+2 ... in flight.  (With the a panel requested one stage
-    // ahead and b three, every wait for a also waited for the two younger b stages: the pipeline ran at one HBM round
-    // trip per stage.)
+    const float alpha = ldexpf(1.f, -(ea + eb));
+    float2 *Cp = d.C + (long long)t * d.sCt;
     // Every load below is UNCONDITIONAL (past the end the stage index is clamped and the data ignored): a branch
     // around a load makes hipcc forget how many requests are outstanding and drain the queue (vmcnt(0)) at the top of
     // the loop.  The packs pad k to a multiple of 64, so the stage count is a multiple of PD = 2.
     auto stage = [&](int s, BStg &R, AStg &RAnext) {
         const uint4 *cur = smem + (s & 1) * 1024;
-        const int sb = min(s + PD, nst - 1), sa2 = min(s + 1 + PD, nst - 1);
+        const int sb = s + PD, sa2 = min(s + 1 + PD, nst - 1);      // (the a pack is L2-resident: clamping is free)
         compute_half(cur, 0, R);
         load_b_half(sb, 0, R);
         compute_half(cur, 1, R);
@@ -509,7 +487,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
         __builtin_amdgcn_sched_barrier(0);
         store_a(RAnext, smem + ((s + 1) & 1) * 1024);                      // a(s+1): requested PD stages ago
         load_a(sa2, RAnext);                                               // its registers are free again
-        if (LONGK && ((s + 1) % FLUSH) == 0) fold();
         __syncthreads();
     };
 
@@ -529,7 +506,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
 #pragma unroll
         for (int p = 0; p < PD; ++p) stage(s + p, RB[p], RAr[p]);
     }
-    if constexpr (LONGK) fold();
 
     // ---- epilogue: C(i, j), i = it 32 + (lane & 31), j = j0 + wave 32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
     // 16-byte accesses: accumulator registers r, r+1 are two adjacent columns of one row; lanes 2q and 2q+1 (adjacent
@@ -538,8 +514,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
     // (Measured at configs[1] by switching parts of the kernel off: dictionary + A S reads alone 0.75 ms = 5.45 TB/s;
     // + the Xs store 0.97 ms; + X / V2 reads and the V2 store 1.29 ms — 1.39 ms with 8-byte accesses; the MFMAs are
     // free, 0.03 ms.  What keeps the kernel from the read-stream rate is its read-modify-write tail.)
-    const float alpha = ldexpf(1.f, -(ea + eb));
-    float2 *Cp = d.C + (long long)t * d.sCt;
     float vmax = 0.f;
     const bool vec4 = ((d.m & 1) == 0) && ((d.ldc & 1) == 0) && ((d.sCt & 1) == 0) && (((uintptr_t)d.C & 15) == 0) &&
                       (EPI != EPI_UPDATE_C || ((((uintptr_t)d.e_r0 | (uintptr_t)d.e_rw0) & 15) == 0));
@@ -556,10 +530,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
                 const int r0 = 2 * rp, r1 = r0 + 1;
-                const float2 o0 = make_float2((LONGK ? Lre[LONGK ? it : 0][r0] : re[it][r0]) * alpha,
-                                              (LONGK ? Lim[LONGK ? it : 0][r0] : im[it][r0]) * alpha);
-                const float2 o1 = make_float2((LONGK ? Lre[LONGK ? it : 0][r1] : re[it][r1]) * alpha,
-                                              (LONGK ? Lim[LONGK ? it : 0][r1] : im[it][r1]) * alpha);
+                const float2 o0 = make_float2(re[it][r0] * alpha,
+                                              im[it][r0] * alpha);
+                const float2 o1 = make_float2(re[it][r1] * alpha,
+                                              im[it][r1] * alpha);
                 const float2 snd = odd ? o0 : o1;
                 const float2 rcv = make_float2(swap1(snd.x), swap1(snd.y));
                 float4 xs = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
@@ -589,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
             for (int r = 0; r < 16; ++r) {
                 const int gj = j0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (gj >= d.n) continue;
-                const float vr = LONGK ? Lre[LONGK ? it : 0][r] : re[it][r], vi = LONGK ? Lim[LONGK ? it : 0][r] : im[it][r];
+                const float vr = re[it][r], vi = im[it][r];
                 const float2 o = make_float2(vr * alpha, vi * alpha);
                 const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
                 if (EPI == EPI_UPDATE_C) {
@@ -816,18 +790,31 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_i * tiles_j;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
-    // v2 (hgemm2_kernel): one row tile, b fragments straight to registers.  JSTSP_H2_V2: bit 0 packed-a products
-    // (the synthesis), bit 1 fp32-a products (K B^H, the G_B applies)
-    static const int v2_mask = getenv("JSTSP_H2_V2") ? atoi(getenv("JSTSP_H2_V2")) : 1;
+    // v2 (hgemm2_kernel): one row tile, b fragments straight to registers.  JSTSP_H2_V2: bit 0 (default) packed-a
+    // products (the synthesis); bit 1 fp32-a products of up to 1024 terms (the G_B applies: 185 -> 135 us each, but
+    // their single-level 512-term sums feed the cancellation Res = A^H Tc - G_A V G_B and triple the rounding noise
+    // in S, 1.9e-6 -> 5.9e-6 relative: off by default)
+    const int v2_mask = getenv("JSTSP_H2_V2") ? atoi(getenv("JSTSP_H2_V2")) : 1;
     const bool pack_ok = d.JT * 32 >= ((d.n + 127) / 128) * 128;       // j padded to 128 columns: 4 waves x 32
     if (d.m <= 64 && pack_ok && d.Ap && (v2_mask & 1) && d.aKS == d.KS && (d.KS % 4) == 0) {
         const int tj2 = (d.n + 127) / 128;
         const long long grid2 = groups * 8 * tj2;
         if (prof_name) prof_begin(ctx, prof_name);
         if (d.epi == EPI_UPDATE_C)
-            hgemm2_kernel<EPI_UPDATE_C, true, 4, 2, false><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
+            hgemm2_kernel<EPI_UPDATE_C, true, 4, 2><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
         else
-            hgemm2_kernel<EPI_NONE, true, 4, 2, false><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
+            hgemm2_kernel<EPI_NONE, true, 4, 2><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
+        if (prof_name) prof_end(ctx, prof_name);
+        JSTSP_HIP(hipGetLastError());
+        return 0;
+    }
+    // (contractions of more than 1024 terms keep the two-level sums of hgemm_kernel: as an in-memory second level in
+    //  this kernel K B^H measured 1.13 ms against 0.98 ms, with 3x the rounding noise in S)
+    if (d.m <= 64 && pack_ok && !d.Ap && (v2_mask & 2) && (d.KS % 4) == 0 && d.epi == EPI_NONE && d.k <= 1024) {
+        const int tj2 = (d.n + 127) / 128;
+        const long long grid2 = groups * 8 * tj2;
+        if (prof_name) prof_begin(ctx, prof_name);
+        hgemm2_kernel<EPI_NONE, false, 4, 2><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
         if (prof_name) prof_end(ctx, prof_name);
         JSTSP_HIP(hipGetLastError());
         return 0;
