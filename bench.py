@@ -161,7 +161,7 @@ def main():
     n_l, ms = ctx.get_profile("correlate")
     n_s, ms_s = ctx.get_profile("synthesize")
     ctx.set_profiling(False)
-    # Dominant kernel: hgemm_kernel<EPI_UPDATE_C> = Xs = (A S) B on the split-f16 matrix pipe with the C / V2 update
+    # Dominant kernel: hgemm2_kernel<EPI_UPDATE_C> = Xs = (A S) B on the split-f16 matrix pipe with the C / V2 update
     # in its epilogue (proposed_algorithm.m:58,:61,:65).  It is HBM-bound: algorithmic bytes per launch =
     #   packed dictionary (4 f16 planes = 8 B per complex entry of B, read once)      G2*M*8 * nB
     # + a operand A S                                                                   N*G2*8 * batch
@@ -176,7 +176,7 @@ def main():
     traffic = traffic_c = None
     try:
         if not a.small and a.batch == 256:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pm = json.load(f)
             traffic = pm["synthesize_update_c"]["hbm_bytes_per_launch"]
             traffic_c = pm["correlate"]["hbm_bytes_per_launch"]
@@ -186,7 +186,7 @@ def main():
     if n_s:
         avg_ms = ms_s / n_s
         ach = bytes_synth / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "hgemm_kernel<EPI_UPDATE_C> ((A S) B + C/V2 update, split-f16 MFMA)",
+        roofline = {"bound": "hbm", "kernel": "hgemm2_kernel<EPI_UPDATE_C> ((A S) B + C/V2 update, split-f16 MFMA, dictionary HBM -> registers)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": n_s, "bytes_per_launch": bytes_synth,

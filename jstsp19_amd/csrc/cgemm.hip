@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     // matrix are redirected to element 0 and zeroed by a select, so every load is unconditional
     // (a predicated load makes hipcc branch around it and serialises the panel fetch).
     float2 ra[NLA], rb[NLB];
+    float2 rb2[(EPI == EPI_UPDATE_X) ? NLB : 1];        // second b source (EPI_UPDATE_X: Z = X - V1/rho formed here)
+    const bool two_b = (EPI == EPI_UPDATE_X) && d.B2 != nullptr;
+    const long long boff2 = two_b ? (d.B2 - d.B) : 0;   // same strides: element e of B2 sits boff2 elements after B's
+    const float bir = two_b ? d.prm[t].irho : 0.f;
     const float2 *pa[NLA], *pb[NLB];
     int la[NLA], lb[NLB], ka[NLA], kb[NLB];
     bool va[NLA], vb[NLB];
@@ -138,12 +142,20 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 #pragma unroll
             for (int p = 0; p < NLA; ++p) { ra[p] = *pa[p]; pa[p] += stepA; }
 #pragma unroll
-            for (int p = 0; p < NLB; ++p) { rb[p] = *pb[p]; pb[p] += stepB; }
+            for (int p = 0; p < NLB; ++p) {
+                rb[p] = *pb[p];
+                if constexpr (EPI == EPI_UPDATE_X) { if (two_b) rb2[p] = pb[p][boff2]; }
+                pb[p] += stepB;
+            }
         } else {                        // k tail: out-of-range elements read element 0 (zeroed in sstore)
 #pragma unroll
             for (int p = 0; p < NLA; ++p) ra[p] = *((va[p] && (k0 + ka[p] < kend)) ? pa[p] : Ap);
 #pragma unroll
-            for (int p = 0; p < NLB; ++p) rb[p] = *((vb[p] && (k0 + kb[p] < kend)) ? pb[p] : Bp);
+            for (int p = 0; p < NLB; ++p) {
+                const float2 *q = (vb[p] && (k0 + kb[p] < kend)) ? pb[p] : Bp;
+                rb[p] = *q;
+                if constexpr (EPI == EPI_UPDATE_X) { if (two_b) rb2[p] = q[boff2]; }
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -160,6 +172,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
             float2 v = rb[p];
+            if constexpr (EPI == EPI_UPDATE_X) { if (two_b) { v.x -= bir * rb2[p].x; v.y -= bir * rb2[p].y; } }
             const bool ok = vb[p] && (!tail || (tail_k0 + kb[p] < kend));
             if (!ok) v = make_float2(0.f, 0.f);
             v.y *= sgnB;

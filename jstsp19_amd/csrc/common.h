@@ -127,6 +127,7 @@ namespace jstsp {
 struct GemmDesc {
     const float2 *A; long long sAt, sAi, sAk; int conjA;
     const float2 *B; long long sBt, sBk, sBj; int conjB;
+    const float2 *B2;           // EPI_UPDATE_X only, may be NULL: b = B - prm[t].irho * B2 (same strides: Z = X - V1/rho on the fly)
     float2 *C; long long sCt; int ldc;
     const float2 *D; long long sDt; int ldd;
     float alpha, beta;
@@ -185,7 +186,12 @@ struct HGemmDesc {
 // Gpart[(t*nsplit + s)*rows*rows + i + rows*j];  amax[t] bounds max(|re|,|im|) of Z[t]
 // skip_prm != nullptr: problems with prm[t].tauY_rho <= 2^-27 amax[t] are skipped (see jacobi2_kernel)
 int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
-                 const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm = nullptr);
+                 const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm = nullptr, const float2 *Z2 = nullptr,
+                 const TrialParams *zprm = nullptr);     // Z2: Gram of Z - zprm[t].irho * Z2 (same layout as Z)
+// G_x = X X^H, G_v = V1 V1^H, G_z = (X - V1/rho)(X - V1/rho)^H in one pass over X and V1 (rows <= 64)
+int launch_hgram3(jstsp_ctx *ctx, const float2 *X, const float2 *V1, long long sZt, int rows, int cols, int count, int nsplit,
+                  const uint32_t *xmax, const uint32_t *vmax, const uint32_t *zmax, const TrialParams *prm, float2 *Gz,
+                  float2 *Gx, float2 *Gv);
 size_t hgemm_pack_bytes(int Kd, int J, int count);
 // amax[t] = max(|re|, |im|) over n contiguous elements of X[t*sXt ...]
 int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax);

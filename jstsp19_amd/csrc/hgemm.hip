@@ -588,9 +588,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
 // ---- Gram partials G_s = sum_{k in chunk s} z_k z_k^H of a rows x cols matrix (rows <= 64), same split-f16
 //      arithmetic: ONE panel (64 rows x 32 k, split on the fly) feeds both MFMA operands,
 //        re G(i,j) = sum ar_i ar_j + ai_i ai_j,   im G(i,j) = sum ai_i ar_j - ar_i ai_j.
+//      Z2 != nullptr: the matrix is Z - zprm[t].irho * Z2, formed on the fly (the svt argument X - V1/rho of
+//      proposed_algorithm.m:35 without ever storing it: X and V1 were written by the preceding kernel).
 __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long long sZt, int rows, int cols, int nsplit,
                                                        const uint32_t *amax, float2 *Gpart, int batch,
-                                                       const TrialParams *skip_prm)
+                                                       const TrialParams *skip_prm, const float2 *Z2,
+                                                       const TrialParams *zprm)
 {
     __shared__ uint4 smem[2 * 1024];        // per stage: a blocks [it 2][ks 2][plane 4], 1 KiB each
     const int t = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
@@ -608,6 +611,8 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
     const float sa_m = arow ? ldexpf(1.f, ea) : 0.f;
     const float2 *abase = Z + (long long)t * sZt;
     const float2 *pa = abase + (arow ? ai : 0) + (long long)(kbeg + 8 * akg) * rows;
+    const long long off2 = Z2 ? (Z2 - Z) : 0;           // same layout: element i of Z2 sits off2 elements after element i of Z
+    const float ir2 = Z2 ? zprm[t].irho : 0.f;
     const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
     const int kfull = (kend - kbeg) / HBK;
 
@@ -616,13 +621,21 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
         if (s < kfull) {
 #pragma unroll
             for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * rows];
+            if (Z2) {
+#pragma unroll
+                for (int v = 0; v < 8; ++v) {
+                    const float2 y = pa[(long long)(s * HBK + v) * rows + off2];
+                    R.a[v].x -= ir2 * y.x; R.a[v].y -= ir2 * y.y;
+                }
+            }
         } else {
             const int kbase = kbeg + s * HBK + 8 * akg;
 #pragma unroll
             for (int v = 0; v < 8; ++v) {
                 const bool ok = kbase + v < kend;
                 const float2 *p = ok ? pa + (long long)(s * HBK + v) * rows : abase;
-                const float2 x = *p;
+                float2 x = *p;
+                if (Z2) { const float2 y = p[off2]; x.x -= ir2 * y.x; x.y -= ir2 * y.y; }
                 R.a[v] = ok ? x : make_float2(0.f, 0.f);
             }
         }
@@ -708,6 +721,131 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
     }
 }
 
+// ---- Three Grams from ONE pass over X and V1 (rows <= 64): G_x = X X^H, G_v = V1 V1^H and G_z = Z Z^H with
+//      Z = X - V1/rho formed in registers — the spectral norms of convergence_error(:,1:2) (proposed_algorithm.m:67,69)
+//      and the svt argument of the next iteration (:35), which is therefore never stored.  Wave (wi, wj) computes block
+//      (wi, wj) of all three Grams with one fp32 accumulator per real sum; k chunks of at most 512 terms per workgroup
+//      (no second-level sums: these Grams feed an eigensolver and a norm ratio, not the gradient).
+__global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const float2 *V1, long long sZt, int rows, int cols,
+                                                        int nsplit, const uint32_t *xmax, const uint32_t *vmax,
+                                                        const uint32_t *zmax, const TrialParams *prm, float2 *Gz,
+                                                        float2 *Gx, float2 *Gv, int batch)
+{
+    __shared__ uint4 smem[3 * 1024];        // panels of X | V1 | Z: blocks [it 2][ks 2][plane 4], 1 KiB each
+    const int t = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    if (t >= batch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave & 1, wj = wave >> 1;
+    const int ex = scale_exp(xmax[t]), ev = scale_exp(vmax[t]), ez = scale_exp(zmax[t]);
+    const int kchunk = ((cols + nsplit - 1) / nsplit + HBK - 1) / HBK * HBK;
+    const int kbeg = split * kchunk, kend = min(cols, kbeg + kchunk);
+    const int nst = kend > kbeg ? (kend - kbeg + HBK - 1) / HBK : 0;
+    const int ai = tid & 63, akg = tid >> 6;
+    const bool arow = ai < rows;
+    const float sx = arow ? ldexpf(1.f, ex) : 0.f, sv = arow ? ldexpf(1.f, ev) : 0.f, sz = arow ? ldexpf(1.f, ez) : 0.f;
+    const float ir = prm[t].irho;
+    const long long base = (long long)t * sZt + (arow ? ai : 0);
+    const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
+
+    struct Stg { float2 x[8], v[8]; };
+    auto load = [&](int s, Stg &R) {
+        const int kbase = kbeg + s * HBK + 8 * akg;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int kk = min(kbase + u, cols - 1);
+            const long long ix = base + (long long)kk * rows;
+            float2 a = X[ix], b = V1[ix];
+            if (kbase + u >= kend) { a = make_float2(0.f, 0.f); b = make_float2(0.f, 0.f); }
+            R.x[u] = a; R.v[u] = b;
+        }
+    };
+    auto put = [&](uint4 *panel, const float2 *val, float sc) {
+        half8 rh, rl, ih, il;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            _Float16 h, l;
+            split2(val[u].x * sc, h, l); rh[u] = h; rl[u] = l;
+            split2(val[u].y * sc, h, l); ih[u] = h; il[u] = l;
+        }
+        uint4 *q = panel + a_slot;
+        q[0] = *reinterpret_cast<uint4 *>(&rh);
+        q[64] = *reinterpret_cast<uint4 *>(&rl);
+        q[128] = *reinterpret_cast<uint4 *>(&ih);
+        q[192] = *reinterpret_cast<uint4 *>(&il);
+    };
+    auto store = [&](const Stg &R) {
+        float2 z[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z[u] = make_float2(R.x[u].x - ir * R.v[u].x, R.x[u].y - ir * R.v[u].y);   // (:35)
+        put(smem, R.x, sx);
+        put(smem + 1024, R.v, sv);
+        put(smem + 2048, z, sz);
+    };
+    f32x16 re[3], im[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { re[g][r] = 0.f; im[g][r] = 0.f; }
+    auto compute = [&]() {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const uint4 *buf = smem + g * 1024;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 *fi = buf + ((wi * 2 + ks) * 4) * 64 + lane;     // rows i: MFMA B operand (tile columns)
+                const uint4 *fj = buf + ((wj * 2 + ks) * 4) * 64 + lane;     // rows j: MFMA A operand (tile rows)
+                const half8 ir_h = as_half8(fi[0]), ir_l = as_half8(fi[64]), ii_h = as_half8(fi[128]), ii_l = as_half8(fi[192]);
+                const uint4 ujr_h = fj[0], ujr_l = fj[64], uji_h = fj[128], uji_l = fj[192];
+                const half8 jr_h = as_half8(ujr_h), jr_l = as_half8(ujr_l), ji_h = as_half8(uji_h), ji_l = as_half8(uji_l);
+                const half8 nji_h = neg_half8(uji_h), nji_l = neg_half8(uji_l);
+                // re G(i,j) = sum ar_i ar_j + ai_i ai_j ;  im G(i,j) = sum ai_i ar_j - ar_i ai_j   (h h + h l + l h each)
+                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_h, re[g], 0, 0, 0);
+                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_h, im[g], 0, 0, 0);
+                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_h, re[g], 0, 0, 0);
+                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_h, im[g], 0, 0, 0);
+                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ir_h, re[g], 0, 0, 0);
+                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ii_h, im[g], 0, 0, 0);
+                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_l, re[g], 0, 0, 0);
+                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_l, im[g], 0, 0, 0);
+                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_l, ii_h, re[g], 0, 0, 0);
+                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_l, ir_h, im[g], 0, 0, 0);
+                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_l, re[g], 0, 0, 0);
+                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_l, im[g], 0, 0, 0);
+            }
+        }
+    };
+    if (nst > 0) {
+        // (measured: a second register set with the panels of stage s+2 in flight is slower, 361 vs 332 us — the stage
+        //  is bound by its own VALU work (address arithmetic, three fp32 -> 2 x f16 splits) and MFMAs, not by HBM latency)
+        Stg R;
+        load(0, R);
+        store(R);
+        __syncthreads();
+        for (int s = 0; s < nst; ++s) {
+            load(min(s + 1, nst - 1), R);           // unconditional (the last stage re-reads itself: cache-hot)
+            compute();
+            __syncthreads();
+            store(R);
+            __syncthreads();
+        }
+    }
+    const int gi = wi * 32 + (lane & 31);
+    const long long po = ((long long)t * nsplit + split) * rows * rows;
+    if (gi < rows) {
+        const float ax = ldexpf(1.f, -2 * ex), av = ldexpf(1.f, -2 * ev), az = ldexpf(1.f, -2 * ez);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gj = wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (gj < rows) {
+                const long long o = po + gi + (long long)gj * rows;
+                Gx[o] = make_float2(re[0][r] * ax, im[0][r] * ax);
+                Gv[o] = make_float2(re[1][r] * av, im[1][r] * av);
+                Gz[o] = make_float2(re[2][r] * az, im[2][r] * az);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // JSTSP_H2 = 0: never, 2: always, 1 / unset: when the contraction is big enough to pay for the two
@@ -766,13 +904,31 @@ int hgemm_repack(jstsp_ctx *ctx, const HPack &p, const float2 *B, long long sBt,
 }
 
 int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
-                 const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm)
+                 const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm, const float2 *Z2,
+                 const TrialParams *zprm)
 {
     JSTSP_REQUIRE(rows > 0 && rows <= 64 && cols > 0 && count > 0 && nsplit > 0, JSTSP_E_SHAPE, "hgram: bad shape");
     const long long grid = (long long)count * nsplit;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgram grid too large");
     prof_begin(ctx, "gram");
-    hgram_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count, skip_prm);
+    JSTSP_REQUIRE(!Z2 || zprm, JSTSP_E_NULL, "hgram: Z2 without per-problem scalars");
+    hgram_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count, skip_prm, Z2, zprm);
+    prof_end(ctx, "gram");
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// Gx / Gv / Gz: partial buffers of the three Grams, all laid out [(t * nsplit + s) * rows * rows + i + rows * j]
+int launch_hgram3(jstsp_ctx *ctx, const float2 *X, const float2 *V1, long long sZt, int rows, int cols, int count, int nsplit,
+                  const uint32_t *xmax, const uint32_t *vmax, const uint32_t *zmax, const TrialParams *prm, float2 *Gz,
+                  float2 *Gx, float2 *Gv)
+{
+    JSTSP_REQUIRE(rows > 0 && rows <= 64 && cols > 0 && count > 0 && nsplit > 0, JSTSP_E_SHAPE, "hgram3: bad shape");
+    const long long grid = (long long)count * nsplit;
+    JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgram3 grid too large");
+    prof_begin(ctx, "gram");
+    hgram3_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx, Gv,
+                                                            count);
     prof_end(ctx, "gram");
     JSTSP_HIP(hipGetLastError());
     return 0;

@@ -39,6 +39,14 @@ struct ProposedWS {
     uint32_t *pmax = nullptr;
 };
 
+// k-split of the fused three-Gram pass (hgram3_kernel: G_x, G_v1 and G_z from one read of X and V1): chunks of at most
+// 512 columns; 0 = that pass is not used for this shape (then every Gram workspace picks its own split)
+static int gram3_nsplit(int N, int M, int G2, bool want_ce)
+{
+    if (!(want_ce && N <= 64 && N <= M && use_hgemm(N, G2, M))) return 0;
+    return std::max(1, std::min(32, (M + 511) / 512));
+}
+
 static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, int nB, bool angles,
                              bool want_ce, int Imax)
 {
@@ -53,8 +61,9 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     if (angles) b += rnd256(batch * g * sizeof(int32_t));
     b += rnd256((size_t)batch * 3 * Imax * sizeof(double));
     b += rnd256(3 * (size_t)batch * sizeof(float));
-    b += GramWS::bytes(N, M, batch, true);
-    if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false);
+    const int ns3 = gram3_nsplit(N, M, G2, want_ce);
+    b += GramWS::bytes(N, M, batch, true, ns3);
+    if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false, ns3);
     if (use_hgemm(N, G2, M))
         b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(8 * batch * sizeof(uint32_t)) +
              hgemm_pack_bytes(G2, N, batch);
@@ -87,8 +96,9 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
                       w.RRes && w.S && w.P1 && w.Tc && w.W && w.GA && w.GB && w.prm && w.ce && w.lam &&
                       (!angles || w.rank),
                   JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
-    JSTSP_TRY(w.gz.alloc(a, N, M, batch, true));
-    if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false));
+    const int ns3 = gram3_nsplit(N, M, G2, want_ce);
+    JSTSP_TRY(w.gz.alloc(a, N, M, batch, true, ns3));
+    if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false, ns3));
     w.h2 = use_hgemm(N, G2, M);
     if (w.h2) {
         // operand maxima of one iteration, one block zeroed once per iteration: kmax | X | V1 | V2 | Znext | wmax | pmax x2.
@@ -291,6 +301,14 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     // opt-in: problems whose threshold is below the fp32 resolution of Z skip the Gram + eigen-decomposition (Y = Z)
     const bool svt_skip = getenv("JSTSP_SVT_SKIP") ? atoi(getenv("JSTSP_SVT_SKIP")) != 0 : false;
     const bool hmax = w.h2 && fz && N <= 64;    // the epilogues also deliver max|X|, |V1|, |V2|, |Znext|: split-f16 Grams
+    // The svt argument Z = X - V1/rho is never stored on that path: the Gram kernel and the (I - Q) Z product form it
+    // from X and V1 on the fly (both were written by the kernel before and are re-read while still close), which saves
+    // one N x M array write per iteration in the X/K/V1 epilogue.  JSTSP_ZFLY=0: store Znext as round 1 did.
+    // Only with convergence_error, where the Gram pass over X and V1 exists anyway and delivers G_z with it
+    // (hgram3_kernel); a Z-only Gram from two sources costs more than the saved write.
+    const bool zfly = hmax && want_ce && gram3_nsplit(N, M, G2, want_ce) > 0 && w.gz.nsplit == w.gn.nsplit &&
+                      (getenv("JSTSP_ZFLY") ? atoi(getenv("JSTSP_ZFLY")) != 0 : true) &&
+                      (getenv("JSTSP_PZ") ? atoi(getenv("JSTSP_PZ")) != 0 : true);     // (needs the (I - Q) Z form)
     float2 *Zbuf[2] = {w.Zb, w.Zb2};            // svt argument of iteration it lives in Zbuf[it & 1]
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
@@ -319,7 +337,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             dq.epi = EPI_UPDATE_X; dq.prm = w.prm;
             dq.e_rw0 = w.V1; dq.e_w1 = w.X; dq.e_w2 = w.ZK;
             dq.e_r0 = w.V2; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
-            dq.e_w3 = (it + 1 < Imax) ? Zn : nullptr;
+            dq.e_w3 = (it + 1 < Imax && !zfly) ? Zn : nullptr;
+            if (zfly && it > 0) { dq.B = w.X; dq.B2 = w.V1; }      // Z = X - V1/rho in the panel loader (it == 0: Z = 0 in Zc)
             dq.epi_store_c = (it + 1 == Imax);          // Y itself is only an output of the last iteration
             if (w.h2) {                                 // max|K| for the split-f16 correlation, from the same epilogue
                 dq.amax_out = w.kmax;
@@ -336,10 +355,17 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
             StreamScope sc(ctx, s1);
             if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
+            if (zfly) {
+                // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
+                JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
+                                        w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
+                JSTSP_HIP(hipEventRecord(ev_gxv, s1));
+                JSTSP_TRY(svt_prepare(ctx, w.gz, w.X, w.prm, nullptr, true, w.zmax, svt_skip, nullptr, true));
+            } else
             JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr, svt_skip));
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
         }
-        if (want_ce) {              // s2: Gram of [X | V1]
+        if (want_ce && !(zfly && it + 1 < Imax)) {              // s2: Gram of [X | V1]
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_x, 0));
             StreamScope sc(ctx, s2);
             JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr));
@@ -428,6 +454,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         if (want_ce) {
             JSTSP_HIP(hipEventRecord(ev_c, sm));
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
+            if (zfly) JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));      // G_x, G_v1 came from the side stream s1
             StreamScope sc(ctx, s2);
             JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gv2, s2));

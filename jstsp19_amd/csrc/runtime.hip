@@ -108,7 +108,7 @@ GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Ma
     d.conjA = (opA == 'C' || opA == 'J');
     d.conjB = (opB == 'C' || opB == 'J');
     if (!tA) { d.sAi = 1; d.sAk = A.ld; } else { d.sAi = A.ld; d.sAk = 1; }   // a(i,kk) = A[i + ld*kk] | A[kk + ld*i]
-    d.B = B.p; d.sBt = B.st;
+    d.B = B.p; d.sBt = B.st; d.B2 = nullptr;
     if (!tB) { d.sBk = 1; d.sBj = B.ld; } else { d.sBk = B.ld; d.sBj = 1; }   // b(kk,j) = B[kk + ld*j] | B[j + ld*kk]
     d.C = C; d.sCt = sCt; d.ldc = ldc;
     d.D = D; d.sDt = sDt; d.ldd = ldd;
@@ -138,10 +138,10 @@ static int pick_nsplit(int n, int kc, int batch)
     return (int)std::min<long long>(want, 32);
 }
 
-size_t GramWS::bytes(int rows, int cols, int batch, bool need_q)
+size_t GramWS::bytes(int rows, int cols, int batch, bool need_q, int force_nsplit)
 {
     const int n = std::min(rows, cols), kc = std::max(rows, cols);
-    const int ns = pick_nsplit(n, kc, batch);
+    const int ns = force_nsplit > 0 ? force_nsplit : pick_nsplit(n, kc, batch);
     size_t b = rnd256((size_t)batch * ns * n * n * sizeof(float2));
     if (need_q) {
         b += rnd256((size_t)batch * n * n * sizeof(float2));
@@ -155,12 +155,12 @@ size_t GramWS::bytes(int rows, int cols, int batch, bool need_q)
     return b;
 }
 
-int GramWS::alloc(Arena &a, int rows_, int cols_, int batch_, bool need_q)
+int GramWS::alloc(Arena &a, int rows_, int cols_, int batch_, bool need_q, int force_nsplit)
 {
     rows = rows_; cols = cols_; batch = batch_;
     n = std::min(rows, cols);
     left = rows <= cols;
-    nsplit = pick_nsplit(n, std::max(rows, cols), batch);
+    nsplit = force_nsplit > 0 ? force_nsplit : pick_nsplit(n, std::max(rows, cols), batch);
     Gpart = a.get<float2>((size_t)batch * nsplit * n * n);
     JSTSP_REQUIRE(Gpart, JSTSP_E_NOMEM, "workspace exhausted (Gram partials)");
     Q = nullptr; Vg = nullptr; Uwarm = nullptr; Twarm = nullptr; warm = 0;
@@ -197,11 +197,13 @@ int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZ
 }
 
 int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count,
-                        const uint32_t *amax, const TrialParams *skip_prm)
+                        const uint32_t *amax, const TrialParams *skip_prm, const float2 *Z2, const TrialParams *zprm)
 {
     if (amax && w.left && w.n <= 64)       // split-f16 path: amax[t0 + i] bounds problem t0 + i
         return launch_hgram(ctx, Z + (long long)t0 * sZt, sZt, w.rows, w.cols, count, w.nsplit, amax + t0,
-                            w.Gpart + (long long)t0 * w.n * w.n * w.nsplit, skip_prm ? skip_prm + t0 : nullptr);
+                            w.Gpart + (long long)t0 * w.n * w.n * w.nsplit, skip_prm ? skip_prm + t0 : nullptr,
+                            Z2 ? Z2 + (long long)t0 * sZt : nullptr, zprm ? zprm + t0 : nullptr);
+    JSTSP_REQUIRE(!Z2, JSTSP_E_ARG, "gram_partials_range: on-the-fly Z needs the split-f16 Gram path");
     const Mat Zm{Z + (long long)t0 * sZt, sZt, w.rows};
     const long long sG = (long long)w.n * w.n;
     float2 *G = w.Gpart + (long long)t0 * sG * w.nsplit;
@@ -219,12 +221,14 @@ int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos
 }
 
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
-                bool sequence, const uint32_t *amax, bool allow_skip)
+                bool sequence, const uint32_t *amax, bool allow_skip, const float2 *Z2, bool gram_done)
 {
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
     const bool skip = allow_skip && amax && prm && !tau && w.left && w.n <= 64;
-    if (amax) JSTSP_TRY(gram_partials_range(ctx, w, Z, sZ, 0, w.batch, amax, skip ? prm : nullptr));
+    JSTSP_REQUIRE(!Z2 || (amax && prm), JSTSP_E_ARG, "svt_prepare: on-the-fly Z needs the split-f16 Gram path");
+    if (gram_done) { /* nothing */ }
+    else if (amax) JSTSP_TRY(gram_partials_range(ctx, w, Z, sZ, 0, w.batch, amax, skip ? prm : nullptr, Z2, Z2 ? prm : nullptr));
     else JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
     if (w.n <= 64) {
         JSTSP_TRY(launch_eig_fast(ctx, EIG_SVT_Q, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau,

@@ -31,8 +31,8 @@ struct GramWS {
     float2 *Uwarm = nullptr;   // eigenvector basis of the previous call (warm start): NE x NE padded for n <= 64, n x n above
     float2 *Twarm = nullptr;   // n > 64: temporary of the warm-start transform G <- Uw^H (G Uw)
     mutable int warm = 0;      // 1 once Uwarm holds a basis
-    static size_t bytes(int rows, int cols, int batch, bool need_q);
-    int alloc(Arena &a, int rows, int cols, int batch, bool need_q);
+    static size_t bytes(int rows, int cols, int batch, bool need_q, int force_nsplit = 0);
+    int alloc(Arena &a, int rows, int cols, int batch, bool need_q, int force_nsplit = 0);
 };
 
 // G partials of Z (split-K over the long dimension).
@@ -45,11 +45,14 @@ int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
 // The two halves of svt_batched: Gram + eigen-decomposition -> projector Q; then Y = Z - Q Z.
 // amax != nullptr (per-problem bound on max(|re|,|im|) of Z): Gram on the split-f16 path when rows <= 64
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
-                bool sequence, const uint32_t *amax = nullptr, bool allow_skip = false);
+                bool sequence, const uint32_t *amax = nullptr, bool allow_skip = false, const float2 *Z2 = nullptr,
+                bool gram_done = false);   // gram_done: the partials of G are already in the workspace
+                // Z2 (split-f16 Gram path only): the svt argument is Z - prm[t].irho * Z2, never stored
 int svt_apply(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float2 *Y);
 // Gram partials of problems [t0, t0 + count) only (same workspace layout as gram_partials).
 int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count,
-                        const uint32_t *amax = nullptr, const TrialParams *skip_prm = nullptr);
+                        const uint32_t *amax = nullptr, const TrialParams *skip_prm = nullptr, const float2 *Z2 = nullptr,
+                        const TrialParams *zprm = nullptr);
 // lam[t] = lambda_max of the Gram partials already in the workspace, all w.batch problems
 int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos = false);
 // Make sure the context's side streams / events exist.

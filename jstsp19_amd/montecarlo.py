@@ -72,9 +72,10 @@ def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None):
         out["omp_mmv"] = _score(Z, zb, metric, noise_var)
     if tssr is not None:
         try:
-            St, _ = J.tssr(inp["subY"], inp["Omega"], inp["A"], inp["B"], tssr[0], inp["tau_Y"].numpy(), tssr[1],
-                           2 * numOfnz)                                                  # :151,:160-161
+            St, _, Ssvt = J.tssr(inp["subY"], inp["Omega"], inp["A"], inp["B"], tssr[0], inp["tau_Y"].numpy(), tssr[1],
+                                 2 * numOfnz)                                            # :151,:160-161
             out["tssr"] = _score(St, zb, metric, noise_var)
+            out["svt"] = _score(Ssvt, zb, metric, noise_var)                             # :152-153
         except J.JstspError:
             pass
     return out
@@ -100,7 +101,8 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
                baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None):
     """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP, MMV-OMP
     [, TSSR]]).  ``metric="rate"``: the rate of plot_rateVSframelength.m:81 instead of the NMSE (HIP solvers only).
-    ``tssr=(Imax_svt, rho_svt)`` adds the commented TSSR recipe of plot_errorVSsnr.m:151,158-162 as a sixth column.
+    ``tssr=(Imax_svt, rho_svt)`` adds the commented recipes of plot_errorVSsnr.m:151-162 as columns six and seven: TSSR
+    (``mc_svt`` then joint OMP) and "SVT-based" (``pinv(A)*Y_svt*pinv(B)``).
 
     ``solve_fn(inputs, Imax) -> (nmse, nmse_angles)`` (two tensors of per-trial NMSE) defaults to the HIP path.
     ``baselines=True`` adds the LS and VAMP columns of plot_errorVSsnr.m:83-105 (HIP path only; VAMP is NaN
@@ -126,7 +128,7 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
     if solve_fn is None:
         solve_fn = _hip_solvers(device, metric)
     n_pts = len(points)
-    ncol = (6 if tssr is not None else 5) if baselines else 2
+    ncol = (7 if tssr is not None else 5) if baselines else 2
     lo, hi = partition(n_pts * n_trials, world, rank)
     acc = torch.zeros((n_pts, ncol + 1), dtype=torch.float64)   # sums per column, then the trial count
     item = lo
@@ -145,7 +147,7 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
         acc[pt, 1] += float(torch.as_tensor(ea).double().sum())
         if baselines:
             b = _hip_baselines(inp, numOfnz, metric, p.noise_var, tssr)
-            for col, key in enumerate(("ls", "vamp", "omp_mmv", "tssr")[:ncol - 2]):
+            for col, key in enumerate(("ls", "vamp", "omp_mmv", "tssr", "svt")[:ncol - 2]):
                 acc[pt, 2 + col] += float(b[key].double().sum()) if key in b else float("nan")
         acc[pt, ncol] += t1 - t0
         item += t1 - t0

@@ -308,15 +308,19 @@ def mmv_omp(A, Y, K, *, norm="l2", ctx=None):
 
 def tssr(Y_prop, Omega, A, B, Imax, tau, rho, K, *, norm="l2", ctx=None):
     """The drivers' two-stage TSSR baseline (plot_errorVSsnr.m:151,158-162, a commented recipe): matrix completion by
-    ``mc_svt`` followed by joint OMP on ``Y_svt*pinv(B)`` with the dictionary ``A``.  Returns (S_tssr, Y_svt)."""
+    ``mc_svt`` followed by joint OMP on ``Y_svt*pinv(B)`` with the dictionary ``A``.  Returns (S_tssr, Y_svt, S_svt) with
+    ``S_svt = pinv(A)*Y_svt*pinv(B)`` the "SVT-based" estimate of :151-152."""
     Y_svt = mc_svt(Y_prop, Omega, Imax, tau, rho, ctx=ctx)
     PB = pinv(B, ctx=ctx)
+    PA = pinv(A, ctx=ctx)
     if _is_torch(Y_svt):
         T = colmajor(Y_svt @ PB)
+        S_svt = colmajor(PA @ T)
     else:
         T = Y_svt @ PB
+        S_svt = PA @ T
     Z, _, _ = mmv_omp(A, T, K, norm=norm, ctx=ctx)
-    return Z, Y_svt
+    return Z, Y_svt, S_svt
 
 
 def mc_svt(OH, Omega, Imax, tau, rho, *, ctx=None):

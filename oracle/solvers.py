@@ -510,8 +510,9 @@ def mmv_omp(A, Y, K, norm="l2"):
 def tssr(Y_prop, Omega, A, B, Imax, tau, rho, K, norm="l2"):
     """plot_errorVSsnr.m:151,158-162 (commented recipe): ``Y_svt = mc_svt(...)``; joint OMP of ``Y_svt*pinv(B)`` on ``A``."""
     Y_svt = mc_svt(Y_prop, Omega, Imax, tau, rho)
-    Z, _ = mmv_omp(A, Y_svt @ np.linalg.pinv(np.asarray(B, dtype=np.complex128)), K, norm)
-    return Z, Y_svt
+    T = Y_svt @ np.linalg.pinv(np.asarray(B, dtype=np.complex128))
+    Z, _ = mmv_omp(A, T, K, norm)
+    return Z, Y_svt, np.linalg.pinv(np.asarray(A, dtype=np.complex128)) @ T       # S_tssr, Y_svt, S_svt (:152)
 
 
 def rate(S, Zbar, noise_var):

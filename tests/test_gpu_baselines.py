@@ -298,9 +298,9 @@ def test_mmv_omp_tssr_and_rate_match_the_oracle():
         assert np.array_equal(sup[t, :cnt[t]], so) and rel_err(Z[t], Zo) < 1e-4
     # TSSR at the reference-native measurement shape
     g = load_golden("proposed_refnative")
-    St, Ysvt = J.tssr(g["subY"], g["Omega"], g["A"], g["B"], 30, float(g["tau_Y"]), 0.1, 8)
-    So, Yo = O.tssr(g["subY"], g["Omega"], g["A"], g["B"], 30, float(g["tau_Y"]), 0.1, 8)
-    assert rel_err(Ysvt, Yo) < 2e-4 and rel_err(St, So) < 2e-3
+    St, Ysvt, Ssvt = J.tssr(g["subY"], g["Omega"], g["A"], g["B"], 30, float(g["tau_Y"]), 0.1, 8)
+    So, Yo, Ssvto = O.tssr(g["subY"], g["Omega"], g["A"], g["B"], 30, float(g["tau_Y"]), 0.1, 8)
+    assert rel_err(Ysvt, Yo) < 2e-4 and rel_err(St, So) < 2e-3 and rel_err(Ssvt, Ssvto) < 2e-3
     # rate
     Zb = r(4, 32, 16)
     Sx = Zb + np.array([0.01, 0.1, 1.0, 5.0])[:, None, None] * r(4, 32, 16)

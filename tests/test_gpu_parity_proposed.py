@@ -182,7 +182,7 @@ def test_sweep_runner_on_hip_matches_oracle_per_point():
     assert hip.shape == (3, 2) and np.all(hip[:, 1] <= hip[:, 0] + 1e-3)      # angle information helps
     # with the conventional-HBF baselines (LS, VAMP, MMV-OMP) as extra columns, and the TSSR recipe
     full = run_sweep(base, [3], 4, Imax=100, batch=4, device=dev, baselines=True, tssr=(30, 0.1)).numpy()
-    assert full.shape == (1, 6) and np.all(np.isfinite(full)) and np.all(full > 0) and np.all(full <= 1)
+    assert full.shape == (1, 7) and np.all(np.isfinite(full)) and np.all(full > 0) and np.all(full <= 1)
     np.testing.assert_allclose(full[0, :2], run_sweep(base, [3], 4, Imax=100, batch=4, device=dev).numpy()[0], atol=1e-7)
     # numOfnz = 100 >= the 32 atoms of the square A: joint OMP ends at the LS estimate (the two curves of
     # results/errorVSsnr_angles.fig coincide)

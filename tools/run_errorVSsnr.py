@@ -27,6 +27,6 @@ out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, n
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print("SNR(dB)  proposed  proposed+angles  LS        VAMP      MMV-OMP%s   (%s, %d trials/point, %s input builder, %.1f s)"
-      % ("   TSSR" if a.tssr else "", "rate [bit/s/Hz]" if a.rate else "capped NMSE", a.trials, a.builder, dt))
+      % ("   TSSR      SVT" if a.tssr else "", "rate [bit/s/Hz]" if a.rate else "capped NMSE", a.trials, a.builder, dt))
 for s, row in zip(snrs, out.tolist()):
     print("%6d   %.5f   %.5f          " % (s, row[0], row[1]) + "   ".join("%.5f" % v for v in row[2:]))
