@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
 // ---- Three Grams from ONE pass over X and V1 (rows <= 64): G_x = X X^H, G_v = V1 V1^H and G_z = Z Z^H with
 //      Z = X - V1/rho formed in registers — the spectral norms of convergence_error(:,1:2) (proposed_algorithm.m:67,69)
 //      and the svt argument of the next iteration (:35), which is therefore never stored.  Wave (wi, wj) computes block
-//      (wi, wj) of all three Grams with one fp32 accumulator per real sum; k chunks of at most 512 terms per workgroup
+//      (wi, wj) of all three Grams with one fp32 accumulator per real sum; k chunks of at most 1024 terms per workgroup
 //      (no second-level sums: these Grams feed an eigensolver and a norm ratio, not the gradient).
 __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const float2 *V1, long long sZt, int rows, int cols,
                                                         int nsplit, const uint32_t *xmax, const uint32_t *vmax,
@@ -748,15 +748,24 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
     const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
 
     struct Stg { float2 x[8], v[8]; };
+    const float2 *px = X + base + (long long)(kbeg + 8 * akg) * rows;
+    const long long dv = V1 - X;                        // same layout: V1's element sits dv elements after X's
+    const int kfull = (kend - kbeg) / HBK;              // stages whose 32 columns all exist
     auto load = [&](int s, Stg &R) {
-        const int kbase = kbeg + s * HBK + 8 * akg;
+        if (s < kfull) {                                // wave-uniform: plain strided loads
+            const float2 *p = px + (long long)(s * HBK) * rows;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int kk = min(kbase + u, cols - 1);
-            const long long ix = base + (long long)kk * rows;
-            float2 a = X[ix], b = V1[ix];
-            if (kbase + u >= kend) { a = make_float2(0.f, 0.f); b = make_float2(0.f, 0.f); }
-            R.x[u] = a; R.v[u] = b;
+            for (int u = 0; u < 8; ++u) { R.x[u] = p[(long long)u * rows]; R.v[u] = p[(long long)u * rows + dv]; }
+        } else {
+            const int kbase = kbeg + s * HBK + 8 * akg;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = min(kbase + u, cols - 1);
+                const long long ix = base + (long long)kk * rows;
+                float2 a = X[ix], b = V1[ix];
+                if (kbase + u >= kend) { a = make_float2(0.f, 0.f); b = make_float2(0.f, 0.f); }
+                R.x[u] = a; R.v[u] = b;
+            }
         }
     };
     auto put = [&](uint4 *panel, const float2 *val, float sc) {

@@ -40,11 +40,14 @@ struct ProposedWS {
 };
 
 // k-split of the fused three-Gram pass (hgram3_kernel: G_x, G_v1 and G_z from one read of X and V1): chunks of at most
-// 512 columns; 0 = that pass is not used for this shape (then every Gram workspace picks its own split)
+// 1024 columns; 0 = that pass is not used for this shape (then every Gram workspace picks its own split)
 static int gram3_nsplit(int N, int M, int G2, bool want_ce)
 {
+    // (measured at configs[1], chunks of 512 / 1024 / 2048 columns: 493 / 497 / 496 channel-estimates/s — more splits
+    //  shorten the single-level fp32 chains but every consumer of the Gram sums the partials again)
+    static const int JSTSP_G3_CHUNK = getenv("JSTSP_G3_CHUNK") ? atoi(getenv("JSTSP_G3_CHUNK")) : 1024;
     if (!(want_ce && N <= 64 && N <= M && use_hgemm(N, G2, M))) return 0;
-    return std::max(1, std::min(32, (M + 511) / 512));
+    return std::max(1, std::min(32, (M + JSTSP_G3_CHUNK - 1) / JSTSP_G3_CHUNK));
 }
 
 static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, int nB, bool angles,
