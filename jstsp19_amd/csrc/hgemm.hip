@@ -119,7 +119,7 @@ __device__ __forceinline__ half8 neg_half8(uint4 u)
 // LDS stage: a blocks [it 2][ks 2][plane 4] then b blocks [jt 2][ks 2][plane 4], 1 KiB each.
 // WJ = waves along j: 2 (64 x 64 tile, 256 threads, two workgroups per CU) or 4 (64 x 128 tile, 512 threads, one
 // workgroup per CU: half as many workgroups split the same a panel).
-template <int EPI, bool APACK, int WJ>
+template <int EPI, bool APACK, int WJ, bool EVEN = false>
 __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmDesc d, int tiles_i, int tiles_j)
 {
     constexpr int NT = 128 * WJ;                  // threads
@@ -172,7 +172,11 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
                                    ((long long)(ti * 2 + (wave >> 1)) * d.KS + (wave & 1)) * 256
                              : nullptr;
     const float sa_m = arow ? sa : 0.f;     // rows outside the product contribute zeros
-    auto load = [&](int s, Stg &R) {
+    // EVEN (k a multiple of 32, even stage count — the K B^H of the ADMM): every load and LDS store is unconditional
+    // (stages past the end re-read stage 0, data unused), so hipcc can count the outstanding requests instead of
+    // draining them (vmcnt(0)) in front of every stage's LDS stores
+    auto load = [&](int s_in, Stg &R) {
+        const int s = EVEN ? (s_in < nst ? s_in : 0) : s_in;
         const uint4 *g = pbw + (long long)(2 * s) * 256;
         const u32x4 *gn = reinterpret_cast<const u32x4 *>(g);
         const u32x4 x0 = __builtin_nontemporal_load(gn), x1 = __builtin_nontemporal_load(gn + 64),
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
             const u32x4 *ga = reinterpret_cast<const u32x4 *>(paw + (long long)(2 * s) * 256);
             R.a0 = ga[0]; R.a1 = ga[64]; R.a2 = ga[128]; R.a3 = ga[192];
         } else {
-            if (s < kfull) {
+            if (EVEN || s < kfull) {
 #pragma unroll
                 for (int v = 0; v < NA; ++v) R.a[v] = pa[(long long)(s * HBK + v) * d.sAk];
             } else {
@@ -265,13 +269,13 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
     // one stage: issue the loads of stage s+2 into `Rfar`, run the MFMAs on `cur`, then move stage s+1 (already in
     // flight in `Rnear` for a whole stage) into `nxt`
     auto stage = [&](int s, const uint4 *cur, uint4 *nxt, Stg &Rnear, Stg &Rfar) {
-        if (s + 2 < nst) load(s + 2, Rfar);
+        if (EVEN || s + 2 < nst) load(s + 2, Rfar);
         compute(cur);
         // keep the LDS stores of the prefetched panels (and the vmcnt waits they carry) behind the MFMAs: the
         // compiler proves the two buffers disjoint and would otherwise hoist them to right after the loads
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nst) store(Rnear, nxt);
+        if (EVEN || s + 1 < nst) store(Rnear, nxt);
         if (((s + 1) % FLUSH) == 0) fold();
         __syncthreads();
     };
@@ -280,13 +284,13 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
     Stg R0, R1;
     uint4 *buf0 = smem, *buf1 = smem + STG;
     load(0, R0);
-    if (nst > 1) load(1, R1);
+    if (EVEN || nst > 1) load(1, R1);
     store(R0, buf0);
     __syncthreads();
 
     for (int s = 0; s < nst; s += 2) {
         stage(s, buf0, buf1, R1, R0);
-        if (s + 1 < nst) stage(s + 1, buf1, buf0, R0, R1);
+        if (EVEN || s + 1 < nst) stage(s + 1, buf1, buf0, R0, R1);
     }
     fold();
 
@@ -590,6 +594,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
 //        re G(i,j) = sum ar_i ar_j + ai_i ai_j,   im G(i,j) = sum ai_i ar_j - ar_i ai_j.
 //      Z2 != nullptr: the matrix is Z - zprm[t].irho * Z2, formed on the fly (the svt argument X - V1/rho of
 //      proposed_algorithm.m:35 without ever storing it: X and V1 were written by the preceding kernel).
+template <bool EVEN>
 __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long long sZt, int rows, int cols, int nsplit,
                                                        const uint32_t *amax, float2 *Gpart, int batch,
                                                        const TrialParams *skip_prm, const float2 *Z2,
@@ -617,8 +622,10 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
     const int kfull = (kend - kbeg) / HBK;
 
     struct Stg { float2 a[8]; };
-    auto load = [&](int s, Stg &R) {
-        if (s < kfull) {
+    // EVEN: every chunk is a whole, even number of 32-column stages: unconditional loads / stores (see hgemm_kernel)
+    auto load = [&](int s_in, Stg &R) {
+        const int s = EVEN ? (s_in < nst ? s_in : 0) : s_in;
+        if (EVEN || s < kfull) {
 #pragma unroll
             for (int v = 0; v < 8; ++v) R.a[v] = pa[(long long)(s * HBK + v) * rows];
             if (Z2) {
@@ -688,11 +695,11 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
         }
     };
     auto stage = [&](int s, const uint4 *cur, uint4 *nxt, Stg &Rnear, Stg &Rfar) {
-        if (s + 2 < nst) load(s + 2, Rfar);
+        if (EVEN || s + 2 < nst) load(s + 2, Rfar);
         compute(cur);
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nst) store(Rnear, nxt);
+        if (EVEN || s + 1 < nst) store(Rnear, nxt);
         if (((s + 1) % FLUSH) == 0) fold();
         __syncthreads();
     };
@@ -700,12 +707,12 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
         Stg R0, R1;
         uint4 *buf0 = smem, *buf1 = smem + 1024;
         load(0, R0);
-        if (nst > 1) load(1, R1);
+        if (EVEN || nst > 1) load(1, R1);
         store(R0, buf0);
         __syncthreads();
         for (int s = 0; s < nst; s += 2) {
             stage(s, buf0, buf1, R1, R0);
-            if (s + 1 < nst) stage(s + 1, buf1, buf0, R0, R1);
+            if (EVEN || s + 1 < nst) stage(s + 1, buf1, buf0, R0, R1);
         }
     }
     fold();
@@ -726,6 +733,7 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
 //      and the svt argument of the next iteration (:35), which is therefore never stored.  Wave (wi, wj) computes block
 //      (wi, wj) of all three Grams with one fp32 accumulator per real sum; k chunks of at most 1024 terms per workgroup
 //      (no second-level sums: these Grams feed an eigensolver and a norm ratio, not the gradient).
+template <bool EVEN>
 __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const float2 *V1, long long sZt, int rows, int cols,
                                                         int nsplit, const uint32_t *xmax, const uint32_t *vmax,
                                                         const uint32_t *zmax, const TrialParams *prm, float2 *Gz,
@@ -751,8 +759,11 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
     const float2 *px = X + base + (long long)(kbeg + 8 * akg) * rows;
     const long long dv = V1 - X;                        // same layout: V1's element sits dv elements after X's
     const int kfull = (kend - kbeg) / HBK;              // stages whose 32 columns all exist
-    auto load = [&](int s, Stg &R) {
-        if (s < kfull) {                                // wave-uniform: plain strided loads
+    // EVEN: every chunk is a whole, even number of 32-column stages: all loads unconditional, two register sets with the
+    // panels of stage s+2 in flight (with a branch around the loads hipcc drains the queue, vmcnt(0), at every store)
+    auto load = [&](int s_in, Stg &R) {
+        const int s = EVEN ? (s_in < nst ? s_in : 0) : s_in;
+        if (EVEN || s < kfull) {                        // wave-uniform: plain strided loads
             const float2 *p = px + (long long)(s * HBK) * rows;
 #pragma unroll
             for (int u = 0; u < 8; ++u) { R.x[u] = p[(long long)u * rows]; R.v[u] = p[(long long)u * rows + dv]; }
@@ -824,18 +835,36 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
         }
     };
     if (nst > 0) {
-        // (measured: a second register set with the panels of stage s+2 in flight is slower, 361 vs 332 us — the stage
-        //  is bound by its own VALU work (address arithmetic, three fp32 -> 2 x f16 splits) and MFMAs, not by HBM latency)
-        Stg R;
-        load(0, R);
-        store(R);
-        __syncthreads();
-        for (int s = 0; s < nst; ++s) {
-            load(min(s + 1, nst - 1), R);           // unconditional (the last stage re-reads itself: cache-hot)
-            compute();
+        if constexpr (EVEN) {
+            Stg R0, R1;
+            load(0, R0);
+            load(1, R1);
+            store(R0);
             __syncthreads();
+            for (int s = 0; s < nst; s += 2) {
+                load(s + 2, R0);
+                compute();
+                __syncthreads();
+                store(R1);
+                __syncthreads();
+                load(s + 3, R1);
+                compute();
+                __syncthreads();
+                store(R0);
+                __syncthreads();
+            }
+        } else {
+            Stg R;
+            load(0, R);
             store(R);
             __syncthreads();
+            for (int s = 0; s < nst; ++s) {
+                load(min(s + 1, nst - 1), R);
+                compute();
+                __syncthreads();
+                store(R);
+                __syncthreads();
+            }
         }
     }
     const int gi = wi * 32 + (lane & 31);
@@ -921,7 +950,10 @@ int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int c
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgram grid too large");
     prof_begin(ctx, "gram");
     JSTSP_REQUIRE(!Z2 || zprm, JSTSP_E_NULL, "hgram: Z2 without per-problem scalars");
-    hgram_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count, skip_prm, Z2, zprm);
+    if (cols % (nsplit * 2 * HBK) == 0)
+        hgram_kernel<true><<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count, skip_prm, Z2, zprm);
+    else
+        hgram_kernel<false><<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count, skip_prm, Z2, zprm);
     prof_end(ctx, "gram");
     JSTSP_HIP(hipGetLastError());
     return 0;
@@ -936,8 +968,12 @@ int launch_hgram3(jstsp_ctx *ctx, const float2 *X, const float2 *V1, long long s
     const long long grid = (long long)count * nsplit;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgram3 grid too large");
     prof_begin(ctx, "gram");
-    hgram3_kernel<<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx, Gv,
-                                                            count);
+    if (cols % (nsplit * 2 * HBK) == 0)
+        hgram3_kernel<true><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx,
+                                                                      Gv, count);
+    else
+        hgram3_kernel<false><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx,
+                                                                       Gv, count);
     prof_end(ctx, "gram");
     JSTSP_HIP(hipGetLastError());
     return 0;
@@ -985,7 +1021,10 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
         return 0;
     }
     if (prof_name) prof_begin(ctx, prof_name);
-    if (wide) {
+    static const bool even_ok = getenv("JSTSP_H2_EVEN") ? atoi(getenv("JSTSP_H2_EVEN")) != 0 : true;
+    if (wide && even_ok && (d.k % 32) == 0 && ((d.KS / 2) % 2) == 0 && d.KS == 2 * (d.k / 32)) {
+        hgemm_kernel<EPI_NONE, false, 4, true><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);
+    } else if (wide) {
         hgemm_kernel<EPI_NONE, false, 4><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     } else if (d.Ap) {
         JSTSP_REQUIRE(d.aKS == d.KS, JSTSP_E_ARG, "hgemm: packed a and b operands disagree on the k padding");
