@@ -526,37 +526,55 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
     };
     if (vec4) {
+        // All X / V2 loads of a row block (eight register pairs: 16 requests per lane) are issued BEFORE the first use,
+        // from addresses that are always valid (out-of-range pairs read the tile's first element and are masked at the
+        // store): with a bounds `continue` in front of the loads hipcc waited for each pair's loads (vmcnt(0)) before
+        // issuing the next pair's — sixteen serialized HBM round trips per lane.
         const bool odd = lane & 1;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int gi = it * 32 + (lane & 31);
             const int gi2 = gi & ~1;
+            float4 xs[8];
+            long long ixs[8];
+            bool ok[8];
 #pragma unroll
             for (int rp = 0; rp < 8; ++rp) {
                 const int r0 = 2 * rp, r1 = r0 + 1;
-                const float2 o0 = make_float2(re[it][r0] * alpha,
-                                              im[it][r0] * alpha);
-                const float2 o1 = make_float2(re[it][r1] * alpha,
-                                              im[it][r1] * alpha);
+                const float2 o0 = make_float2(re[it][r0] * alpha, im[it][r0] * alpha);
+                const float2 o1 = make_float2(re[it][r1] * alpha, im[it][r1] * alpha);
                 const float2 snd = odd ? o0 : o1;
                 const float2 rcv = make_float2(swap1(snd.x), swap1(snd.y));
-                float4 xs = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
+                xs[rp] = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
                 const int gj = j0 + wave * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * (lane >> 5) + (odd ? 1 : 0);
-                if (gi2 >= d.m || gj >= d.n) continue;
-                const long long ix = (long long)t * d.sCt + gi2 + (long long)gj * d.ldc;
-                if (EPI == EPI_UPDATE_C) {
-                    // Xs in xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
-                    const float4 x = *reinterpret_cast<const float4 *>(d.e_r0 + ix);
-                    float4 v2 = *reinterpret_cast<const float4 *>(d.e_rw0 + ix);
-                    v2.x = omc * (v2.x - rho * (x.x - xs.x));
-                    v2.y = omc * (v2.y - rho * (x.y - xs.y));
-                    v2.z = omc * (v2.z - rho * (x.z - xs.z));
-                    v2.w = omc * (v2.w - rho * (x.w - xs.w));
-                    *reinterpret_cast<float4 *>(d.e_rw0 + ix) = v2;
-                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y))), fmaxf(fabsf(v2.z), fabsf(v2.w)));
-                }
-                *reinterpret_cast<float4 *>(Cp + gi2 + (long long)gj * d.ldc) = xs;
+                ok[rp] = gi2 < d.m && gj < d.n;
+                ixs[rp] = (long long)t * d.sCt + (ok[rp] ? gi2 + (long long)gj * d.ldc : 0);
             }
+            if (EPI == EPI_UPDATE_C) {
+                float4 x[8], v2[8];
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    x[rp] = *reinterpret_cast<const float4 *>(d.e_r0 + ixs[rp]);
+                    v2[rp] = *reinterpret_cast<const float4 *>(d.e_rw0 + ixs[rp]);
+                }
+                asm volatile("" ::: "memory");      // keep the sixteen requests together, ahead of every store
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    // Xs in xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
+                    float4 v = v2[rp];
+                    v.x = omc * (v.x - rho * (x[rp].x - xs[rp].x));
+                    v.y = omc * (v.y - rho * (x[rp].y - xs[rp].y));
+                    v.z = omc * (v.z - rho * (x[rp].z - xs[rp].z));
+                    v.w = omc * (v.w - rho * (x[rp].w - xs[rp].w));
+                    if (ok[rp]) {
+                        *reinterpret_cast<float4 *>(d.e_rw0 + ixs[rp]) = v;
+                        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    }
+                }
+            }
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp)
+                if (ok[rp]) *reinterpret_cast<float4 *>(d.C + ixs[rp]) = xs[rp];
         }
     } else {
 #pragma unroll
