@@ -111,7 +111,8 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
         JSTSP_REQUIRE(w.kmax, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
         w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch; w.wmax = w.kmax + 5 * (size_t)batch;
         w.pmax = w.kmax + 6 * (size_t)batch;
-        w.Wp.KS = 4 * ((G2 + 63) / 64); w.Wp.JT = 4 * ((N + 127) / 128); w.Wp.count = batch;
+        w.Wp.KS = 4 * ((G2 + 63) / 64); w.Wp.JT = 2 * ((N + 63) / 64); w.Wp.count = batch;     // (an a pack needs whole 64-row
+                                                                                            //  tiles only, not 128-wide ones)
         w.Wp.st = (long long)w.Wp.JT * w.Wp.KS * 256;
         w.Wp.data = a.get<uint4>((size_t)batch * w.Wp.st);
         w.Wp.bmax = w.wmax;
