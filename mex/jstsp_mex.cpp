@@ -180,6 +180,40 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                                 x.data(), JSTSP_HOST);
         if (rc) fail("jstsp_vamp_c32", rc);
         plhs[0] = from_c32(x, N, 1);
+    } else if (fn == "mmv_omp") {
+        // (A, K, Y) -> [Z, support]   replaces spx.pursuit.joint.OrthogonalMatchingPursuit(A, K).solve(Y).Z
+        // (plot_errorVSsnr.m:116-117; sparse-plex is not vendored: published simultaneous OMP, l2 row score)
+        const int N = (int)mxGetM(prhs[1]), Gr = (int)mxGetN(prhs[1]);
+        const int K = (int)mxGetScalar(prhs[2]);
+        const int S = (int)mxGetN(prhs[3]);
+        if ((int)mxGetM(prhs[3]) != N) mexErrMsgIdAndTxt("jstsp:shape", "mmv_omp: size(Y,1) must equal size(A,1)");
+        std::vector<jstsp_c32> A, Y, Z((size_t)Gr * S);
+        to_c32(prhs[1], A); to_c32(prhs[3], Y);
+        std::vector<int32_t> idx(K), cnt(1);
+        int rc = jstsp_mmv_omp_c32(g_ctx, N, Gr, S, 1, A.data(), 0, Y.data(), K, 2, Z.data(), idx.data(), cnt.data(), JSTSP_HOST);
+        if (rc) fail("jstsp_mmv_omp_c32", rc);
+        plhs[0] = from_c32(Z, Gr, S);
+        if (nlhs >= 2) {
+            plhs[1] = mxCreateDoubleMatrix(1, cnt[0], mxREAL);
+            for (int i = 0; i < cnt[0]; ++i) mxGetDoubles(plhs[1])[i] = idx[i];
+        }
+    } else if (fn == "pinv") {
+        // (A) -> pinv(A) through the float64 SVD kernel (small matrices; MATLAB's own pinv works as well)
+        const int R = (int)mxGetM(prhs[1]), C = (int)mxGetN(prhs[1]);
+        std::vector<jstsp_c32> A, P((size_t)R * C);
+        to_c32(prhs[1], A);
+        int rc = jstsp_pinv_c32(g_ctx, R, C, 1, A.data(), P.data(), JSTSP_HOST);
+        if (rc) fail("jstsp_pinv_c32", rc);
+        plhs[0] = from_c32(P, C, R);
+    } else if (fn == "rate") {
+        // (S, Zbar, noise_var) -> log2(real(det(eye(Nr) + 1/Nr*Zbar*Zbar'/(noise_var + nmse))))   plot_rateVSframelength.m:81
+        const int R = (int)mxGetM(prhs[1]), C = (int)mxGetN(prhs[1]);
+        std::vector<jstsp_c32> S, Zb;
+        to_c32(prhs[1], S); to_c32(prhs[2], Zb);
+        double r = 0.0;
+        int rc = jstsp_rate_c32(g_ctx, R, C, 1, S.data(), Zb.data(), mxGetScalar(prhs[3]), &r, JSTSP_HOST);
+        if (rc) fail("jstsp_rate_c32", rc);
+        plhs[0] = mxCreateDoubleScalar(r);
     } else {
         mexErrMsgIdAndTxt("jstsp:args", "unknown function '%s'", name);
     }
