@@ -162,6 +162,39 @@ def gen_vamp():
     save("vamp", A=A, B=B, Gb=Gb, Y=Ym, Phi=Phi, y=y, sigma=1.0, L=12, x=x_lit, Zbar=Zbar)
 
 
+def gen_baselines2():
+    """Joint OMP (published simultaneous OMP: sparse-plex is un-vendored, parity unpinned), pinv / LS with an
+    ill-conditioned square pilot factor (plot_errorVSsnr.m:83), the TSSR / SVT-based recipes (:151-162) and the rate of
+    plot_rateVSframelength.m:81 on seeded inputs."""
+    rng = np.random.default_rng(16)
+    r = lambda *sh: rng.standard_normal(sh) + 1j * rng.standard_normal(sh)
+    N, Gr, Sx = 16, 16, 9
+    A = r(N, Gr) / np.sqrt(N)
+    Z0 = np.zeros((Gr, Sx), complex)
+    Z0[[2, 7, 11]] = 3 * r(3, Sx)
+    Y = A @ Z0 + 0.05 * r(N, Sx)
+    Zl2, sl2 = S.mmv_omp(A, Y, 5, "l2")
+    Zl1, sl1 = S.mmv_omp(A, Y, 5, "l1")
+    # LS with cond(B) = 1e3 (square B as the drivers' T_hbf == G2)
+    G2 = 8
+    U, _ = np.linalg.qr(r(G2, G2)); V, _ = np.linalg.qr(r(G2, G2))
+    B = (U * np.logspace(0, -3, G2)) @ V.conj().T
+    Yl = A @ r(Gr, G2) @ B
+    S_ls = np.linalg.pinv(A) @ Yl @ np.linalg.pinv(B)
+    # TSSR on a small completion problem
+    M = 20
+    Bw = r(G2, M) / np.sqrt(G2)
+    Om = (rng.random((N, M)) < 0.6).astype(float)
+    Zt = np.zeros((Gr, G2), complex); Zt[[1, 9]] = 2 * r(2, G2)
+    Yp = Om * (A @ Zt @ Bw + 0.02 * r(N, M))
+    S_tssr, Y_svt, S_svt = S.tssr(Yp, Om, A, Bw, 25, 0.05, 0.1, 4)
+    Zb = r(Gr, G2)
+    Sx2 = Zb + 0.2 * r(Gr, G2)
+    save("baselines2", A=A, Y=Y, K=5, Z_l2=Zl2, sup_l2=sl2, Z_l1=Zl1, sup_l1=sl1, B_ls=B, Y_ls=Yl, S_ls=S_ls,
+         B_t=Bw, Omega_t=Om, Y_t=Yp, tau_t=0.05, rho_t=0.1, Imax_t=25, K_t=4, S_tssr=S_tssr, Y_svt=Y_svt, S_svt=S_svt,
+         Zbar_r=Zb, S_r=Sx2, noise_var=0.3, rate=S.rate(Sx2, Zb, 0.3))
+
+
 def main():
     t0 = time.time()
     gen_proposed("proposed_small", PARAMS_SMALL, 5.0, 1, 30, literal=True, types=("approximate", "std"))
@@ -171,6 +204,7 @@ def main():
     gen_sparse_admm()
     gen_mc()
     gen_vamp()
+    gen_baselines2()
     if "--fast" not in sys.argv:
         # reference-native shape (N=32, M=140, Gr=32, G2=16): dense K1 is 4480^2, K2 4480x512
         gen_proposed("proposed_refnative", PARAMS_REF, 5.0, 3, 100, literal=True, types=("approximate",))

@@ -309,3 +309,17 @@ def test_mmv_omp_tssr_and_rate_match_the_oracle():
     np.testing.assert_allclose(out, ref, rtol=2e-5)
     wide = r(2, 40, 12)                                        # Nr > columns: the Gram of the smaller side
     np.testing.assert_allclose(J.rate(0.9 * wide, wide, 0.1), [O.rate(0.9 * wide[t], wide[t], 0.1) for t in range(2)], rtol=2e-5)
+
+
+def test_baselines2_fixture_through_the_c_abi():
+    """The committed fixture tests/golden/baselines2.npz through jstsp_mmv_omp_c32 / jstsp_ls_c32 / tssr / jstsp_rate_c32."""
+    import jstsp19_amd as J
+    g = load_golden("baselines2")
+    for norm in ("l2", "l1"):
+        Z, sup, cnt = J.mmv_omp(g["A"], g["Y"], int(g["K"]), norm=norm)
+        assert np.array_equal(sup[:cnt], g["sup_" + norm]) and rel_err(Z, g["Z_" + norm]) < 1e-4
+    assert rel_err(J.ls_estimate(g["Y_ls"], g["A"], g["B_ls"]), g["S_ls"]) < 2e-3          # cond(B) = 1e3: eps32 * cond
+    St, Ysvt, Ssvt = J.tssr(g["Y_t"], g["Omega_t"], g["A"], g["B_t"], int(g["Imax_t"]), float(g["tau_t"]), float(g["rho_t"]),
+                            int(g["K_t"]))
+    assert rel_err(Ysvt, g["Y_svt"]) < 2e-4 and rel_err(St, g["S_tssr"]) < 2e-3 and rel_err(Ssvt, g["S_svt"]) < 2e-3
+    assert abs(J.rate(g["S_r"], g["Zbar_r"], float(g["noise_var"])) - float(g["rate"])) < 2e-4

@@ -235,3 +235,19 @@ def test_mmv_omp_known_answers_and_rate_identity():
     e = O.spectral_norm(Zb - S) ** 2 / O.spectral_norm(Zb) ** 2
     lam = np.linalg.eigvalsh(Zb @ Zb.conj().T)
     assert abs(O.rate(S, Zb, 0.3) - np.sum(np.log2(1 + lam / (6 * (0.3 + e))))) < 1e-10
+
+
+def test_oracle_reproduces_the_baselines2_fixture():
+    """tests/golden/baselines2.npz (oracle.make_golden.gen_baselines2): joint OMP supports and coefficients, the LS estimate
+    with a cond-1e3 square pilot factor, TSSR / SVT-based estimates and the rate — pins the oracle against drift."""
+    from oracle import solvers as O
+    g = load_golden("baselines2")
+    for norm in ("l2", "l1"):
+        Z, sup = O.mmv_omp(g["A"], g["Y"], int(g["K"]), norm)
+        assert np.array_equal(sup, g["sup_" + norm]) and np.allclose(Z, g["Z_" + norm], atol=1e-12)
+    assert np.allclose(np.linalg.pinv(g["A"]) @ g["Y_ls"] @ np.linalg.pinv(g["B_ls"]), g["S_ls"], atol=1e-9)
+    St, Ysvt, Ssvt = O.tssr(g["Y_t"], g["Omega_t"], g["A"], g["B_t"], int(g["Imax_t"]), float(g["tau_t"]), float(g["rho_t"]),
+                            int(g["K_t"]))
+    assert np.allclose(St, g["S_tssr"], atol=1e-10) and np.allclose(Ysvt, g["Y_svt"], atol=1e-10)
+    assert np.allclose(Ssvt, g["S_svt"], atol=1e-10)
+    assert abs(O.rate(g["S_r"], g["Zbar_r"], float(g["noise_var"])) - float(g["rate"])) < 1e-12
