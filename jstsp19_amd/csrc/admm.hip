@@ -179,7 +179,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void step_v_kernel(int g, const float2 *Res, const float2 *RRes,
                                                     float2 *V, float2 *S, const int32_t *rank,
                                                     int cnt, const TrialParams *prm, double *ce3,
-                                                    int Imax, int it)
+                                                    int Imax, int it, float2 *RV)
 {
     __shared__ double sh[NT / 64];
     const int t = blockIdx.x;
@@ -207,6 +207,13 @@ __global__ __launch_bounds__(NT) void step_v_kernel(int g, const float2 *Res, co
         v.x += ax * r.x - ay * r.y;
         v.y += ax * r.y + ay * r.x;
         V[base + i] = v;
+        if (RV) {       // R v_new = R v + alpha R res: carried between the periodic recomputations of R v (proposed.hip)
+            const float2 rr = RRes[base + i];
+            float2 rv = RV[base + i];
+            rv.x += ax * rr.x - ay * rr.y;
+            rv.y += ax * rr.y + ay * rr.x;
+            RV[base + i] = rv;
+        }
         float2 s = make_float2(soft1(v.x, thr), soft1(v.y, thr));
         if (rank && rank[base + i] >= cnt) s = make_float2(0.f, 0.f);
         S[base + i] = s;
@@ -296,14 +303,14 @@ int launch_update_c(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, co
 }
 int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const float2 *RRes, float2 *V,
                   float2 *S, const int32_t *rank, int cnt, const TrialParams *prm, double *ce3,
-                  int Imax, int it)
+                  int Imax, int it, float2 *RV)
 {
     if (g >= 8192)
         hipLaunchKernelGGL(step_v_kernel<1024>, dim3(batch), dim3(1024), 0, ctx->stream, g, Res, RRes, V, S, rank,
-                           cnt, prm, ce3, Imax, it);
+                           cnt, prm, ce3, Imax, it, RV);
     else
         hipLaunchKernelGGL(step_v_kernel<256>, dim3(batch), dim3(256), 0, ctx->stream, g, Res, RRes, V, S, rank,
-                           cnt, prm, ce3, Imax, it);
+                           cnt, prm, ce3, Imax, it, RV);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -235,7 +235,7 @@ int launch_update_c(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, co
                     float2 *V2, float2 *C, const TrialParams *prm);
 int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const float2 *RRes,
                   float2 *V, float2 *S, const int32_t *rank, int cnt, const TrialParams *prm,
-                  double *ce3, int Imax, int it);
+                  double *ce3, int Imax, int it, float2 *RV = nullptr);    // RV != nullptr: RV += alpha * RRes as well
 int launch_soft(jstsp_ctx *ctx, int g, int batch, const float2 *V, float2 *S, const int32_t *rank,
                 int cnt, const TrialParams *prm);
 int launch_inv_d(jstsp_ctx *ctx, long long nm, int batch, const float *Omega, float scale2rho,

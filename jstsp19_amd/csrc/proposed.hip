@@ -289,6 +289,11 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     // 2.66 to 4.26 ms), which muddles per-kernel accounting — off until the side chains are
     // lighter than the MFMA-bound Grams they currently contain.
     // (read at every call, not cached in statics: tests switch them inside one process)
+    // R v (`R*v` of :47) is recomputed from v every 4th iteration and carried by R v += alpha R res (the `R*res` of :48
+    // is computed anyway) in between.  Measured at configs[1], 6 trials against the float64 oracle, refresh period
+    // 1 / 4 / 8 / never: 514 / 529 / 533 / 536 channel-estimates/s, max |dNMSE| 2.4e-7 / 2.7e-7 / 2.7e-7 / 4.4e-7,
+    // max |dS|/max|S| 2.5e-6 / 2.8e-6 / 3.2e-6 / 4.6e-6.  JSTSP_RV_REFRESH=1 recomputes every iteration.
+    const int rv_refresh = std::max(1, getenv("JSTSP_RV_REFRESH") ? atoi(getenv("JSTSP_RV_REFRESH")) : 4);
     const bool fuse = getenv("JSTSP_FUSE") ? atoi(getenv("JSTSP_FUSE")) != 0 : true;
     const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0 : false;
     uint32_t *const kmax0 = w.kmax;
@@ -404,14 +409,16 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             return launch_hgemm(ctx, hg, nullptr);
         };
         if (approx) {
-            JSTSP_TRY(apply_R(w.V, w.RV));
+            // R v: recomputed from v every `rv_refresh` iterations, carried by R v += alpha R res in between (both are
+            // `R*v` of :47; the recurrence alone drifts in fp32)
+            if (it % rv_refresh == 0) JSTSP_TRY(apply_R(w.V, w.RV));
             JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
                            -1.f));
             //    R*res for alpha = res'*res / (res'*R*res)                                    (:48)
             JSTSP_TRY(apply_R(w.Res, w.RRes));
             //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
-                                    Imax, it));
+                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr));
         } else {
             //    v = U\(L\k) = pinv(A) K pinv(B)   [ = G_A^-1 (A^H Tc) G_B^-1 on the Gram route: GA / GB hold the inverses ]  (:53)
             float2 *left = PB ? w.V : w.P1;        // result of the A side; the B side (if any) finishes into V
