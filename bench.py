@@ -244,10 +244,13 @@ def main():
             "mean_nmse": mean_nmse, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         line.update(extra)
-        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # after the process group is gone: RCCL may print its own shutdown lines, the JSON line must be the last one
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
