@@ -248,7 +248,13 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # after the process group is gone: RCCL may print its own shutdown lines, the JSON line must be the last one
+        # The JSON line must be the last line of stdout: RCCL writes its banner ("Hostname", "Librccl path") through C
+        # stdio, which is fully buffered on a pipe and would otherwise be flushed at exit, after this line.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
 
