@@ -14,9 +14,10 @@ from __future__ import annotations
 
 import torch
 
-from .system_model import SweepParams, build_inputs, build_trials, draw_trials
+from .system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, build_trials, draw_trials,
+                           draw_trials_training)
 
-__all__ = ["partition", "run_sweep", "run_points", "sweep_points"]
+__all__ = ["partition", "run_sweep", "run_points", "sweep_points", "run_approx_sweep"]
 
 
 def partition(n_items, world, rank):
@@ -161,3 +162,56 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
 def run_sweep(base: SweepParams, snr_db_list, n_trials, **kw):
     """The SNR sweep of plot_errorVSsnr.m:48-180 (see ``run_points``)."""
     return run_points(sweep_points(base, "snr_db", [float(s) for s in snr_db_list]), n_trials, **kw)
+
+
+def _hip_alg12(inp, Imax):
+    """plot_errorVSsnr_approx.m:60-72 on the HIP path: Alg.1 ('std') and Alg.2 ('approximate'), each scored
+    through its completed measurement, ``S = pinv(A)*Y*pinv(B)``."""
+    from . import solvers as J
+    zb = J.colmajor(inp["Zbar"].to(torch.complex64))
+    out = []
+    for kind in ("std", "approximate"):
+        _, Y, _ = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax, inp["tau_X"].numpy(),
+                                       inp["tau_S"].numpy(), inp["rho"].numpy(), kind, want_ce=False)   # :60,:67
+        out.append(J.nmse_spectral(J.ls_estimate(Y, inp["A"], inp["B"]), zb))                            # :61-65
+    return out
+
+
+def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, batch=64, seed=20190913, device=None,
+                     solve_fn=None, dist=None):
+    """The Alg.1-vs-Alg.2 sweep of plot_errorVSsnr_approx.m:34-85: for each SNR and each Imax, ``n_trials`` fresh
+    realisations of wideband_hybBF_comm_system_training, both solver variants, capped NMSE of
+    ``pinv(A)*Y*pinv(B)``, mean then ``min(., 1)`` (:76-77).
+
+    Returns a float64 tensor (len(Imax_list), len(snr_db_list), 2) — ``[..., 0]`` is mean_error_proposed,
+    ``[..., 1]`` mean_error_proposed_approx — identical on every rank.  ``solve_fn(inputs, Imax) -> (e_std, e_approx)``
+    defaults to the HIP path; the (sweep point, trial) pairs are sharded over ranks as in ``run_points``.
+    """
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if solve_fn is None:
+        solve_fn = _hip_alg12
+    pts = [(si, ii) for si in range(len(snr_db_list)) for ii in range(len(Imax_list))]    # loop order of :34-38
+    lo, hi = partition(len(pts) * n_trials, world, rank)
+    acc = torch.zeros((len(pts), 3), dtype=torch.float64)
+    item = lo
+    while item < hi:
+        pt = item // n_trials
+        t0 = item % n_trials
+        t1 = min(n_trials, t0 + batch, t0 + (hi - item))
+        si, ii = pts[pt]
+        p = TrainingParams(base.Nt, base.Nr, base.L, base.T, base.ratio, base.clusters, base.rays, float(snr_db_list[si]))
+        draws = draw_trials_training(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
+        e1, e2 = solve_fn(build_inputs_training(p, draws), int(Imax_list[ii]))
+        acc[pt, 0] += float(torch.as_tensor(e1).double().sum())
+        acc[pt, 1] += float(torch.as_tensor(e2).double().sum())
+        acc[pt, 2] += t1 - t0
+        item += t1 - t0
+    if dist is not None:
+        buf = acc.to(device) if dist.get_backend() == "nccl" else acc
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        acc = buf.cpu()
+    mean = torch.clamp(acc[:, :2] / acc[:, 2:3], max=1.0)                                  # :76-77
+    return mean.reshape(len(snr_db_list), len(Imax_list), 2).transpose(0, 1).contiguous()

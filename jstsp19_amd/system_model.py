@@ -17,7 +17,8 @@ import math
 
 import torch
 
-__all__ = ["SweepParams", "draw_trials", "build_inputs", "build_trials", "zc_beamformer", "dft_dictionary"]
+__all__ = ["SweepParams", "draw_trials", "build_inputs", "build_trials", "zc_beamformer", "dft_dictionary",
+           "TrainingParams", "draw_trials_training", "build_inputs_training"]
 
 
 class SweepParams:
@@ -115,6 +116,39 @@ def _laplacian(u):
     return beta * (math.exp(-math.sqrt(2.0) / 50.0 * math.pi) - torch.cosh(u))
 
 
+def _channel(p, draws):
+    """wideband_mmwave_channel.m:1-40 for a batch: H (T,Nr,Nt,L), Zbar (T,Gr,L*Gt), Dr, Dt (complex128)."""
+    dev = draws["gains"].device
+    T = draws["gains"].shape[0]
+    Np = p.clusters * p.rays
+    c128 = torch.complex128
+    Dr = dft_dictionary(p.Nr, p.Gr, dev)
+    Dt = dft_dictionary(p.Nt, p.Gt, dev)
+    # taps reuse tap 1's steering vectors (:24), cluster c's rays weighted (C - c) (:29)
+    Ar1 = _steer(_laplacian(draws["u_r"][:, 0, :]), p.Nr).transpose(1, 2)      # (T, Nr, Np)
+    At1 = _steer(_laplacian(draws["u_t"][:, 0, :]), p.Nt).transpose(1, 2)      # (T, Nt, Np)
+    w = (p.clusters - torch.arange(Np, device=dev) // p.rays).to(torch.float64)   # (Np,)
+    coef = draws["gains"] * w / math.sqrt(Np)                                   # (T, L, Np)   :33
+    # H[t,:,:,l] = Ar1 diag(coef[t,l]) At1^H
+    H = torch.einsum("trp,tlp,tsp->trsl", Ar1, coef.to(c128), At1.conj())       # (T, Nr, Nt, L)
+    Z = torch.einsum("rg,trsl,sh->tghl", Dr.conj(), H, Dt)                      # Dr' H_l Dt   :35
+    Zbar = Z.permute(0, 1, 3, 2).reshape(T, p.Gr, p.L * p.Gt)                   # [Z_1 ... Z_L] :38  (col = l*Gt + h)
+    return H, Zbar, Dr, Dt
+
+
+def _toeplitz_rows(sym, L):
+    """Rows 1..L of the Hermitian ``toeplitz(s_k)`` of every pilot sequence: (T,Nt,Tp) -> (T,Nt,Tp,L)
+    with ``[..., k, :, l] = Psi_bar(k,:,l)`` (proposed_hbf.m:15-18)."""
+    Tp = sym.shape[-1]
+    j = torch.arange(Tp, device=sym.device)
+    rows = []
+    for l in range(L):
+        d = j - l
+        r = sym[:, :, d.abs()]
+        rows.append(torch.where((d >= 0)[None, None, :], r, r.conj()))
+    return torch.stack(rows, dim=-1)
+
+
 def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=False):
     """plot_errorVSsnr.m:57-136 for a batch of trials.
 
@@ -127,31 +161,14 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=Fals
     from .solvers import colmajor
     dev = draws["gains"].device
     T = draws["gains"].shape[0]
-    Np = p.clusters * p.rays
     c128 = torch.complex128
-    Dr = dft_dictionary(p.Nr, p.Gr, dev)
-    Dt = dft_dictionary(p.Nt, p.Gt, dev)
-    # --- channel: taps reuse tap 1's steering vectors (:24), cluster c's rays weighted (C - c) (:29)
-    Ar1 = _steer(_laplacian(draws["u_r"][:, 0, :]), p.Nr).transpose(1, 2)      # (T, Nr, Np)
-    At1 = _steer(_laplacian(draws["u_t"][:, 0, :]), p.Nt).transpose(1, 2)      # (T, Nt, Np)
-    w = (p.clusters - torch.arange(Np, device=dev) // p.rays).to(torch.float64)   # (Np,)
-    coef = draws["gains"] * w / math.sqrt(Np)                                   # (T, L, Np)   :33
-    # H[t,:,:,l] = Ar1 diag(coef[t,l]) At1^H
-    H = torch.einsum("trp,tlp,tsp->trsl", Ar1, coef.to(c128), At1.conj())       # (T, Nr, Nt, L)
-    Z = torch.einsum("rg,trsl,sh->tghl", Dr.conj(), H, Dt)                      # Dr' H_l Dt   :35
-    Zbar = Z.permute(0, 1, 3, 2).reshape(T, p.Gr, p.L * p.Gt)                   # [Z_1 ... Z_L] :38  (col = l*Gt + h)
+    H, Zbar, Dr, Dt = _channel(p, draws)
     # --- pilots: Psi_bar(k,:,l) = row l of toeplitz(s_k) (proposed_hbf.m:17), Hermitian Toeplitz
     s = 1.0 / math.sqrt(2.0)
     alphabet = torch.tensor([complex(s, s), complex(-s, s), complex(s, -s), complex(-s, -s)], device=dev, dtype=c128)
     sym = alphabet[draws["qam_idx"]]                                            # (T, Nt, T_prop)
     Tp = p.T_prop
-    j = torch.arange(Tp, device=dev)
-    rows = []
-    for l in range(p.L):
-        d = j - l
-        r = sym[:, :, d.abs()]
-        rows.append(torch.where((d >= 0)[None, None, :], r, r.conj()))
-    Psi_bar = torch.stack(rows, dim=-1)                                         # (T, Nt, T_prop, L)
+    Psi_bar = _toeplitz_rows(sym, p.L)                                          # (T, Nt, T_prop, L)
     # --- received signal, sampling mask, measurement (proposed_hbf.m:13-42)
     Y = torch.einsum("trsl,tsjl->trj", H, Psi_bar)                              # sum_l H_l Psi_bar_l   :19
     R = Y + math.sqrt(p.noise_var / 2.0) * draws["noise"]                       # :22, plot_errorVSsnr.m:60
@@ -185,6 +202,81 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=Fals
     return dict(**extra, subY=colmajor(subY.to(out_dtype)), Omega=colmajor(Omega.to(torch.float32)),
                 A=colmajor(A.to(out_dtype)), B=colmajor(B.to(out_dtype)), Zbar=Zbar, H=H,
                 tau_Y=tau_Y.cpu(), tau_Z=tau_Z.cpu(), rho=rho.cpu(), indx_S=indx_S)
+
+
+class TrainingParams:
+    """Parameters of the Alg.1-vs-Alg.2 driver — names follow plot_errorVSsnr_approx.m:8-20
+    (``Gr = Nr``, ``Gt = Nt``; the frame is T columns, not T*Nt)."""
+
+    def __init__(self, Nt=4, Nr=32, L=4, T=70, ratio=0.75, clusters=2, rays=3, snr_db=5.0):
+        self.Nt, self.Nr, self.L, self.T, self.ratio = Nt, Nr, L, T, float(ratio)
+        self.Gr, self.Gt = Nr, Nt
+        self.clusters, self.rays = clusters, rays
+        self.snr_db = float(snr_db)
+
+    @property
+    def Lr(self):                           # wideband_hybBF_comm_system_training.m:5 (MATLAB round)
+        return int(math.floor(self.ratio * self.Nr + 0.5))
+
+    @property
+    def noise_var(self):                    # plot_errorVSsnr_approx.m:35
+        return 10.0 ** (-self.snr_db / 10.0)
+
+    @property
+    def solver_shape(self):
+        return self.Nr, self.T, self.Gr, self.L * self.Gt
+
+
+def draw_trials_training(p: TrainingParams, trial_ids, seed=20190913, sweep_idx=0, device="cuda"):
+    """Random numbers of plot_errorVSsnr_approx.m:45-46 for the given global trial indices:
+    gains, u_r, u_t as ``draw_trials``; noise (T,Nr,T) and pilots (T,Nt,T) complex128 with unit-variance
+    parts; omega_rows (T,T,Lr) int64."""
+    Np = p.clusters * p.rays
+    out = {k: [] for k in ("gains", "u_r", "u_t", "noise", "pilots", "omega_rows")}
+    g = torch.Generator(device=device)
+    for tid in trial_ids:
+        g.manual_seed(_trial_seed(seed, sweep_idx, int(tid)))
+        gr = torch.randn((2, p.L, Np), generator=g, device=device, dtype=torch.float64)
+        out["gains"].append(torch.complex(gr[0], gr[1]) / math.sqrt(2.0))        # wideband_mmwave_channel.m:19
+        out["u_r"].append(torch.rand((p.L, Np), generator=g, device=device, dtype=torch.float64))
+        out["u_t"].append(torch.rand((p.L, Np), generator=g, device=device, dtype=torch.float64))
+        nz = torch.randn((2, p.Nr, p.T), generator=g, device=device, dtype=torch.float64)
+        out["noise"].append(torch.complex(nz[0], nz[1]))                         # ...training.m:16
+        pl = torch.randn((2, p.Nt, p.T), generator=g, device=device, dtype=torch.float64)
+        out["pilots"].append(torch.complex(pl[0], pl[1]))                        # :20
+        keys = torch.rand((p.T, p.Nr), generator=g, device=device)               # :50-51 randperm(Nr)(1:Lr)
+        out["omega_rows"].append(keys.argsort(dim=1)[:, :p.Lr])
+    return {k: torch.stack(v) for k, v in out.items()}
+
+
+def build_inputs_training(p: TrainingParams, draws, out_dtype=torch.complex64):
+    """wideband_hybBF_comm_system_training.m:1-58 + plot_errorVSsnr_approx.m:45-58 for a batch of trials.
+
+    Same layout as ``build_inputs``: subY (T,N,M), Omega float32, A (N,Gr) shared (unitary DFT combiner x DFT
+    dictionary), B (T,L*Nt,M), Zbar/H complex128, tau_X, tau_S, rho (T,) float64 CPU tensors.
+    """
+    from .solvers import colmajor
+    dev = draws["gains"].device
+    T = draws["gains"].shape[0]
+    H, Zbar, Dr, Dt = _channel(p, draws)                                        # plot_errorVSsnr_approx.m:45
+    Psi_bar = _toeplitz_rows(draws["pilots"] / math.sqrt(2.0), p.L)             # ...training.m:19-22,:28
+    n = torch.arange(p.Nr, device=dev, dtype=torch.float64)
+    ph = -2.0 * math.pi * n[:, None] * n[None, :] / p.Nr
+    W = torch.complex(torch.cos(ph), torch.sin(ph)) / math.sqrt(p.Nr)           # :10  fft(eye(Nr))/sqrt(Nr)
+    R = torch.einsum("trsl,tsjl->trj", H, Psi_bar) + math.sqrt(p.noise_var / 2.0) * draws["noise"]   # :16,:30,:33
+    Omega = torch.zeros((T, p.Nr, p.T), device=dev, dtype=torch.float64)
+    Omega.scatter_(1, draws["omega_rows"].transpose(1, 2), 1.0)                 # :48-53
+    subY = Omega * torch.einsum("re,trj->tej", W.conj(), R)                     # :54
+    fro2 = (subY.abs() ** 2).sum(dim=(1, 2))
+    tau_X = 1.0 / fro2                                                          # plot_errorVSsnr_approx.m:50
+    tau_S = tau_X / 2.0                                                         # :51
+    sv = torch.linalg.svdvals(subY)
+    rho = torch.sqrt(sv[:, 5] ** 2 * (tau_X + tau_S) / 2.0)                     # :52-53  eigs() -> sigma_6^2
+    A = W.conj().transpose(0, 1) @ Dr                                           # :54
+    B = torch.einsum("sh,tsjl->tlhj", Dt.conj(), Psi_bar).reshape(T, p.L * p.Nt, p.T)   # :55-58
+    return dict(subY=colmajor(subY.to(out_dtype)), Omega=colmajor(Omega.to(torch.float32)),
+                A=colmajor(A.to(out_dtype)), B=colmajor(B.to(out_dtype)), Zbar=Zbar, H=H,
+                tau_X=tau_X.cpu(), tau_S=tau_S.cpu(), rho=rho.cpu())
 
 
 def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, device=None, with_hbf=False,

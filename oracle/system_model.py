@@ -14,7 +14,8 @@ import numpy as np
 __all__ = [
     "matlab_round", "toeplitz_matlab", "qam4_alphabet", "create_beamformer",
     "wideband_mmwave_channel", "proposed_hbf", "hbf", "training_inputs_errorVSsnr",
-    "rho_from_eigs",
+    "rho_from_eigs", "wideband_hybBF_comm_system_training", "training_inputs_errorVSsnr_approx",
+    "draw_trial_approx",
 ]
 
 
@@ -245,3 +246,74 @@ def draw_trial(rng, params):
     omega_rows = np.stack([rng.permutation(p["Mr_e"])[:p["Mr"]] for _ in range(T_prop)])
     return dict(gains=gains, u_r=u_r, u_t=u_t, noise=noise, qam_idx=qam_idx,
                 omega_rows=omega_rows)
+
+
+def wideband_hybBF_comm_system_training(H, T, snr, subSamplingRatio, noise, pilots, omega_rows):
+    """basic_system_functions/wideband_hybBF_comm_system_training.m:1-58 — the builder of the
+    Alg.1-vs-Alg.2 driver (plot_errorVSsnr_approx.m:46): Gaussian Hermitian-Toeplitz pilots, the
+    unitary DFT combiner over all Nr outputs, ``Lr = round(ratio*Nr)`` of them kept per column.
+
+    Explicit draws: ``noise`` (Nr x T, randn + 1j*randn), ``pilots`` (Nt x T, randn + 1j*randn —
+    scaled by 1/sqrt(2) here as :20 does), ``omega_rows`` (T x Lr ints, 0-based: randperm(Nr)(1:Lr)).
+    Returns (Y_proposed_hbf, Y_conventional_hbf, W_tilde, Psi_bar, Omega, Lr).
+    """
+    Nr, Nt, L = H.shape                                 # :4
+    Lr = int(matlab_round(subSamplingRatio * Nr))       # :5
+    n = np.arange(Nr)
+    W_tilde = np.exp(-2j * np.pi * np.outer(n, n) / Nr) / np.sqrt(Nr)   # :10  fft(eye(Nr))/sqrt(Nr)
+    Nn = np.sqrt(snr / 2) * noise                       # :16
+    Psi_bar = np.zeros((Nt, T, L), complex)             # :9
+    for k in range(Nt):                                 # :19-22
+        s = pilots[k] / np.sqrt(2)                      # :20
+        Psi_bar[k] = toeplitz_rows(s, L).T              # :21,:28  Psi_bar(k,:,l) = Psi_i(l,:,k)
+    R = np.zeros((Nr, T), complex)                      # :25
+    for l in range(L):
+        R = R + H[:, :, l] @ Psi_bar[:, :, l]           # :30
+    R = R + Nn                                          # :33
+    Omega = np.zeros((Nr, T))                           # :48
+    for t in range(T):
+        Omega[omega_rows[t, :Lr], t] = 1                # :49-53
+    Y_conv = W_tilde.conj().T @ R                       # :57
+    return Omega * Y_conv, Y_conv, W_tilde, Psi_bar, Omega, Lr   # :54
+
+
+def training_inputs_errorVSsnr_approx(params, draws):
+    """plot_errorVSsnr_approx.m:45-60 for one trial.
+
+    ``params``: dict(Nt, Nr, L, T, clusters, rays, ratio, noise_var) (Gr = Nr, Gt = Nt, :9-10).
+    ``draws``: dict(gains, u_r, u_t, noise (Nr x T), pilots (Nt x T), omega_rows (T x Lr)).
+    Returns dict(subY, Omega, A, B, tau_X, tau_S, rho, Zbar, H, Lr).
+    """
+    p = params
+    Nt, Nr, L, T = p["Nt"], p["Nr"], p["L"], p["T"]
+    H, Zbar, _, _, Dr, Dt = wideband_mmwave_channel(
+        L, Nr, Nt, p["clusters"], p["rays"], Nr, Nt,
+        draws["gains"], draws["u_r"], draws["u_t"])     # :45
+    Y_prop, _, W_tilde, Psi_bar, Omega, Lr = wideband_hybBF_comm_system_training(
+        H, T, p["noise_var"], p["ratio"], draws["noise"], draws["pilots"], draws["omega_rows"])   # :46
+    tau_X = 1 / np.linalg.norm(Y_prop, "fro") ** 2      # :50
+    tau_S = tau_X / 2                                   # :51
+    sv = np.linalg.svd(Y_prop, compute_uv=False)
+    ev = np.concatenate([sv ** 2, np.zeros(max(0, T - sv.size))])
+    rho = float(np.sqrt(ev[min(5, T - 1)] * (tau_X + tau_S) / 2))   # :52-53  eigs() -> 6 largest
+    A = W_tilde.conj().T @ Dr                           # :54
+    B = np.zeros((L * Nt, T), complex)                  # :55
+    for l in range(L):
+        B[l * Nt:(l + 1) * Nt, :] = Dt.conj().T @ Psi_bar[:, :, l]   # :57
+    return dict(subY=Y_prop, Omega=Omega, A=A, B=B, tau_X=float(tau_X), tau_S=float(tau_S), rho=rho,
+                Zbar=Zbar, H=H, Lr=Lr)
+
+
+def draw_trial_approx(rng, params):
+    """Draw one trial's random numbers of plot_errorVSsnr_approx.m:45-46 (numpy Generator)."""
+    p = params
+    Np = p["clusters"] * p["rays"]
+    L, Nr, Nt, T = p["L"], p["Nr"], p["Nt"], p["T"]
+    Lr = int(matlab_round(p["ratio"] * Nr))
+    gains = (rng.standard_normal((L, Np)) + 1j * rng.standard_normal((L, Np))) / np.sqrt(2)
+    u_r = rng.random((L, Np))
+    u_t = rng.random((L, Np))
+    noise = rng.standard_normal((Nr, T)) + 1j * rng.standard_normal((Nr, T))
+    pilots = rng.standard_normal((Nt, T)) + 1j * rng.standard_normal((Nt, T))
+    omega_rows = np.stack([rng.permutation(Nr)[:Lr] for _ in range(T)])
+    return dict(gains=gains, u_r=u_r, u_t=u_t, noise=noise, pilots=pilots, omega_rows=omega_rows)

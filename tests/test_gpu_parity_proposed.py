@@ -192,6 +192,23 @@ def test_sweep_runner_on_hip_matches_oracle_per_point():
     assert rt.shape == (1, 2) and np.all(rt > 0) and rt[0, 1] >= rt[0, 0] - 1e-3
 
 
+def test_alg1_vs_alg2_sweep_on_hip_matches_oracle_per_point():
+    """montecarlo.run_approx_sweep (plot_errorVSsnr_approx.m:34-85: wideband_hybBF_comm_system_training inputs,
+    'std' and 'approximate', S = pinv(A)*Y*pinv(B)) with the HIP solvers vs the oracle on identical trials,
+    at the driver's own sizes (Nt 4, Nr 32, L 4, T 70, ratio 0.75)."""
+    import torch
+    from jstsp19_amd.montecarlo import run_approx_sweep
+    from jstsp19_amd.system_model import TrainingParams
+    from tests.test_system_model import _oracle_alg12
+    base = TrainingParams()
+    dev = torch.device("cuda:0")
+    hip = run_approx_sweep(base, [-15, 0, 15], [10, 50], 4, batch=4, device=dev).numpy()
+    ref = run_approx_sweep(base, [-15, 0, 15], [10, 50], 4, batch=4, device=dev, solve_fn=_oracle_alg12).numpy()
+    assert hip.shape == (2, 3, 2) and np.all(hip > 0) and np.all(hip <= 1)
+    np.testing.assert_allclose(hip, ref, rtol=2e-4, atol=1e-6)
+    assert np.all(hip[:, 2, :] < hip[:, 0, :])                              # the NMSE falls with the SNR
+
+
 def test_lanczos_lambda_max_agrees_with_householder_sturm():
     """convergence_error(:,1:2) takes lambda_max from the one-wave Lanczos kernel (JSTSP_LANCZOS=0 switches back to the
     Householder + Sturm kernel): both must give the same ratios far inside the 2e-3 parity tolerance — Gram orders

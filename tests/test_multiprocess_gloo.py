@@ -53,6 +53,23 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_approx(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from jstsp19_amd.montecarlo import run_approx_sweep
+    from jstsp19_amd.system_model import TrainingParams
+    from tests.test_system_model import _oracle_alg12
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    out = run_approx_sweep(TrainingParams(Nt=2, Nr=8, L=2, T=12), [0.0, 10.0], [5, 10], 3, batch=2,
+                           device=torch.device("cpu"), solve_fn=_oracle_alg12, dist=dist)
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_partition_covers_everything_once():
     from jstsp19_amd.montecarlo import partition
     for n in (0, 1, 7, 15, 5000):
@@ -84,3 +101,25 @@ def test_two_rank_gloo_sweep_equals_single_process():
     assert np.array_equal(res[0], res[1])                       # every rank holds the reduced result
     np.testing.assert_allclose(res[0], single, rtol=1e-12)      # independent of the number of ranks
     assert single.shape == (3, 2) and np.all(single > 0) and np.all(single <= 1)
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_alg1_vs_alg2_sweep_equals_single_process():
+    from jstsp19_amd.montecarlo import run_approx_sweep
+    from jstsp19_amd.system_model import TrainingParams
+    from tests.test_system_model import _oracle_alg12
+    single = run_approx_sweep(TrainingParams(Nt=2, Nr=8, L=2, T=12), [0.0, 10.0], [5, 10], 3, batch=2,
+                              device=torch.device("cpu"), solve_fn=_oracle_alg12).numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_approx, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = dict(q.get(timeout=500) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(res[0], res[1])
+    np.testing.assert_allclose(res[0], single, rtol=1e-12)
+    assert single.shape == (2, 2, 2)

@@ -3,7 +3,8 @@ plot_errorVSsnr.m:57-136, on the same random draws.  Runs on CPU."""
 import numpy as np
 import torch
 
-from jstsp19_amd.system_model import SweepParams, build_inputs, draw_trials
+from jstsp19_amd.system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, draw_trials,
+                                       draw_trials_training)
 from oracle import system_model as osm
 
 
@@ -86,3 +87,75 @@ def test_sweep_points_of_the_sibling_drivers():
     pts = sweep_points(base, "Nt", [2, 8])
     assert [q.Gt for q in pts] == [2, 8]
     assert [q.snr_db for q in sweep_points(base, "snr_db", [-15, 0, 15])] == [-15.0, 0.0, 15.0]
+
+
+def _oracle_alg12(inp, Imax):
+    """plot_errorVSsnr_approx.m:60-72 with the oracle as solver (the runner's hook)."""
+    from oracle import solvers as O
+    A = inp["A"].cpu().numpy().astype(complex)
+    PA = np.linalg.pinv(A)
+    out = ([], [])
+    for t in range(inp["subY"].shape[0]):
+        B = inp["B"][t].cpu().numpy().astype(complex)
+        PB = np.linalg.pinv(B)
+        zb = inp["Zbar"][t].cpu().numpy()
+        for col, kind in enumerate(("std", "approximate")):
+            _, Y, _ = O.proposed_algorithm(inp["subY"][t].cpu().numpy().astype(complex),
+                                           inp["Omega"][t].cpu().numpy().astype(float), A, B, Imax, float(inp["tau_X"][t]),
+                                           float(inp["tau_S"][t]), float(inp["rho"][t]), kind, want_ce=False)
+            out[col].append(O.nmse_capped(PA @ Y @ PB, zb))
+    return torch.tensor(out[0]), torch.tensor(out[1])
+
+
+def test_training_builder_matches_oracle_per_trial():
+    """wideband_hybBF_comm_system_training.m + plot_errorVSsnr_approx.m:45-58: batched torch builder vs the
+    oracle's per-trial restatement on the same draws, at the driver's own sizes."""
+    p = TrainingParams(Nt=4, Nr=32, L=4, T=70, ratio=0.75, snr_db=-5.0)
+    assert p.Lr == 24 and p.solver_shape == (32, 70, 32, 16)
+    draws = draw_trials_training(p, [0, 3], seed=5, device="cpu")
+    out = build_inputs_training(p, draws, out_dtype=torch.complex128)
+    op = dict(Nt=p.Nt, Nr=p.Nr, L=p.L, T=p.T, clusters=p.clusters, rays=p.rays, ratio=p.ratio, noise_var=p.noise_var)
+    for t in range(2):
+        ref = osm.training_inputs_errorVSsnr_approx(op, {k: v[t].numpy() for k, v in draws.items()})
+        assert ref["Lr"] == 24
+        np.testing.assert_allclose(out["H"][t].numpy(), ref["H"], atol=1e-12)
+        np.testing.assert_allclose(out["Zbar"][t].numpy(), ref["Zbar"], atol=1e-11)
+        np.testing.assert_allclose(out["subY"][t].numpy(), ref["subY"], atol=1e-11)
+        np.testing.assert_array_equal(out["Omega"][t].numpy(), ref["Omega"])
+        np.testing.assert_allclose(out["A"].numpy(), ref["A"], atol=1e-12)
+        np.testing.assert_allclose(out["B"][t].numpy(), ref["B"], atol=1e-12)
+        np.testing.assert_allclose(float(out["tau_X"][t]), ref["tau_X"], rtol=1e-12)
+        np.testing.assert_allclose(float(out["tau_S"][t]), ref["tau_X"] / 2, rtol=1e-12)
+        np.testing.assert_allclose(float(out["rho"][t]), ref["rho"], rtol=1e-10)
+        assert np.all(ref["Omega"].sum(axis=0) == 24)
+    # the combiner is unitary and A = W' Dr with Dr the same DFT: A is the identity (Gr = Nr)
+    np.testing.assert_allclose(out["A"].numpy(), np.eye(32), atol=1e-12)
+    assert TrainingParams(Nr=10, ratio=0.25).Lr == 3          # MATLAB round(2.5) = 3, not numpy's 2
+
+
+def test_training_builder_is_the_reference_alternative_formulation():
+    """The commented check of wideband_hybBF_comm_system_training.m:35-44: R - N equals
+    sum_k [H(:,k,1) ... H(:,k,L)] * Psi_i(1:L,:,k)."""
+    rng = np.random.default_rng(3)
+    p = dict(Nt=3, Nr=8, L=3, T=12, clusters=2, rays=2, ratio=0.5, noise_var=0.0)
+    d = osm.draw_trial_approx(rng, p)
+    inp = osm.training_inputs_errorVSsnr_approx(p, d)
+    H = inp["H"]
+    Y = np.zeros((8, 12), complex)
+    for k in range(3):
+        Y += H[:, k, :] @ osm.toeplitz_rows(d["pilots"][k] / np.sqrt(2), 3)
+    n = np.arange(8)
+    W = np.exp(-2j * np.pi * np.outer(n, n) / 8) / np.sqrt(8)
+    np.testing.assert_allclose(inp["subY"], inp["Omega"] * (W.conj().T @ Y), atol=1e-12)
+
+
+def test_alg1_vs_alg2_sweep_runner_with_oracle_solver():
+    """run_approx_sweep (plot_errorVSsnr_approx.m:34-85) on CPU with the oracle as the solver hook: shape, caps,
+    the NMSE falls with the SNR, and both variants end close to each other (the figure's point)."""
+    from jstsp19_amd.montecarlo import run_approx_sweep
+    base = TrainingParams(Nt=2, Nr=8, L=2, T=20, ratio=0.75)
+    out = run_approx_sweep(base, [-10.0, 10.0], [5, 20], 3, batch=2, device=torch.device("cpu"),
+                           solve_fn=_oracle_alg12).numpy()
+    assert out.shape == (2, 2, 2) and np.all(out > 0) and np.all(out <= 1)
+    assert np.all(out[:, 1, :] < out[:, 0, :])
+    assert np.all(np.abs(out[1, :, 0] - out[1, :, 1]) < 0.5 * out[1, :, 0] + 1e-3)
