@@ -224,14 +224,23 @@ typedef struct jstsp_model {
     int T_hbf;              /* training length of the conventional HBF baseline (0 = not wanted) :22         */
     int shared_pilots;      /* 0: new pilots every trial (plot_errorVSsnr.m:63-67); 1: one pilot set per sweep point */
     double noise_var;       /* 10^(-snr_db/10)                                       :49                     */
+    /* what the sibling drivers change in the construction (all-zero = plot_errorVSsnr.m):                   */
+    int beamformer;         /* JSTSP_BF_ZC: createBeamformer(Nr,'ZC') :124; JSTSP_BF_DFT: 'fft' (plot_errorVSframelength.m:123,
+                               plot_errorVSnt.m:123, plot_rateVSframelength.m:116) and 'ps' (plot_errorVSadmmiters.m:47,
+                               plot_errorVSzy.m:53) - createBeamformer.m:5 and :12-13 are the same unitary DFT matrix */
+    int rho_rule;           /* JSTSP_RHO_MIN6: min(eigs(Y'*Y)) :129-130; JSTSP_RHO_MAX: max(eigs(Y'*Y))
+                               (plot_errorVSdelays.m:128, plot_errorVSnrf.m:128, plot_errorVSnt.m:129, plot_errorVSpaths.m:128) */
+    double rho_scale;       /* factor on rho (0 = 1; plot_errorVSzy.m:65 halves it)                                   */
 } jstsp_model;
+enum { JSTSP_BF_ZC = 0, JSTSP_BF_DFT = 1 };
+enum { JSTSP_RHO_MIN6 = 0, JSTSP_RHO_MAX = 1 };
 
 /* Output arrays of jstsp_build_trials_c32 (NULL = not wanted); column-major per trial, trial index last.
  * With N = Mr_e, M = T_prop, G2 = L*Gt, Np = clusters*rays: */
 typedef struct jstsp_trials {
     jstsp_c32 *subY;        /* N x M x batch                                                                  */
     float *Omega;           /* N x M x batch                                                                  */
-    jstsp_c32 *A;           /* N x Gr        (trial-independent: ZC beamformer x DFT dictionary)              */
+    jstsp_c32 *A;           /* N x Gr        (trial-independent: beamformer x DFT dictionary)                 */
     jstsp_c32 *B;           /* G2 x M x batch                                                                 */
     jstsp_c32 *Zbar;        /* Gr x G2 x batch   the true angle-delay channel [Z_1 ... Z_L]                   */
     jstsp_c32 *H;           /* Nr x (Nt*L) x batch   [H_1 ... H_L]                                            */

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libjstsp_mi355x.so")
 
 HOST, DEVICE = 0, 1
 TYPE_APPROXIMATE, TYPE_STD = 0, 1
+BF_ZC, BF_DFT = 0, 1
+RHO_MIN6, RHO_MAX = 0, 1
 
 c_void_p, c_int, c_ll, c_dp, c_ip = C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_int)
 
@@ -21,7 +23,8 @@ c_void_p, c_int, c_ll, c_dp, c_ip = C.c_void_p, C.c_int, C.c_longlong, C.POINTER
 class Model(C.Structure):
     """struct jstsp_model (include/jstsp.h)."""
     _fields_ = [(n, c_int) for n in ("Nt", "Nr", "L", "T_prop", "Mr", "Mr_e", "Gr", "Gt", "clusters", "rays",
-                                     "T_hbf", "shared_pilots")] + [("noise_var", C.c_double)]
+                                     "T_hbf", "shared_pilots")] + [("noise_var", C.c_double), ("beamformer", c_int),
+                                                                   ("rho_rule", c_int), ("rho_scale", C.c_double)]
 
 
 class Trials(C.Structure):

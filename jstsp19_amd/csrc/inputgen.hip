@@ -218,7 +218,8 @@ __device__ __forceinline__ double block_sum256(double v, double *sh)
 // tau_Y = 1/||Y||_F^2, tau_Z = 1/(2 ||Zbar||_F^2), rho = sqrt(lambda_6(Y'Y) / ||Y||_F^2)   (plot_errorVSsnr.m:127-130)
 // lam: the n = min(N, M) non-zero-capable eigenvalues of the Gram; eigs() returns the 6 largest of the M x M matrix.
 __global__ __launch_bounds__(256) void hyper_kernel(long long nm, long long nz, int n, int Mcols, const float2 *subY,
-                                                    const float2 *Zbar, const float *lam, double *hyp)
+                                                    const float2 *Zbar, const float *lam, double *hyp, int rho_max,
+                                                    double rho_scale)
 {
     __shared__ double sh[4];
     __shared__ float sl[128];
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(256) void hyper_kernel(long long nm, long long nz, 
     for (int i = threadIdx.x; i < n; i += 256) sl[i] = lam[(size_t)t * n + i];
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int want = min(5, Mcols - 1);        // 0-based position in the descending list of Mcols eigenvalues
+        // 0-based position in the descending list of Mcols eigenvalues: min(eigs(.)) = the 6th, max(eigs(.)) = the 1st
+        const int want = rho_max ? 0 : min(5, Mcols - 1);
         double l6 = 0.0;
         if (want < n) {
             // the (want+1)-th largest: rank by counting (n <= 128)
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void hyper_kernel(long long nm, long long nz, 
         }
         hyp[3 * t + 0] = 1.0 / fy;
         hyp[3 * t + 1] = 0.5 / fz;
-        hyp[3 * t + 2] = sqrt(l6 / fy);
+        hyp[3 * t + 2] = rho_scale * sqrt(l6 / fy);
     }
 }
 
@@ -298,6 +300,9 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     JSTSP_REQUIRE(m.Mr_e >= 1 && m.Mr_e <= m.Nr && m.Mr >= 1 && m.Mr <= m.Mr_e, JSTSP_E_SHAPE,
                   "build_trials: need 1 <= Mr <= Mr_e <= Nr");
     JSTSP_REQUIRE(m.L <= m.Tp, JSTSP_E_SHAPE, "build_trials: L > T_prop");
+    JSTSP_REQUIRE((mp->beamformer == JSTSP_BF_ZC || mp->beamformer == JSTSP_BF_DFT) &&
+                      (mp->rho_rule == JSTSP_RHO_MIN6 || mp->rho_rule == JSTSP_RHO_MAX) && mp->rho_scale >= 0.0,
+                  JSTSP_E_ARG, "build_trials: bad beamformer / rho_rule / rho_scale");
     JSTSP_REQUIRE(mp->noise_var >= 0.0, JSTSP_E_ARG, "build_trials: negative noise variance");
     JSTSP_REQUIRE(mp->T_hbf >= 0 && mp->T_hbf <= m.Tp, JSTSP_E_SHAPE, "build_trials: T_hbf outside [0, T_prop]");
     m.Np = m.clusters * m.rays; m.NtL = m.Nt * m.L; m.G2 = m.L * m.Gt;
@@ -362,7 +367,8 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     // ---- dictionaries -------------------------------------------------------------------------
     dict_kernel<<<grid_for((long long)m.Nr * m.Gr), 256, 0, st>>>(m.Nr, m.Gr, 0, Dr);
     dict_kernel<<<grid_for((long long)m.Nt * m.Gt), 256, 0, st>>>(m.Nt, m.Gt, 0, Dt);
-    dict_kernel<<<grid_for((long long)m.Nr * m.Nr), 256, 0, st>>>(m.Nr, m.Nr, 1, W);
+    // createBeamformer.m: 'ZC' (:15-16, plot_errorVSsnr.m:124) or 'fft' / 'ps' (:5,:12-13 - the same unitary DFT matrix)
+    dict_kernel<<<grid_for((long long)m.Nr * m.Nr), 256, 0, st>>>(m.Nr, m.Nr, mp->beamformer == JSTSP_BF_ZC ? 1 : 0, W);
     // ---- channel, pilots ------------------------------------------------------------------------
     channel_kernel<<<dim3(grid_for((long long)nH, 64), batch), 256, lds_ch, st>>>(m, gains, u_r, u_t, Hmat);
     pilots_kernel<<<dim3(grid_for((long long)nPsi, 1024), batch), 256, 0, st>>>(m, qam, Psi);
@@ -391,7 +397,8 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
         JSTSP_TRY(gram_partials(ctx, w, subY, (long long)nY));
         JSTSP_TRY(launch_eig(ctx, EIG_VECS, w.n, batch, w.Gpart, (long long)w.n * w.n * w.nsplit, w.nsplit,
                              (long long)w.n * w.n, nullptr, nullptr, w.Q, lam, w.Vg));
-        hyper_kernel<<<batch, 256, 0, st>>>((long long)nY, (long long)nZ, w.n, M, subY, Zbar, lam, hyp);
+        hyper_kernel<<<batch, 256, 0, st>>>((long long)nY, (long long)nZ, w.n, M, subY, Zbar, lam, hyp,
+                                            mp->rho_rule == JSTSP_RHO_MAX, mp->rho_scale > 0.0 ? mp->rho_scale : 1.0);
         JSTSP_HIP(hipGetLastError());
     }
     // ---- support ordering -------------------------------------------------------------------------------

@@ -17,7 +17,8 @@ import torch
 from .system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, build_trials, draw_trials,
                            draw_trials_training)
 
-__all__ = ["partition", "run_sweep", "run_points", "sweep_points", "run_approx_sweep"]
+__all__ = ["partition", "run_sweep", "run_points", "sweep_points", "run_approx_sweep", "driver", "run_driver",
+           "admmiters_points", "run_convergence_curves", "zy_points", "run_zy"]
 
 
 def partition(n_items, world, rank):
@@ -33,15 +34,71 @@ def sweep_points(base: SweepParams, name, values):
     ``snr_db`` (plot_errorVSsnr.m:24,48), ``L`` (plot_errorVSdelays.m:45-51), ``T``
     (plot_errorVSframelength.m:46-51), ``Mr`` (plot_errorVSnrf.m:46), ``Nt`` (plot_errorVSnt.m:46-52),
     ``rays`` (plot_errorVSpaths.m:47-51)."""
-    pts = []
-    for v in values:
-        kw = dict(Nt=base.Nt, Nr=base.Nr, L=base.L, T=base.T, Mr=base.Mr, Mr_e=base.Mr_e, Gr=base.Gr, Gt=base.Gt,
-                  clusters=base.clusters, rays=base.rays, snr_db=base.snr_db)
-        kw[name] = v
-        if name == "Nt":
-            kw["Gt"] = v                      # the drivers keep Gt = Nt
-        pts.append(SweepParams(**kw))
-    return pts
+    return [base.replace(**{name: v}) for v in values]
+
+
+def driver(name):
+    """The sweep of one of the reference's drivers at ITS OWN parameters: ``dict(points, Imax, numOfnz, n_trials,
+    metric, axis, values)`` ready for ``run_points(d["points"], d["n_trials"], Imax=d["Imax"], numOfnz=d["numOfnz"],
+    metric=d["metric"], baselines=True)``.  Each driver's construction quirks are kept: beamformer kind, the
+    min/max eigenvalue in rho, the (L, T) and (Nt, T) pairs that move together.
+
+    ================== ======================================= =====================================================
+    name               sweep axis                              cite
+    ================== ======================================= =====================================================
+    errorVSsnr         snr_db = -15:3:15                       plot_errorVSsnr.m:8-25,124-130
+    errorVSdelays      L = 2,4,6,8,10 with T = 5,10,...,25     plot_errorVSdelays.m:7-21,43-46,122,128
+    errorVSframelength T = 5,15,25,35 (Nt = 8, 'fft')          plot_errorVSframelength.m:7-22,44-46,123,129
+    errorVSnrf         Mr = 4,8,12,16 (T = 5)                  plot_errorVSnrf.m:7-22,44-46,122,128
+    errorVSnt          Nt = 4,6,8,12,16 with T = 35,..,35,25   plot_errorVSnt.m:7-22,44-48,123,129
+    errorVSpaths       rays = 1,3,6,9,12                       plot_errorVSpaths.m:7-23,45,122,128
+    rateVSframelength  T = 5,10,15 (Nt = 8, 'fft'), rate       plot_rateVSframelength.m:7-22,44-46,116,122
+    ================== ======================================= =====================================================
+    """
+    snr = lambda db: dict(snr_db=float(db))
+    if name == "errorVSsnr":
+        base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)
+        axis, values, pts = "snr_db", list(range(-15, 16, 3)), None
+        cfg = dict(Imax=100, numOfnz=100, n_trials=1, metric="nmse")
+    elif name == "errorVSdelays":
+        base = SweepParams(Nt=4, Nr=32, L=2, T=5, Mr=4, rho_rule="max", **snr(5))
+        axis, values = "L", [2, 4, 6, 8, 10]
+        pts = [base.replace(L=L, T=5 * (i + 1)) for i, L in enumerate(values)]
+        cfg = dict(Imax=100, numOfnz=50, n_trials=10, metric="nmse")
+    elif name == "errorVSframelength":
+        base = SweepParams(Nt=8, Nr=32, L=4, T=5, Mr=4, beamformer="fft", **snr(15))
+        axis, values, pts = "T", [5, 15, 25, 35], None
+        cfg = dict(Imax=100, numOfnz=50, n_trials=1, metric="nmse")
+    elif name == "errorVSnrf":
+        base = SweepParams(Nt=4, Nr=32, L=4, T=5, Mr=4, rho_rule="max", **snr(5))
+        axis, values, pts = "Mr", [4, 8, 12, 16], None
+        cfg = dict(Imax=100, numOfnz=100, n_trials=50, metric="nmse")
+    elif name == "errorVSnt":
+        base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4, beamformer="fft", rho_rule="max", **snr(15))
+        axis, values = "Nt", [4, 6, 8, 12, 16]
+        pts = [base.replace(Nt=nt, T=t) for nt, t in zip(values, [35, 35, 35, 35, 25])]
+        cfg = dict(Imax=100, numOfnz=50, n_trials=50, metric="nmse")
+    elif name == "errorVSpaths":
+        base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4, rho_rule="max", **snr(5))
+        axis, values, pts = "rays", [1, 3, 6, 9, 12], None
+        cfg = dict(Imax=100, numOfnz=100, n_trials=1, metric="nmse")
+    elif name == "rateVSframelength":
+        base = SweepParams(Nt=8, Nr=32, L=4, T=5, Mr=4, beamformer="fft", **snr(15))
+        axis, values, pts = "T", [5, 10, 15], None
+        cfg = dict(Imax=100, numOfnz=50, n_trials=1, metric="rate")
+    else:
+        raise ValueError("unknown driver %r" % (name,))
+    cfg.update(points=pts if pts is not None else sweep_points(base, axis, values), axis=axis, values=values)
+    return cfg
+
+
+def run_driver(name, n_trials=None, **kw):
+    """``run_points`` on the preset of ``driver(name)`` (all seven columns' worth of baselines unless overridden);
+    ``n_trials`` defaults to the driver's own maxMCRealizations."""
+    d = driver(name)
+    kw.setdefault("baselines", True)
+    return run_points(d["points"], d["n_trials"] if n_trials is None else n_trials, Imax=d["Imax"], numOfnz=d["numOfnz"],
+                      metric=d["metric"], **kw)
 
 
 def _score(S, zb, metric, noise_var):
@@ -215,3 +272,105 @@ def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, 
         acc = buf.cpu()
     mean = torch.clamp(acc[:, :2] / acc[:, 2:3], max=1.0)                                  # :76-77
     return mean.reshape(len(snr_db_list), len(Imax_list), 2).transpose(0, 1).contiguous()
+
+
+def _generic_sharded(points, n_trials, width, work, *, batch, seed, device, dist, builder):
+    """Shared skeleton of the curve-type drivers: shard the (point, trial) pairs over ranks, build ``batch`` trials at
+    a time, add ``work(inputs, point) -> (batch, width)`` per-trial rows, one all-reduce, mean per point."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    lo, hi = partition(len(points) * n_trials, world, rank)
+    acc = torch.zeros((len(points), width + 1), dtype=torch.float64)
+    item = lo
+    while item < hi:
+        pt = item // n_trials
+        t0 = item % n_trials
+        t1 = min(n_trials, t0 + batch, t0 + (hi - item))
+        p = points[pt]
+        if builder == "hip":
+            inp = build_trials(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device)
+        else:
+            inp = build_inputs(p, draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device))
+        rows = torch.as_tensor(work(inp, p)).double().reshape(t1 - t0, width).cpu()
+        acc[pt, :width] += rows.sum(dim=0)
+        acc[pt, width] += t1 - t0
+        item += t1 - t0
+    if dist is not None:
+        buf = acc.to(device) if dist.get_backend() == "nccl" else acc
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        acc = buf.cpu()
+    return acc[:, :width] / acc[:, width:width + 1]
+
+
+def admmiters_points():
+    """The four panels of plot_errorVSadmmiters.m (:10-24, :76-90, :141-154, :206-219): (Nt, frame, SNR) =
+    (4, 40, 15 dB), (16, 160, 15 dB), (16, 160, 5 dB), (16, 480, 5 dB); Mr = 16, 'ps' combiner, the frame is T
+    itself (:21), 20 realisations, Imax = 100."""
+    mk = lambda Nt, T, db: SweepParams(Nt=Nt, Nr=32, L=4, T=T, Mr=16, snr_db=float(db), beamformer="ps", T_prop=T)
+    return [mk(4, 40, 15), mk(16, 160, 15), mk(16, 160, 5), mk(16, 480, 5)]
+
+
+def run_convergence_curves(points, n_trials=20, *, Imax=100, batch=20, seed=20190913, device=None, solve_fn=None,
+                           dist=None, builder=None):
+    """plot_errorVSadmmiters.m:32-71: the mean over realisations of ``convergence_error`` (Imax x 3) of
+    ``proposed_algorithm`` (:61) and of ``proposed_algorithm_angles`` (:64) per panel.
+
+    Returns float64 (len(points), 2, Imax, 3): ``[:, 0]`` = mean_error_k, ``[:, 1]`` = mean_error_angles_k.
+    ``solve_fn(inputs, Imax) -> (ce, ce_angles)`` (each (batch, Imax, 3)) defaults to the HIP path.
+    """
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if builder is None:
+        builder = "hip" if solve_fn is None else "torch"
+
+    def hip(inp, Imax_):
+        from . import solvers as J
+        args = (Imax_, inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate")
+        _, _, ce = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], *args)
+        _, _, cea = J.proposed_algorithm_angles(inp["subY"], inp["Omega"], inp["indx_S"], inp["A"], inp["B"], *args)
+        return ce, cea
+
+    fn = hip if solve_fn is None else solve_fn
+
+    def work(inp, p):
+        ce, cea = fn(inp, Imax)
+        return torch.stack([torch.as_tensor(ce).double().cpu(), torch.as_tensor(cea).double().cpu()], dim=1)
+
+    out = _generic_sharded(points, n_trials, 2 * Imax * 3, work, batch=batch, seed=seed, device=device, dist=dist,
+                           builder=builder)
+    return out.reshape(len(points), 2, Imax, 3)
+
+
+def zy_points(F_range=(5,)):
+    """plot_errorVSzy.m:7-22,30: Nt = 16, Nr = 32, Mr = 16, 6 rays, frame = 16*F columns, 15 dB, 'ps', rho halved."""
+    return [SweepParams(Nt=16, Nr=32, L=4, T=16 * F, Mr=16, rays=6, snr_db=15.0, beamformer="ps", rho_scale=0.5,
+                        T_prop=16 * F) for F in F_range]
+
+
+def run_zy(points=None, n_trials=1, *, Imax=50, batch=32, seed=20190913, device=None, solve_fn=None, dist=None,
+           builder=None):
+    """plot_errorVSzy.m:28-84: per frame length the mean capped NMSE of the solver's ``S`` (the "Z" curve, :67-71)
+    and of ``A'*Y*pinv(B)`` built from its completed measurement (the "Y" curve, :73-77).
+    Returns float64 (len(points), 2).  ``solve_fn(inputs, Imax) -> (e_z, e_y)`` defaults to the HIP path."""
+    if points is None:
+        points = zy_points()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if builder is None:
+        builder = "hip" if solve_fn is None else "torch"
+
+    def hip(inp, Imax_):
+        from . import solvers as J
+        S, Y, _ = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax_, inp["tau_Y"].numpy(),
+                                       inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate", want_ce=False)   # :66
+        zb = J.colmajor(inp["Zbar"].to(torch.complex64))
+        Sy = J.colmajor(inp["A"].conj().transpose(-1, -2) @ Y @ J.pinv(inp["B"]))                                 # :73
+        return J.nmse_spectral(S, zb), J.nmse_spectral(Sy, zb)
+
+    fn = hip if solve_fn is None else solve_fn
+
+    def work(inp, p):
+        ez, ey = fn(inp, Imax)
+        return torch.stack([torch.as_tensor(ez).double().cpu(), torch.as_tensor(ey).double().cpu()], dim=1)
+
+    return _generic_sharded(points, n_trials, 2, work, batch=batch, seed=seed, device=device, dist=dist, builder=builder)

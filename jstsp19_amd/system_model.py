@@ -22,19 +22,40 @@ __all__ = ["SweepParams", "draw_trials", "build_inputs", "build_trials", "zc_bea
 
 
 class SweepParams:
-    """Parameters of one sweep point — names follow plot_errorVSsnr.m:8-25."""
+    """Parameters of one sweep point — names follow plot_errorVSsnr.m:8-25.
 
-    def __init__(self, Nt, Nr, L, T, Mr, Mr_e=None, Gr=None, Gt=None, clusters=2, rays=3, snr_db=5.0):
+    What the sibling drivers change in the construction: ``beamformer`` ('ZC', or 'fft' / 'ps' — the same unitary
+    DFT matrix, createBeamformer.m:5,12-13), ``rho_rule`` ('min': min(eigs(Y'Y)) = the 6th largest eigenvalue,
+    'max': the largest), ``rho_scale`` (plot_errorVSzy.m:65 halves rho) and ``T_prop`` (plot_errorVSadmmiters.m:21 and
+    plot_errorVSzy.m:30 use the frame length itself instead of T*Nt).
+    """
+
+    def __init__(self, Nt, Nr, L, T, Mr, Mr_e=None, Gr=None, Gt=None, clusters=2, rays=3, snr_db=5.0,
+                 beamformer="ZC", rho_rule="min", rho_scale=1.0, T_prop=None):
         self.Nt, self.Nr, self.L, self.T, self.Mr = Nt, Nr, L, T, Mr
         self.Mr_e = Nr if Mr_e is None else Mr_e
         self.Gr = Nr if Gr is None else Gr
         self.Gt = Nt if Gt is None else Gt
         self.clusters, self.rays = clusters, rays
         self.snr_db = float(snr_db)
+        if beamformer not in ("ZC", "fft", "ps") or rho_rule not in ("min", "max"):
+            raise ValueError("beamformer must be 'ZC', 'fft' or 'ps'; rho_rule 'min' or 'max'")
+        self.beamformer, self.rho_rule, self.rho_scale = beamformer, rho_rule, float(rho_scale)
+        self._T_prop = T_prop
+
+    def replace(self, **kw):
+        """A copy with some parameters changed (``Gt`` follows ``Nt`` unless given, as the drivers keep Gt = Nt)."""
+        cur = dict(Nt=self.Nt, Nr=self.Nr, L=self.L, T=self.T, Mr=self.Mr, Mr_e=self.Mr_e, Gr=self.Gr, Gt=self.Gt,
+                   clusters=self.clusters, rays=self.rays, snr_db=self.snr_db, beamformer=self.beamformer,
+                   rho_rule=self.rho_rule, rho_scale=self.rho_scale, T_prop=self._T_prop)
+        if "Nt" in kw and "Gt" not in kw:
+            cur["Gt"] = kw["Nt"]
+        cur.update(kw)
+        return SweepParams(**cur)
 
     @property
     def T_prop(self):                       # plot_errorVSsnr.m:23
-        return self.T * self.Nt
+        return self.T * self.Nt if self._T_prop is None else self._T_prop
 
     @property
     def noise_var(self):                    # :49
@@ -101,6 +122,11 @@ def zc_beamformer(N, device, dtype=torch.complex128):
     m = torch.arange(1, N + 1, device=device, dtype=torch.float64)[None, :]
     ph = -11.0 * n * math.pi * m / N
     return (torch.complex(torch.cos(ph), torch.sin(ph)) / math.sqrt(N)).to(dtype)
+
+
+def _beamformer(p, device):
+    """createBeamformer(Nr, kind): 'ZC' (:15-16), 'fft' (:5) and 'ps' (:12-13) — the last two are the same matrix."""
+    return zc_beamformer(p.Nr, device) if p.beamformer == "ZC" else dft_dictionary(p.Nr, p.Nr, device)
 
 
 def _steer(phi, Mn):
@@ -172,7 +198,8 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=Fals
     # --- received signal, sampling mask, measurement (proposed_hbf.m:13-42)
     Y = torch.einsum("trsl,tsjl->trj", H, Psi_bar)                              # sum_l H_l Psi_bar_l   :19
     R = Y + math.sqrt(p.noise_var / 2.0) * draws["noise"]                       # :22, plot_errorVSsnr.m:60
-    W_e = zc_beamformer(p.Nr, dev)[:, :p.Mr_e]                                  # :11, plot_errorVSsnr.m:124
+    Wfull = _beamformer(p, dev)
+    W_e = Wfull[:, :p.Mr_e]                                                     # :11, plot_errorVSsnr.m:124
     Omega = torch.zeros((T, p.Mr_e, Tp), device=dev, dtype=torch.float64)
     Omega.scatter_(1, draws["omega_rows"].transpose(1, 2), 1.0)                 # :36-41
     subY = Omega * torch.einsum("re,trj->tej", W_e.conj(), R)                   # :42
@@ -181,7 +208,7 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=Fals
     tau_Y = 1.0 / fro2
     tau_Z = 0.5 / (Zbar.abs() ** 2).sum(dim=(1, 2))
     sv = torch.linalg.svdvals(subY)
-    rho = torch.sqrt(sv[:, 5] ** 2 / fro2)
+    rho = p.rho_scale * torch.sqrt(sv[:, 0 if p.rho_rule == "max" else 5] ** 2 / fro2)
     # --- dictionary factors (:132-136)
     A = W_e.conj().transpose(0, 1) @ Dr                                         # Mr_e x Gr
     B = torch.einsum("sh,tsjl->tlhj", Dt.conj(), Psi_bar).reshape(T, p.L * p.Gt, Tp)   # rows l*Gt + h
@@ -191,7 +218,7 @@ def build_inputs(p: SweepParams, draws, out_dtype=torch.complex64, with_hbf=Fals
     if with_hbf:
         # conventional HBF with all Nr RF chains over a shorter frame (plot_errorVSsnr.m:73-80, hbf.m:1-26)
         Th = p.T_hbf
-        Wc = zc_beamformer(p.Nr, dev)                                           # Mr_hbf = Nr columns (:11,:73)
+        Wc = Wfull                                                              # Mr_hbf = Nr columns (:11,:73)
         Psi_c = Psi_bar[:, :, :Th, :]                                           # Psi_i(1:T_hbf,1:T_hbf,:) rows 1..L
         Rc = torch.einsum("trsl,tsjl->trj", H, Psi_c) + math.sqrt(p.noise_var / 2.0) * draws["noise"][:, :, :Th]
         Y_hbf = torch.einsum("re,trj->tej", Wc.conj(), Rc)                      # hbf.m:24
@@ -302,7 +329,8 @@ def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, d
     Np = p.clusters * p.rays
     Th = p.T_hbf if with_hbf else 0
     model = _lib.Model(p.Nt, p.Nr, p.L, p.T_prop, p.Mr, p.Mr_e, p.Gr, p.Gt, p.clusters, p.rays, Th,
-                       1 if shared_pilots else 0, p.noise_var)
+                       1 if shared_pilots else 0, p.noise_var, _lib.BF_ZC if p.beamformer == "ZC" else _lib.BF_DFT,
+                       _lib.RHO_MAX if p.rho_rule == "max" else _lib.RHO_MIN6, p.rho_scale)
     c64, f32 = torch.complex64, torch.float32
     out = dict(subY=empty_colmajor(batch, N, M, c64, device), Omega=empty_colmajor(batch, N, M, f32, device),
                A=empty_colmajor(1, N, Gr, c64, device)[0], B=empty_colmajor(batch, G2, M, c64, device),

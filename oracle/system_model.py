@@ -191,7 +191,9 @@ def rho_from_eigs(Y, which="min6"):
 def training_inputs_errorVSsnr(params, draws):
     """plot_errorVSsnr.m:57-136 for one trial — the solver inputs of the proposed scheme.
 
-    ``params``: dict(Nt, Nr, Mr_e, Gr, Gt, clusters, rays, L, Mr, T, noise_var).
+    ``params``: dict(Nt, Nr, Mr_e, Gr, Gt, clusters, rays, L, Mr, T, noise_var) and, for the sibling drivers,
+    optionally ``beamformer`` ('ZC' | 'fft' | 'ps'), ``rho_rule`` ('min' | 'max', plot_errorVSdelays.m:128),
+    ``rho_scale`` (plot_errorVSzy.m:65), ``T_prop`` (plot_errorVSadmmiters.m:21: the frame itself).
     ``draws``: dict(gains, u_r, u_t, noise (Nr x T_prop complex standard normal * 1 — scaled
     here by sqrt(var/2) as :60 does with two real normals), qam_idx (Nt x T_prop ints 0..3),
     omega_rows (T_prop x Mr ints)).
@@ -199,7 +201,7 @@ def training_inputs_errorVSsnr(params, draws):
     """
     p = params
     Nt, Nr, L, T = p["Nt"], p["Nr"], p["L"], p["T"]
-    T_prop = T * Nt                                     # :23
+    T_prop = p.get("T_prop") or T * Nt                  # :23
     H, Zbar, _, _, Dr, Dt = wideband_mmwave_channel(
         L, Nr, Nt, p["clusters"], p["rays"], p["Gr"], p["Gt"],
         draws["gains"], draws["u_r"], draws["u_t"])     # :57
@@ -209,12 +211,12 @@ def training_inputs_errorVSsnr(params, draws):
     for k in range(Nt):                                 # :63-67
         s = alphabet[draws["qam_idx"][k]]
         Psi_rows[:, :, k] = toeplitz_rows(s, L)
-    W = create_beamformer(Nr, "ZC")                     # :124
+    W = create_beamformer(Nr, p.get("beamformer", "ZC"))   # :124
     Y_prop, W_tilde, Psi_bar, Omega, _ = proposed_hbf(
         H, Nn, Psi_rows, T_prop, p["Mr_e"], p["Mr"], W, draws["omega_rows"])   # :125
     tau_Y = 1 / np.linalg.norm(Y_prop, "fro") ** 2      # :127
     tau_Z = 1 / np.linalg.norm(Zbar, "fro") ** 2 / 2    # :128
-    rho = rho_from_eigs(Y_prop, "min6")                 # :129-130
+    rho = p.get("rho_scale", 1.0) * rho_from_eigs(Y_prop, "max" if p.get("rho_rule") == "max" else "min6")   # :129-130
     A = W_tilde.conj().T @ Dr                           # :132
     Gt = p["Gt"]
     B = np.zeros((L * Gt, T_prop), complex)             # :133
@@ -232,7 +234,7 @@ def draw_trial(rng, params):
     p = params
     Np = p["clusters"] * p["rays"]
     L, Nr, Nt = p["L"], p["Nr"], p["Nt"]
-    T_prop = p["T"] * Nt
+    T_prop = p.get("T_prop") or p["T"] * Nt
     gains = np.zeros((L, Np), complex)
     u_r = np.zeros((L, Np))
     u_t = np.zeros((L, Np))

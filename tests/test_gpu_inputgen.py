@@ -22,13 +22,19 @@ def _oracle_inputs(p, out, t):
              noise=out["noise"][t].cpu().numpy().astype(complex), qam_idx=out["qam_idx"][t].cpu().numpy().astype(int),
              omega_rows=rows)
     op = dict(Nt=p.Nt, Nr=p.Nr, Mr_e=p.Mr_e, Gr=p.Gr, Gt=p.Gt, clusters=p.clusters, rays=p.rays, L=p.L, Mr=p.Mr,
-              T=p.T, noise_var=p.noise_var)
+              T=p.T, noise_var=p.noise_var, beamformer=p.beamformer, rho_rule=p.rho_rule, rho_scale=p.rho_scale,
+              T_prop=p.T_prop)
     return osm.training_inputs_errorVSsnr(op, d), d
 
 
 @pytest.mark.parametrize("kw", [dict(Nt=4, Nr=16, L=3, T=6, Mr=4, snr_db=5.0),
                                 dict(Nt=4, Nr=32, L=4, T=20, Mr=4, snr_db=-5.0),          # plot_errorVSsnr.m shape
-                                dict(Nt=2, Nr=12, L=2, T=7, Mr=3, Mr_e=9, Gr=16, Gt=4, clusters=3, rays=2, snr_db=10.0)])
+                                dict(Nt=2, Nr=12, L=2, T=7, Mr=3, Mr_e=9, Gr=16, Gt=4, clusters=3, rays=2, snr_db=10.0),
+                                # what the sibling drivers change: 'fft' combiner + max(eigs) (plot_errorVSnt.m:123,129),
+                                # 'ps' combiner, the frame itself as T_prop, rho halved (plot_errorVSzy.m:30,53,65)
+                                dict(Nt=6, Nr=32, L=4, T=10, Mr=4, snr_db=15.0, beamformer="fft", rho_rule="max"),
+                                dict(Nt=16, Nr=32, L=4, T=80, Mr=16, rays=6, snr_db=15.0, beamformer="ps", rho_scale=0.5,
+                                     T_prop=80)])
 def test_build_trials_matches_oracle_on_its_own_draws(kw):
     from jstsp19_amd.system_model import SweepParams, build_trials
     p = SweepParams(**kw)

@@ -209,6 +209,62 @@ def test_alg1_vs_alg2_sweep_on_hip_matches_oracle_per_point():
     assert np.all(hip[:, 2, :] < hip[:, 0, :])                              # the NMSE falls with the SNR
 
 
+@pytest.mark.parametrize("name", ["errorVSdelays", "errorVSnt", "errorVSnrf", "rateVSframelength"])
+def test_sibling_driver_presets_on_hip_match_oracle(name):
+    """montecarlo.run_driver: the sibling drivers at their own parameters (beamformer kind, min/max eigenvalue in rho,
+    joint (L,T) / (Nt,T) axes) — proposed / angles columns against the oracle on the same HIP-built trials."""
+    import torch
+    from jstsp19_amd.montecarlo import driver, run_points
+    from oracle import solvers as O
+    d = driver(name)
+    pts = d["points"][:2] + d["points"][-1:]
+    rate = d["metric"] == "rate"
+
+    def oracle_solve(inp, Imax):
+        e, ea = [], []
+        A = inp["A"].cpu().numpy().astype(complex)
+        for t in range(inp["subY"].shape[0]):
+            args = (inp["subY"][t].cpu().numpy().astype(complex), inp["Omega"][t].cpu().numpy().astype(float), A,
+                    inp["B"][t].cpu().numpy().astype(complex), Imax, float(inp["tau_Y"][t]), float(inp["tau_Z"][t]),
+                    float(inp["rho"][t]), "approximate")
+            S, _, _ = O.proposed_algorithm(*args, want_ce=False)
+            Sa, _, _ = O.proposed_algorithm(*args, indx_S=inp["indx_S"][t].cpu().numpy(), want_ce=False)
+            zb = inp["Zbar"][t].cpu().numpy()
+            e.append(O.nmse_capped(S, zb)); ea.append(O.nmse_capped(Sa, zb))
+        return torch.tensor(e), torch.tensor(ea)
+
+    dev = torch.device("cuda:0")
+    hip = run_points(pts, 2, Imax=d["Imax"], numOfnz=d["numOfnz"], metric=d["metric"], baselines=True, batch=2,
+                     device=dev).numpy()
+    assert hip.shape == (3, 5) and np.all(np.isfinite(hip)) and np.all(hip > 0)
+    if not rate:
+        ref = run_points(pts, 2, Imax=d["Imax"], batch=2, device=dev, solve_fn=oracle_solve, builder="hip").numpy()
+        np.testing.assert_allclose(hip[:, :2], ref, rtol=1e-3, atol=2e-6)
+        assert np.all(hip <= 1)
+
+
+def test_convergence_curves_and_zy_on_hip_match_oracle():
+    """run_convergence_curves (plot_errorVSadmmiters.m:32-71, the first panel's parameters) and run_zy
+    (plot_errorVSzy.m:28-84 at its own size) against the oracle on the same HIP-built trials."""
+    import torch
+    from jstsp19_amd.montecarlo import admmiters_points, run_convergence_curves, run_zy, zy_points
+    from tests.test_system_model import _oracle_curves, _oracle_zy
+    dev = torch.device("cuda:0")
+    pts = admmiters_points()[:1]
+    hip = run_convergence_curves(pts, 3, Imax=40, batch=3, device=dev).numpy()
+    ref = run_convergence_curves(pts, 3, Imax=40, batch=3, device=dev, solve_fn=_oracle_curves, builder="hip").numpy()
+    assert hip.shape == (1, 2, 40, 3)
+    assert np.all(np.isinf(hip[:, :, 0, 2])) and np.all(np.isinf(ref[:, :, 0, 2]))      # C = 0 before iteration 1
+    np.testing.assert_allclose(hip[:, :, 1:, :], ref[:, :, 1:, :], rtol=2e-3, atol=1e-7)
+    np.testing.assert_allclose(hip[:, :, 0, :2], ref[:, :, 0, :2], rtol=2e-3, atol=1e-7)
+    big = run_convergence_curves(admmiters_points()[3:], 2, Imax=100, batch=2, device=dev).numpy()   # 32 x 480, G2 = 64
+    assert big.shape == (1, 2, 100, 3) and np.all(np.isfinite(big[:, :, 1:, :])) and big[0, 0, -1, 0] < big[0, 0, 0, 0]
+    zy = run_zy(zy_points(), 2, batch=2, device=dev).numpy()
+    zr = run_zy(zy_points(), 2, batch=2, device=dev, solve_fn=_oracle_zy, builder="hip").numpy()
+    assert zy.shape == (1, 2)
+    np.testing.assert_allclose(zy, zr, rtol=1e-3, atol=2e-6)
+
+
 def test_lanczos_lambda_max_agrees_with_householder_sturm():
     """convergence_error(:,1:2) takes lambda_max from the one-wave Lanczos kernel (JSTSP_LANCZOS=0 switches back to the
     Householder + Sturm kernel): both must give the same ratios far inside the 2e-3 parity tolerance — Gram orders

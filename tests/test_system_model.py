@@ -1,6 +1,7 @@
 """Product-side batched input builder (torch) vs the oracle's per-trial literal restatement of
 plot_errorVSsnr.m:57-136, on the same random draws.  Runs on CPU."""
 import numpy as np
+import pytest
 import torch
 
 from jstsp19_amd.system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, draw_trials,
@@ -159,3 +160,94 @@ def test_alg1_vs_alg2_sweep_runner_with_oracle_solver():
     assert out.shape == (2, 2, 2) and np.all(out > 0) and np.all(out <= 1)
     assert np.all(out[:, 1, :] < out[:, 0, :])
     assert np.all(np.abs(out[1, :, 0] - out[1, :, 1]) < 0.5 * out[1, :, 0] + 1e-3)
+
+
+def _oracle_params(p):
+    return dict(Nt=p.Nt, Nr=p.Nr, Mr_e=p.Mr_e, Gr=p.Gr, Gt=p.Gt, clusters=p.clusters, rays=p.rays, L=p.L, Mr=p.Mr,
+                T=p.T, noise_var=p.noise_var, beamformer=p.beamformer, rho_rule=p.rho_rule, rho_scale=p.rho_scale,
+                T_prop=p.T_prop)
+
+
+@pytest.mark.parametrize("kw", [dict(beamformer="fft"),                                  # plot_errorVSframelength.m:123
+                                dict(rho_rule="max"),                                    # plot_errorVSdelays.m:128
+                                dict(beamformer="ps", rho_scale=0.5, T_prop=12)])        # plot_errorVSzy.m:53,65,30
+def test_sibling_driver_construction_variants_match_oracle(kw):
+    p = SweepParams(Nt=4, Nr=16, L=3, T=6, Mr=4, snr_db=5.0, **kw)
+    assert p.T_prop == (12 if "T_prop" in kw else 24)
+    draws = draw_trials(p, [2], seed=11, device="cpu")
+    out = build_inputs(p, draws, out_dtype=torch.complex128, with_hbf=True)
+    ref = osm.training_inputs_errorVSsnr(_oracle_params(p), _to_np(draws, 0))
+    np.testing.assert_allclose(out["subY"][0].numpy(), ref["subY"], atol=1e-11)
+    np.testing.assert_allclose(out["A"].numpy(), ref["A"], atol=1e-12)
+    np.testing.assert_allclose(out["B"][0].numpy(), ref["B"], atol=1e-12)
+    np.testing.assert_allclose(float(out["rho"][0]), ref["rho"], rtol=1e-10)
+    if kw.get("beamformer") in ("fft", "ps"):                  # unitary DFT combiner x DFT dictionary
+        np.testing.assert_allclose(out["A"].numpy(), np.eye(16), atol=1e-12)
+        np.testing.assert_allclose(osm.create_beamformer(16, "fft"), osm.create_beamformer(16, "ps"), atol=1e-14)
+    if kw.get("rho_rule") == "max":
+        s = np.linalg.svd(ref["subY"], compute_uv=False)
+        np.testing.assert_allclose(ref["rho"], s[0] / np.linalg.norm(ref["subY"], "fro"), rtol=1e-12)
+
+
+def test_driver_presets_follow_the_reference_scripts():
+    from jstsp19_amd.montecarlo import admmiters_points, driver, zy_points
+    d = driver("errorVSdelays")                                 # plot_errorVSdelays.m:16,43-46: (L, T) move together
+    assert [(p.L, p.T, p.T_prop, p.T_hbf) for p in d["points"]] == [(2, 5, 20, 4), (4, 10, 40, 4), (6, 15, 60, 8),
+                                                                    (8, 20, 80, 12), (10, 25, 100, 12)]
+    assert all(p.rho_rule == "max" and p.beamformer == "ZC" and p.snr_db == 5.0 for p in d["points"])
+    d = driver("errorVSnt")                                     # plot_errorVSnt.m:7,22,44-48
+    assert [(p.Nt, p.Gt, p.T, p.T_prop) for p in d["points"]] == [(4, 4, 35, 140), (6, 6, 35, 210), (8, 8, 35, 280),
+                                                                  (12, 12, 35, 420), (16, 16, 25, 400)]
+    assert all(p.beamformer == "fft" and p.rho_rule == "max" for p in d["points"])
+    d = driver("errorVSnrf")                                    # :20,45 — round(5/(32/16)) = round(2.5) = 3 in MATLAB
+    assert [(p.Mr, p.T_hbf) for p in d["points"]] == [(4, 4), (8, 4), (12, 8), (16, 12)]
+    assert driver("rateVSframelength")["metric"] == "rate" and driver("errorVSsnr")["values"] == list(range(-15, 16, 3))
+    assert [p.solver_shape for p in admmiters_points()] == [(32, 40, 32, 16), (32, 160, 32, 64), (32, 160, 32, 64),
+                                                            (32, 480, 32, 64)]
+    z = zy_points()[0]
+    assert z.solver_shape == (32, 80, 32, 64) and z.rho_scale == 0.5 and z.rays == 6
+    with pytest.raises(ValueError):
+        driver("nope")
+
+
+def _oracle_curves(inp, Imax):
+    from oracle import solvers as O
+    A = inp["A"].cpu().numpy().astype(complex)
+    ce, cea = [], []
+    for t in range(inp["subY"].shape[0]):
+        args = (inp["subY"][t].cpu().numpy().astype(complex), inp["Omega"][t].cpu().numpy().astype(float), A,
+                inp["B"][t].cpu().numpy().astype(complex), Imax, float(inp["tau_Y"][t]), float(inp["tau_Z"][t]),
+                float(inp["rho"][t]), "approximate")
+        ce.append(O.proposed_algorithm(*args)[2])
+        cea.append(O.proposed_algorithm(*args, indx_S=inp["indx_S"][t].cpu().numpy())[2])
+    return torch.tensor(np.stack(ce)), torch.tensor(np.stack(cea))
+
+
+def _oracle_zy(inp, Imax):
+    from oracle import solvers as O
+    A = inp["A"].cpu().numpy().astype(complex)
+    ez, ey = [], []
+    for t in range(inp["subY"].shape[0]):
+        B = inp["B"][t].cpu().numpy().astype(complex)
+        S, Y, _ = O.proposed_algorithm(inp["subY"][t].cpu().numpy().astype(complex),
+                                       inp["Omega"][t].cpu().numpy().astype(float), A, B, Imax, float(inp["tau_Y"][t]),
+                                       float(inp["tau_Z"][t]), float(inp["rho"][t]), "approximate", want_ce=False)
+        zb = inp["Zbar"][t].cpu().numpy()
+        ez.append(O.nmse_capped(S, zb))
+        ey.append(O.nmse_capped(A.conj().T @ Y @ np.linalg.pinv(B), zb))
+    return torch.tensor(ez), torch.tensor(ey)
+
+
+def test_convergence_curve_and_zy_runners_with_oracle_solver():
+    """plot_errorVSadmmiters.m:32-71 and plot_errorVSzy.m:28-84 on CPU with the oracle as the solver hook."""
+    from jstsp19_amd.montecarlo import run_convergence_curves, run_zy
+    pts = [SweepParams(Nt=2, Nr=8, L=2, T=12, Mr=4, snr_db=15.0, beamformer="ps", T_prop=12)]
+    cur = run_convergence_curves(pts, 3, Imax=12, batch=2, device=torch.device("cpu"), solve_fn=_oracle_curves).numpy()
+    assert cur.shape == (1, 2, 12, 3) and np.all(cur >= 0)
+    assert np.all(np.isinf(cur[:, :, 0, 2])) and np.all(np.isfinite(cur[:, :, 1:, :]))   # C = 0 before iteration 1: x/0
+    assert cur[0, 0, -1, 0] < cur[0, 0, 0, 0]                    # epsilon_1 falls over the iterations
+    one = run_convergence_curves(pts, 1, Imax=12, batch=1, device=torch.device("cpu"), solve_fn=_oracle_curves).numpy()
+    inp = build_inputs(pts[0], draw_trials(pts[0], [0], device="cpu"))
+    np.testing.assert_allclose(one[0, 0], _oracle_curves(inp, 12)[0][0].numpy(), rtol=1e-12)
+    zy = run_zy([pts[0].replace(rho_scale=0.5)], 3, Imax=10, batch=2, device=torch.device("cpu"), solve_fn=_oracle_zy).numpy()
+    assert zy.shape == (1, 2) and np.all(zy > 0) and np.all(zy <= 1)
