@@ -1,0 +1,428 @@
+// One pass over the dictionary per ADMM iteration (proposed_algorithm.m:38-65, 'approximate').
+//
+// An iteration of the reference touches B twice: Xs = A S B (:58) and, one iteration later, K2'*k = A^H K B^H (:47),
+// with the element-wise updates of X, V1, V2, C and k (:38-43,:61-65) in between.  Both products stream the whole
+// dictionary from HBM (the dominant traffic of the solver).  Here one kernel walks over B ONCE per iteration: for a
+// tile of 32 columns m of B (all G2 rows, 128 KiB in split-f16 form) resident in LDS it computes
+//   phase A   Xs(:, tile)  = (A S) B(:, tile)                            contraction over g   (:58)
+//   update    V2, X, V1, k of the NEXT iteration on that tile            element-wise        (:61-65, :38-43)
+//   phase B   P += k(:, tile) B(:, tile)^H                               contraction over m   (:47, first factor)
+// and keeps the N x G2 sums P of its column range in registers; the per-range partials are summed afterwards.
+//
+// The same B tile serves as an MFMA operand with g as contraction index (phase A) and with m as contraction index
+// (phase B).  Its LDS image is [plane][m/4][g/4][4 m][4 g] halves: a row of a 4 x 4 micro-block is a phase-A
+// fragment piece (ds_read_b64), a column of it — picked out of the 32-byte block with v_perm_b32 — a phase-B piece.
+// Everything is computed transposed (Xs^T = B^T (A S)^T) so that the accumulator layout of phase A
+// (lane = n, registers = 4 consecutive m) IS the B-operand layout of phase B's 16x16x32 MFMA: k goes from the
+// element-wise update to the second product through a 16-KiB LDS exchange and never touches HBM.
+//
+// Shapes: N = 64, G2 = 512, M a multiple of 32 * parts.  Everything else keeps the three-kernel path.
+#include "solver_common.h"
+#include <cstdlib>
+
+namespace jstsp {
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FPAD = 64;          // bytes of padding per LDS row (4 m-quads of one plane then hit 4 different bank groups)
+constexpr int KBACK = 4;          // the k scale is taken 2^4 below the one its previous maximum would give (see fused_pass_kernel)
+
+// e such that amax * 2^e lies in [2^13, 2^14)   (as hgemm.hip)
+__device__ __host__ inline int fscale_exp(uint32_t amax_bits)
+{
+    const int be = (int)((amax_bits >> 23) & 0xff);
+    if (be == 0 || be == 255) return 0;
+    return 13 - (be - 127);
+}
+__device__ __forceinline__ void fsplit(float x, _Float16 &h, _Float16 &l)
+{
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
+}
+__device__ __forceinline__ half8 h8(uint4 u) { return *reinterpret_cast<half8 *>(&u); }
+__device__ __forceinline__ uint4 negu(uint4 u)
+{
+    u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+    return u;
+}
+__device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(b), c, 0, 0, 0);
+}
+
+// ---- B -> tile images: out[t][tile][plane 4][mq 8][gq G2/4][r 4][c 4] halves, m = 32 tile + 4 mq + r, g = 4 gq + c
+__global__ __launch_bounds__(256) void pack_bf_kernel(const float2 *B, long long sBt, int G2, int M, const uint32_t *bmax,
+                                                      int sbmax, uint4 *out, long long sOut)
+{
+    const int t = blockIdx.y;
+    const int GQ = G2 >> 2;
+    const long long per_tile = 16ll * GQ;                   // 8 mq * GQ gq * 2 row pairs
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)(M / 32) * per_tile) return;
+    const int tile = (int)(idx / per_tile);
+    int rem = (int)(idx % per_tile);
+    const int rh = rem & 1; rem >>= 1;
+    const int gq = rem % GQ, mq = rem / GQ;
+    const float s = ldexpf(1.f, fscale_exp(bmax[(long long)t * sbmax]));
+    half8 pl[4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int m = tile * 32 + 4 * mq + 2 * rh + rr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float2 x = B[(long long)t * sBt + (4 * gq + c) + (long long)G2 * m];
+            _Float16 h, l;
+            fsplit(x.x * s, h, l); pl[0][4 * rr + c] = h; pl[1][4 * rr + c] = l;
+            fsplit(x.y * s, h, l); pl[2][4 * rr + c] = h; pl[3][4 * rr + c] = l;
+        }
+    }
+    uint4 *o = out + (long long)t * sOut + (long long)tile * (16ll * G2);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o[((long long)(p * 8 + mq) * GQ + gq) * 2 + rh] = *reinterpret_cast<uint4 *>(&pl[p]);
+}
+
+// ---- W = A S (N x G2, column-major) -> B-operand fragments of (A S)^T: out[t][ks G2/32][nb 4][plane 4][lane 64],
+//      lane l: n = 16 nb + (l & 15), g = 32 ks + 8 (l >> 4) + 0..7
+__global__ __launch_bounds__(256) void pack_as_kernel(const float2 *W, long long sWt, int G2, const uint32_t *wmax, uint4 *out,
+                                                      long long sOut)
+{
+    const int t = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (G2 / 32) * 256) return;
+    const int lane = idx & 63, nb = (idx >> 6) & 3, ks = idx >> 8;
+    const int n = 16 * nb + (lane & 15), g0 = 32 * ks + 8 * (lane >> 4);
+    const float s = ldexpf(1.f, fscale_exp(wmax[t]));
+    half8 pl[4];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const float2 x = W[(long long)t * sWt + n + 64ll * (g0 + v)];
+        _Float16 h, l;
+        fsplit(x.x * s, h, l); pl[0][v] = h; pl[1][v] = l;
+        fsplit(x.y * s, h, l); pl[2][v] = h; pl[3][v] = l;
+    }
+    uint4 *o = out + (long long)t * sOut + (long long)((ks * 4 + nb) * 4) * 64 + lane;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o[p * 64] = *reinterpret_cast<uint4 *>(&pl[p]);
+}
+
+// ---- Tc[t] = sum over the column ranges of the partial sums
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float4 *P, int parts, long long n4, float4 *out)
+{
+    const int t = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 *p = P + (long long)t * parts * n4 + i;
+    float4 a = p[0];
+    for (int s = 1; s < parts; ++s) {
+        const float4 b = p[(long long)s * n4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    out[(long long)t * n4 + i] = a;
+}
+
+// a k entry left the f16 range of its scale somewhere in the solve: the results are not to be trusted - make that loud
+__global__ __launch_bounds__(256) void poison_kernel(const uint32_t *ovf, float2 *S, long long n)
+{
+    if (!*ovf) return;
+    const float q = __builtin_nanf("");
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) S[i] = make_float2(q, q);
+}
+
+template <int GB>
+__global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
+{
+    constexpr int G2 = 128 * GB;
+    constexpr int ROWB = G2 * 8 + FPAD;        // bytes of one LDS row: (G2/4) micro-blocks of 32 B
+    constexpr int TILEB = 32 * ROWB;           // 4 planes x 8 m-quads
+    constexpr int CPT = G2 / 32;               // 16-byte chunks per thread per tile
+    constexpr int CPR = G2 / 2;                // chunks per row
+    constexpr int KSH = G2 / 64;               // 32-wide k-steps per g-half
+    extern __shared__ __align__(16) unsigned char lds[];
+    unsigned char *tile = lds;
+    unsigned char *xch = lds + TILEB;          // 16 KiB: phase-A partial sums, then the k fragments
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int t = (slot / d.parts) * 8 + xcd;  // the column ranges of one problem run on ONE XCD: (A S) stays in its L2
+    if (t >= d.batch) return;
+    const int part = slot % d.parts;
+    const int tpw = (d.M / 32) / d.parts;
+    const int tile0 = part * tpw;
+
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, q = l >> 4, c16 = l & 15;
+    const int nb = w & 3, kh = w >> 2;
+
+    const TrialParams prm = d.prm[t];
+    const int eb = fscale_exp(d.bmax[(long long)t * d.sbmax]), ew = fscale_exp(d.wmax[t]);
+    // k of this pass is formed and consumed here, its maximum is only known afterwards: the scale comes from the
+    // previous iteration's max|k|, backed off by 2^KBACK (room for a 2^(2+KBACK)-fold growth before f16 overflows; entries
+    // keep 22 bits down to 2^-13 of the maximum and 2^-25 absolute of the scaled range below - far under the fp32 noise
+    // of the sums).  An overflow raises d.ovf.
+    const int ek = fscale_exp(d.kmax_prev[t]) - KBACK;
+    const float sxs = ldexpf(1.f, -(eb + ew)), sk = ldexpf(1.f, ek), sp = ldexpf(1.f, -(eb + ek));
+    const float rho = prm.rho, ir = prm.irho, omc = 1.f - prm.c_coef, omr = 1.f - rho, omir = 1.f - ir;
+
+    const uint4 *bsrc = d.Bf + (long long)t * d.sBf;
+    const long long tile_u4 = 16ll * G2;
+    uint4 pf[CPT];
+    auto gload = [&](int tl) {
+        const uint4 *s = bsrc + (long long)tl * tile_u4 + tid;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) pf[c] = s[512 * c];
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int ch = tid + 512 * c;
+            *reinterpret_cast<uint4 *>(tile + ch * 16 + (ch / CPR) * FPAD) = pf[c];
+        }
+    };
+
+    f32x4 pr[GB][4], pi[GB][4];
+#pragma unroll
+    for (int gb = 0; gb < GB; ++gb)
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) { pr[gb][n2] = f32x4{0.f, 0.f, 0.f, 0.f}; pi[gb][n2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float kmx = 0.f, xmx = 0.f, v1mx = 0.f, zmx = 0.f, v2mx = 0.f;
+
+    const long long base = (long long)t * d.snm + 16 * nb + c16;      // + 64 m
+    const uint4 *asp = d.ASp + (long long)t * d.sAS + (long long)(kh * KSH) * 1024 + nb * 256 + l;
+    const int perm_sel = (c16 & 1) ? 0x07060302 : 0x05040100;
+    const bool cw = (c16 & 2) != 0;
+
+    gload(tile0);
+    sstore();
+    __syncthreads();
+
+    for (int i = 0; i < tpw; ++i) {
+        const int m0 = (tile0 + i) * 32;
+        // ================= phase A: Xs^T(tile) = B^T (A S)^T, this wave: n-block nb, g-half kh, both m-blocks
+        f32x4 ar[2], ai[2];
+        ar[0] = ar[1] = ai[0] = ai[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint4 wf[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) wf[p] = asp[p * 64];
+#pragma unroll 2
+        for (int ks = 0; ks < KSH; ++ks) {
+            uint4 wn[4];
+            const uint4 *nx = asp + (long long)min(ks + 1, KSH - 1) * 1024;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) wn[p] = nx[p * 64];
+            const uint4 nwi_h = negu(wf[2]), nwi_l = negu(wf[3]);
+            const int goff = (kh * (G2 / 2) + 32 * ks + 8 * q) * 8 + (c16 & 3) * 8;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int mq = 4 * mb + (c16 >> 2);
+                uint4 bf[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const unsigned char *a = tile + (p * 8 + mq) * ROWB + goff;
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(a), hi = *reinterpret_cast<const uint2 *>(a + 32);
+                    bf[p] = uint4{lo.x, lo.y, hi.x, hi.y};
+                }
+                // re += Br Wr - Bi Wi ; im += Br Wi + Bi Wr   (h h + h l + l h each)
+                ar[mb] = mma(bf[0], wf[0], ar[mb]); ar[mb] = mma(bf[0], wf[1], ar[mb]); ar[mb] = mma(bf[1], wf[0], ar[mb]);
+                ar[mb] = mma(bf[2], nwi_h, ar[mb]); ar[mb] = mma(bf[2], nwi_l, ar[mb]); ar[mb] = mma(bf[3], nwi_h, ar[mb]);
+                ai[mb] = mma(bf[0], wf[2], ai[mb]); ai[mb] = mma(bf[0], wf[3], ai[mb]); ai[mb] = mma(bf[1], wf[2], ai[mb]);
+                ai[mb] = mma(bf[2], wf[0], ai[mb]); ai[mb] = mma(bf[2], wf[1], ai[mb]); ai[mb] = mma(bf[3], wf[0], ai[mb]);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) wf[p] = wn[p];
+        }
+        // the two g-halves meet: wave (nb, kh) keeps m-block kh and hands m-block 1 - kh to wave (nb, 1 - kh)
+        {
+            const f32x4 sr = kh ? ar[0] : ar[1], si = kh ? ai[0] : ai[1];
+            f32x4 *x4 = reinterpret_cast<f32x4 *>(xch);
+            const int dw = nb + 4 * (1 - kh);
+            x4[(dw * 2 + 0) * 64 + l] = sr;
+            x4[(dw * 2 + 1) * 64 + l] = si;
+        }
+        // the element-wise operands of this wave's block: n = 16 nb + c16, m = m0 + 16 kh + 4 q + s
+        float2 ex[4], ev1[4], ev2[4], esy[4], ey[4];
+        float eid[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long ix = base + 64ll * (m0 + 16 * kh + 4 * q + s);
+            ex[s] = d.X[ix]; ev1[s] = d.V1[ix]; ev2[s] = d.V2[ix]; esy[s] = d.subY[ix]; ey[s] = d.Y[ix]; eid[s] = d.invD[ix];
+        }
+        __syncthreads();
+        f32x4 xr = kh ? ar[1] : ar[0], xi = kh ? ai[1] : ai[0];
+        {
+            const f32x4 *x4 = reinterpret_cast<const f32x4 *>(xch);
+            const f32x4 orr = x4[(w * 2 + 0) * 64 + l], oi = x4[(w * 2 + 1) * 64 + l];
+            xr += orr; xi += oi;
+        }
+        half4 kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long ix = base + 64ll * (m0 + 16 * kh + 4 * q + s);
+            const float2 xs = make_float2(xr[s] * sxs, xi[s] * sxs);
+            // V2 <- (1 - cc)(V2 - rho (X - Xs))                       (:61 + :65, C == -V2)
+            const float2 v2 = make_float2(omc * (ev2[s].x - rho * (ex[s].x - xs.x)), omc * (ev2[s].y - rho * (ex[s].y - xs.y)));
+            // X <- iK1 (V1 + rho Y + subY + V2 + rho C + rho Xs)      (:38-40)
+            const float2 x = make_float2((ev1[s].x + rho * ey[s].x + esy[s].x + omr * v2.x + rho * xs.x) * eid[s],
+                                         (ev1[s].y + rho * ey[s].y + esy[s].y + omr * v2.y + rho * xs.y) * eid[s]);
+            const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);                  // (:43)
+            const float2 v1 = make_float2(ev1[s].x + rho * (ey[s].x - x.x), ev1[s].y + rho * (ey[s].y - x.y));   // (:64)
+            d.V2[ix] = v2; d.X[ix] = x; d.V1[ix] = v1;
+            const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+            v2mx = fmaxf(v2mx, fmaxf(fabsf(v2.x), fabsf(v2.y)));
+            xmx = fmaxf(xmx, fmaxf(fabsf(x.x), fabsf(x.y)));
+            v1mx = fmaxf(v1mx, fmaxf(fabsf(v1.x), fabsf(v1.y)));
+            zmx = fmaxf(zmx, fmaxf(fabsf(zn.x), fabsf(zn.y)));
+            kmx = fmaxf(kmx, fmaxf(fabsf(kk.x), fabsf(kk.y)));
+            _Float16 h, lo;
+            fsplit(kk.x * sk, h, lo); kf[0][s] = h; kf[1][s] = lo;
+            fsplit(kk.y * sk, h, lo); kf[2][s] = h; kf[3][s] = lo;
+        }
+        __syncthreads();                        // every wave has read its partial sums: the exchange area is free
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<half4 *>(xch + ((nb * 4 + p) * 64 + l) * 16 + kh * 8) = kf[p];
+        __syncthreads();
+        // next tile on its way while phase B runs (the last tile is fetched again: unconditional loads)
+        gload(tile0 + min(i + 1, tpw - 1));
+        // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
+#pragma unroll
+        for (int gb = 0; gb < GB; ++gb) {
+            const int gq = (16 * GB * w + 16 * gb + c16) >> 2;
+            uint4 bf[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t o[4];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const unsigned char *a = tile + (p * 8 + 4 * hh + q) * ROWB + gq * 32;
+                    const uint4 r01 = *reinterpret_cast<const uint4 *>(a), r23 = *reinterpret_cast<const uint4 *>(a + 16);
+                    const uint32_t w0 = cw ? r01.y : r01.x, w1 = cw ? r01.w : r01.z;
+                    const uint32_t w2 = cw ? r23.y : r23.x, w3 = cw ? r23.w : r23.z;
+                    o[2 * hh] = __builtin_amdgcn_perm(w1, w0, perm_sel);
+                    o[2 * hh + 1] = __builtin_amdgcn_perm(w3, w2, perm_sel);
+                }
+                bf[p] = uint4{o[0], o[1], o[2], o[3]};
+            }
+#pragma unroll
+            for (int n2 = 0; n2 < 4; ++n2) {
+                uint4 kq[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) kq[p] = *reinterpret_cast<const uint4 *>(xch + ((n2 * 4 + p) * 64 + l) * 16);
+                // re += Br kr + Bi ki ; im += Br ki - Bi kr
+                pr[gb][n2] = mma(bf[0], kq[0], pr[gb][n2]); pr[gb][n2] = mma(bf[0], kq[1], pr[gb][n2]);
+                pr[gb][n2] = mma(bf[1], kq[0], pr[gb][n2]);
+                pr[gb][n2] = mma(bf[2], kq[2], pr[gb][n2]); pr[gb][n2] = mma(bf[2], kq[3], pr[gb][n2]);
+                pr[gb][n2] = mma(bf[3], kq[2], pr[gb][n2]);
+                pi[gb][n2] = mma(bf[0], kq[2], pi[gb][n2]); pi[gb][n2] = mma(bf[0], kq[3], pi[gb][n2]);
+                pi[gb][n2] = mma(bf[1], kq[2], pi[gb][n2]);
+                const uint4 nh = negu(kq[0]), nl = negu(kq[1]);
+                pi[gb][n2] = mma(bf[2], nh, pi[gb][n2]); pi[gb][n2] = mma(bf[2], nl, pi[gb][n2]);
+                pi[gb][n2] = mma(bf[3], nh, pi[gb][n2]);
+            }
+        }
+        __syncthreads();                        // the tile and the k fragments are dead
+        sstore();
+        __syncthreads();
+    }
+
+    // ---- partial sums of this column range: Ppart[t][part][n + 64 g]
+    float2 *po = d.Ppart + ((long long)t * d.parts + part) * (64ll * G2);
+#pragma unroll
+    for (int gb = 0; gb < GB; ++gb)
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int g = 16 * GB * w + 16 * gb + 4 * q + s;
+                po[64ll * g + 16 * n2 + c16] = make_float2(pr[gb][n2][s] * sp, pi[gb][n2][s] * sp);
+            }
+    // ---- operand maxima of the next consumers, overflow flag of the k scale
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmx = fmaxf(kmx, __shfl_xor(kmx, o)); xmx = fmaxf(xmx, __shfl_xor(xmx, o)); v1mx = fmaxf(v1mx, __shfl_xor(v1mx, o));
+        zmx = fmaxf(zmx, __shfl_xor(zmx, o)); v2mx = fmaxf(v2mx, __shfl_xor(v2mx, o));
+    }
+    if (l == 0) {
+        if (d.kmax_out) atomicMax(&d.kmax_out[t], __float_as_uint(kmx));
+        if (d.xmax) atomicMax(&d.xmax[t], __float_as_uint(xmx));
+        if (d.v1max) atomicMax(&d.v1max[t], __float_as_uint(v1mx));
+        if (d.zmax) atomicMax(&d.zmax[t], __float_as_uint(zmx));
+        if (d.v2max) atomicMax(&d.v2max[t], __float_as_uint(v2mx));
+        if (d.ovf && !(kmx * sk < 60000.f)) atomicOr(d.ovf, 1u);
+    }
+}
+
+}  // namespace
+
+bool fused_shape_ok(int N, int M, int G2, int parts)
+{
+    return N == 64 && G2 == 512 && parts > 0 && M % (32 * parts) == 0;
+}
+
+size_t fused_bytes(int M, int G2, int nB, int batch, int parts)
+{
+    return rnd256((size_t)nB * (M / 32) * 16 * G2 * sizeof(uint4)) + rnd256((size_t)batch * (G2 / 32) * 1024 * sizeof(uint4)) +
+           rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256(sizeof(uint32_t));
+}
+
+int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts)
+{
+    f.parts = parts;
+    f.sBf = (long long)(M / 32) * 16 * G2;
+    f.sAS = (long long)(G2 / 32) * 1024;
+    f.Bf = ar.get<uint4>((size_t)nB * f.sBf);
+    f.ASp = ar.get<uint4>((size_t)batch * f.sAS);
+    f.Ppart = ar.get<float2>((size_t)batch * parts * 64 * G2);
+    f.ovf = ar.get<uint32_t>(1);
+    JSTSP_REQUIRE(f.Bf && f.ASp && f.Ppart && f.ovf, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
+    return 0;
+}
+
+int fused_pack_b(jstsp_ctx *ctx, const FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax)
+{
+    const long long n = (long long)(M / 32) * 16 * (G2 / 4);
+    hipLaunchKernelGGL(pack_bf_kernel, dim3((unsigned)((n + 255) / 256), nB), dim3(256), 0, ctx->stream, B, sBt, G2, M, bmax, 1,
+                       f.Bf, f.sBf);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int batch, const uint32_t *wmax)
+{
+    hipLaunchKernelGGL(pack_as_kernel, dim3((G2 / 32), batch), dim3(256), 0, ctx->stream, W, sWt, G2, wmax, f.ASp, f.sAS);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d)
+{
+    JSTSP_REQUIRE(fused_shape_ok(64, d.M, d.G2, d.parts), JSTSP_E_UNSUPPORTED, "fused pass: shape");
+    constexpr int GB = 4;
+    const size_t sh = (size_t)32 * (128 * GB * 8 + FPAD) + 16384;
+    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
+    prof_begin(ctx, "fused_pass");
+    hipLaunchKernelGGL(fused_pass_kernel<GB>, dim3(grid), dim3(512), sh, ctx->stream, d);
+    prof_end(ctx, "fused_pass");
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int fused_poison(jstsp_ctx *ctx, const FusedWS &f, float2 *S, long long n)
+{
+    hipLaunchKernelGGL(poison_kernel, dim3(64), dim3(256), 0, ctx->stream, f.ovf, S, n);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int fused_reduce(jstsp_ctx *ctx, const FusedWS &f, int G2, int batch, float2 *Tc)
+{
+    const long long n4 = 64ll * G2 / 2;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n4 + 255) / 256), batch), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float4 *>(f.Ppart), f.parts, n4, reinterpret_cast<float4 *>(Tc));
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace jstsp

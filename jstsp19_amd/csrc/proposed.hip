@@ -171,6 +171,11 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                                   : rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + hinv_bytes(Gr, nA)) +
                 (pinv_fits(G2, M) ? rnd256((size_t)nB * M * G2 * sizeof(float2))
                                   : rnd256((size_t)nB * G2 * G2 * sizeof(float2)) + hinv_bytes(G2, nB));
+    // one pass over the dictionary per iteration (fused.hip); JSTSP_FUSED_PARTS = column ranges per problem
+    const int fparts = std::max(1, getenv("JSTSP_FUSED_PARTS") ? atoi(getenv("JSTSP_FUSED_PARTS")) : 8);
+    const bool want_fused = (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : false) && approx && want_ce &&
+                            Imax > 1 && fused_shape_ok(N, M, G2, fparts);
+    if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);
     if (memspace == JSTSP_HOST) {
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
                 rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
@@ -319,6 +324,17 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                       (getenv("JSTSP_ZFLY") ? atoi(getenv("JSTSP_ZFLY")) != 0 : true) &&
                       (getenv("JSTSP_PZ") ? atoi(getenv("JSTSP_PZ")) != 0 : true);     // (needs the (I - Q) Z form)
     float2 *Zbuf[2] = {w.Zb, w.Zb2};            // svt argument of iteration it lives in Zbuf[it & 1]
+    // Fused pass (fused.hip): after the gradient step of iteration it, ONE kernel forms Xs = A S B, the V2 / X / V1 / k
+    // updates of :61-65 and of the next iteration's :38-43, and the first factor K B^H of the next :47 - the dictionary
+    // is read once per iteration instead of twice.  The next iteration then starts at the gradient step.
+    const bool fusedp = want_fused && zfly && !overlap && !svt_skip;
+    FusedWS fw;
+    if (fusedp) {
+        JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts));
+        JSTSP_TRY(fused_pack_b(ctx, fw, B, strideB, G2, M, nB, w.Bs.bmax));
+        JSTSP_HIP(hipMemsetAsync(fw.ovf, 0, sizeof(uint32_t), sm));
+    }
+    bool passed = false;                        // X, V1, k-partials of this iteration came from the previous pass
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
         // every operand maximum of this iteration starts from zero (one memset instead of four)
@@ -328,13 +344,15 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             const size_t boff = (size_t)(it & 1) * 8 * (size_t)batch;
             w.kmax = kmax0 + boff; w.nmax = w.kmax + batch; w.zmax = w.kmax + 4 * (size_t)batch;
             w.wmax = w.kmax + 5 * (size_t)batch; w.pmax = w.kmax + 6 * (size_t)batch;
-            JSTSP_HIP(hipMemsetAsync(w.kmax, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
+            if (!passed) JSTSP_HIP(hipMemsetAsync(w.kmax, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
         } else if (w.h2g) JSTSP_HIP(hipMemsetAsync(w.pmax, 0, 2 * (size_t)batch * sizeof(uint32_t), sm));
         int apply_no = 0;
         // -- sub 1: Y = svt(X - V1/rho, tau_Y/rho) = Z - Q Z                                 (:35)
         if (it > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gxv, 0));
-        if (fz) {
+        if (passed) {
+            // sub 1, sub 2, k and the V1 update of this iteration were applied by the previous iteration's pass
+        } else if (fz) {
             // Y = Z - Q Z with the X / K / V1 updates (and the next Z) applied to the tile in registers (:35-43,:64)
             // Y = Z - Q Z as (I - Q) Z: the beta-term form reads the Z tile a second time from HBM (PMC: +0.5 GB)
             static const bool pz = getenv("JSTSP_PZ") ? atoi(getenv("JSTSP_PZ")) != 0 : true;
@@ -370,6 +388,11 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                                         w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
                 JSTSP_HIP(hipEventRecord(ev_gxv, s1));
                 JSTSP_TRY(svt_prepare(ctx, w.gz, w.X, w.prm, nullptr, true, w.zmax, svt_skip, nullptr, true));
+                if (fusedp) {       // Y of the next iteration = (I - Q) Z, consumed by the pass at the end of this one
+                    JSTSP_TRY(launch_eye_minus(ctx, N, batch, w.gz.Q, w.gz.Q));
+                    JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
+                    JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{w.Zb, snm, N}, w.Y, snm, N));
+                }
             } else
             JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr, svt_skip));
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
@@ -382,7 +405,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
         //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
-        if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
+        if (passed) {
+            JSTSP_TRY(fused_reduce(ctx, fw, G2, batch, w.Tc));
+        } else if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
             JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, M, batch, Mat{w.ZK, snm, N}, Mat{PB, strideB ? (long long)M * G2 : 0, M},
                            w.Tc, sng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
         } else if (w.h2) {
@@ -440,6 +465,19 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         } else
         JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N));
         if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(sm, ev_gv2, 0));
+        passed = false;
+        if (fusedp && it + 1 < Imax) {
+            // the pass writes the operand maxima of iteration it + 1 (k, X, V1, next Z): zero that block now
+            uint32_t *nx = kmax0 + (size_t)((it + 1) & 1) * 8 * (size_t)batch;
+            JSTSP_HIP(hipMemsetAsync(nx, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
+            JSTSP_TRY(fused_pack_as(ctx, fw, w.W, sng, G2, batch, w.wmax));
+            FusedDesc fd{fw.Bf, strideB ? fw.sBf : 0, w.Bs.bmax, strideB ? 1 : 0, fw.ASp, fw.sAS, w.wmax, w.kmax,
+                         w.X, w.V1, w.V2, subY, w.Y, w.invD, snm, w.prm, fw.Ppart,
+                         nx, nx + batch, nx + 2 * (size_t)batch, nx + 4 * (size_t)batch, w.nmax + 2 * (size_t)batch, fw.ovf,
+                         M, G2, batch, fparts};
+            JSTSP_TRY(launch_fused_pass(ctx, fd));
+            passed = true;
+        } else
         if (w.h2) {
             static const bool apack = getenv("JSTSP_H2_APACK") ? atoi(getenv("JSTSP_H2_APACK")) != 0 : true;
             if (apack)      // a(i, k = g) = W[i + N g] in fragment order, once per iteration instead of once per j-tile
@@ -475,6 +513,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         }
     }
     if (want_ce && Imax > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_ce, 0));
+    if (fusedp) JSTSP_TRY(fused_poison(ctx, fw, w.S, (long long)(batch * g)));
 
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), w.S, batch * g, memspace));
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), w.Y, batch * nm, memspace));

@@ -104,4 +104,35 @@ template <class T> int stage_out(jstsp_ctx *ctx, T *dst, const T *dev, size_t n,
 }
 inline size_t rnd256(size_t b) { return (b + 255) & ~size_t(255); }
 
+// ---- one pass over the dictionary per iteration (fused.hip) ---------------------------------
+struct FusedWS {
+    uint4 *Bf = nullptr; long long sBf = 0;       // tile images of B, uint4 per problem
+    uint4 *ASp = nullptr; long long sAS = 0;      // B-operand fragments of (A S)^T, re-packed every iteration
+    float2 *Ppart = nullptr;                      // [batch][parts][N x G2] partial sums of K B^H
+    uint32_t *ovf = nullptr;                      // raised when a k entry left the f16 range of its scale
+    int parts = 0;
+};
+struct FusedDesc {
+    const uint4 *Bf; long long sBf;               // 0: one dictionary for the batch
+    const uint32_t *bmax; int sbmax;
+    const uint4 *ASp; long long sAS;
+    const uint32_t *wmax;                         // [batch] max|A S|
+    const uint32_t *kmax_prev;                    // [batch] max|k| of the previous iteration
+    float2 *X, *V1, *V2;                          // N x M state, updated in place
+    const float2 *subY, *Y; const float *invD;
+    long long snm;
+    const TrialParams *prm;
+    float2 *Ppart;
+    uint32_t *kmax_out, *xmax, *v1max, *zmax, *v2max, *ovf;
+    int M, G2, batch, parts;
+};
+bool fused_shape_ok(int N, int M, int G2, int parts);
+size_t fused_bytes(int M, int G2, int nB, int batch, int parts);
+int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts);
+int fused_pack_b(jstsp_ctx *ctx, const FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax);
+int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int batch, const uint32_t *wmax);
+int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d);
+int fused_reduce(jstsp_ctx *ctx, const FusedWS &f, int G2, int batch, float2 *Tc);
+int fused_poison(jstsp_ctx *ctx, const FusedWS &f, float2 *S, long long n);    // NaN into S if a k scale overflowed
+
 }  // namespace jstsp
