@@ -310,6 +310,10 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                     const float4 y = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
                     const int gj = n0 + wj * (BN / 2) + nb * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * lhi + (odd ? 1 : 0);
                     if (gi2 >= d.m || gj >= d.n) continue;
+                    if (d.epi_store_c == 2) {       // Y only (the fused pass applies the updates): nothing else is touched
+                        *reinterpret_cast<float4 *>(Cp + gi2 + (long long)gj * d.ldc) = y;
+                        continue;
+                    }
                     const long long ix = (long long)t * d.sCt + gi2 + (long long)gj * d.ldc;
                     float4 v1 = *reinterpret_cast<const float4 *>(d.e_rw0 + ix);
                     const float4 v2 = *reinterpret_cast<const float4 *>(d.e_r0 + ix);
@@ -375,6 +379,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                         Cp[gi + (long long)gj * d.ldc] = o;
                     } else if (EPI == EPI_UPDATE_X) {
                         // o = Y
+                        if (d.epi_store_c == 2) { Cp[gi + (long long)gj * d.ldc] = o; continue; }
                         const float rho = d.prm[t].rho, ir = d.prm[t].irho;
                         float2 v1 = d.e_rw0[ix];
                         const float2 v2 = d.e_r0[ix], xs = d.e_r2[ix], sy = d.e_r3[ix];

@@ -139,7 +139,7 @@ struct GemmDesc {
     float2 *e_rw0, *e_w1, *e_w2, *e_w3;     // in/out and output arrays
     const float2 *e_r0, *e_r1, *e_r2, *e_r3;
     const float *e_f0;
-    int epi_store_c;                        // EPI_UPDATE_X: also store Y into C
+    int epi_store_c;                        // EPI_UPDATE_X: 1 also store Y into C; 2 store Y ONLY (no update applied)
     uint32_t *amax_x, *amax_v1, *amax_z;    // EPI_UPDATE_X: optional [batch] maxima of the new X, V1, Znext
     uint32_t *amax_out;                     // optional [batch]: atomicMax of max(|re|,|im|) (float bits) over the
                                             // stored product (EPI_NONE) / over K (EPI_UPDATE_X); caller zeroes it

@@ -27,7 +27,8 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int FPAD = 64;          // bytes of padding per LDS row (4 m-quads of one plane then hit 4 different bank groups)
+constexpr int FPAD = 128;         // bytes of padding per LDS row: row stride = 2 (mod 4) 64-byte slots, for which the four
+                                  // 16-lane groups of the phase-A ds_read_b128 each cover all 64 banks once
 constexpr int KBACK = 4;          // the k scale is taken 2^4 below the one its previous maximum would give (see fused_pass_kernel)
 
 // e such that amax * 2^e lies in [2^13, 2^14)   (as hgemm.hip)
@@ -42,46 +43,45 @@ __device__ __forceinline__ void fsplit(float x, _Float16 &h, _Float16 &l)
     h = (_Float16)x;
     l = (_Float16)(x - (float)h);
 }
-__device__ __forceinline__ half8 h8(uint4 u) { return *reinterpret_cast<half8 *>(&u); }
-__device__ __forceinline__ uint4 negu(uint4 u)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // native vectors: arrays of them stay in registers
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));      // (arrays of HIP's uint4 struct were kept in scratch)
+__device__ __forceinline__ u32x4 negu(u32x4 u) { return u ^ 0x80008000u; }
+__device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c)
 {
-    u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
-    return u;
-}
-__device__ __forceinline__ f32x4 mma(uint4 a, uint4 b, f32x4 c)
-{
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(h8(a), h8(b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
 
-// ---- B -> tile images: out[t][tile][plane 4][mq 8][gq G2/4][r 4][c 4] halves, m = 32 tile + 4 mq + r, g = 4 gq + c
+// ---- B -> tile images.  A tile is 32 columns m of B, all G2 rows, as halves in micro-blocks [4 m][8 g] (64 bytes): one
+//      row (16 bytes: 8 consecutive g of one m) is a phase-A fragment, a column of four halves a phase-B fragment piece.
+//      16-byte chunk (p, mq, g8, r) = row r of micro-block (m quad mq, g octet g8) of plane p.  In HBM the chunks are ordered
+//      [wave w][block gb][p][mq][g8 & 1][r] with g8 = 2 (GB w + gb) + (g8 & 1), GB = G2 / 128: the 4 KiB a wave fetches per
+//      refill step (its own 16 rows g of phase B) are contiguous.
 __global__ __launch_bounds__(256) void pack_bf_kernel(const float2 *B, long long sBt, int G2, int M, const uint32_t *bmax,
                                                       int sbmax, uint4 *out, long long sOut)
 {
     const int t = blockIdx.y;
-    const int GQ = G2 >> 2;
-    const long long per_tile = 16ll * GQ;                   // 8 mq * GQ gq * 2 row pairs
+    const int G8 = G2 >> 3;
+    const long long per_tile = 32ll * G8;                   // 8 mq * 4 r * G8
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)(M / 32) * per_tile) return;
     const int tile = (int)(idx / per_tile);
     int rem = (int)(idx % per_tile);
-    const int rh = rem & 1; rem >>= 1;
-    const int gq = rem % GQ, mq = rem / GQ;
+    const int g8 = rem % G8; rem /= G8;                     // g fastest: coalesced reads of B
+    const int r = rem & 3, mq = rem >> 2;
+    const int m = tile * 32 + 4 * mq + r;
     const float s = ldexpf(1.f, fscale_exp(bmax[(long long)t * sbmax]));
     half8 pl[4];
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int m = tile * 32 + 4 * mq + 2 * rh + rr;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float2 x = B[(long long)t * sBt + (4 * gq + c) + (long long)G2 * m];
-            _Float16 h, l;
-            fsplit(x.x * s, h, l); pl[0][4 * rr + c] = h; pl[1][4 * rr + c] = l;
-            fsplit(x.y * s, h, l); pl[2][4 * rr + c] = h; pl[3][4 * rr + c] = l;
-        }
+    for (int c = 0; c < 8; ++c) {
+        const float2 x = B[(long long)t * sBt + (8 * g8 + c) + (long long)G2 * m];
+        _Float16 h, l;
+        fsplit(x.x * s, h, l); pl[0][c] = h; pl[1][c] = l;
+        fsplit(x.y * s, h, l); pl[2][c] = h; pl[3][c] = l;
     }
     uint4 *o = out + (long long)t * sOut + (long long)tile * (16ll * G2);
+    const int blk = g8 >> 1, g8i = g8 & 1;                  // blk = GB w + gb
 #pragma unroll
-    for (int p = 0; p < 4; ++p) o[((long long)(p * 8 + mq) * GQ + gq) * 2 + rh] = *reinterpret_cast<uint4 *>(&pl[p]);
+    for (int p = 0; p < 4; ++p) o[(((long long)(blk * 4 + p) * 8 + mq) * 2 + g8i) * 4 + r] = *reinterpret_cast<uint4 *>(&pl[p]);
 }
 
 // ---- W = A S (N x G2, column-major) -> B-operand fragments of (A S)^T: out[t][ks G2/32][nb 4][plane 4][lane 64],
@@ -131,14 +131,14 @@ __global__ __launch_bounds__(256) void poison_kernel(const uint32_t *ovf, float2
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) S[i] = make_float2(q, q);
 }
 
-template <int GB>
+// DBG (timing experiments only, results are wrong): 1 skips the phase-A products, 2 the element-wise loads / stores,
+// 4 the phase-B products, 8 the tile refill
+template <int GB, int DBG>
 __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 {
     constexpr int G2 = 128 * GB;
-    constexpr int ROWB = G2 * 8 + FPAD;        // bytes of one LDS row: (G2/4) micro-blocks of 32 B
+    constexpr int ROWB = G2 * 8 + FPAD;        // bytes of one LDS row: (G2/8) micro-blocks of 64 B
     constexpr int TILEB = 32 * ROWB;           // 4 planes x 8 m-quads
-    constexpr int CPT = G2 / 32;               // 16-byte chunks per thread per tile
-    constexpr int CPR = G2 / 2;                // chunks per row
     constexpr int KSH = G2 / 64;               // 32-wide k-steps per g-half
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned char *tile = lds;
@@ -165,21 +165,11 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     const float sxs = ldexpf(1.f, -(eb + ew)), sk = ldexpf(1.f, ek), sp = ldexpf(1.f, -(eb + ek));
     const float rho = prm.rho, ir = prm.irho, omc = 1.f - prm.c_coef, omr = 1.f - rho, omir = 1.f - ir;
 
-    const uint4 *bsrc = d.Bf + (long long)t * d.sBf;
-    const long long tile_u4 = 16ll * G2;
-    uint4 pf[CPT];
-    auto gload = [&](int tl) {
-        const uint4 *s = bsrc + (long long)tl * tile_u4 + tid;
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) pf[c] = s[512 * c];
-    };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            const int ch = tid + 512 * c;
-            *reinterpret_cast<uint4 *>(tile + ch * 16 + (ch / CPR) * FPAD) = pf[c];
-        }
-    };
+    // refill of the tile: wave w owns the rows g of its phase-B range, block gb of them = 256 chunks, 4 per lane (plane p = c)
+    const u32x4 *const bt = reinterpret_cast<const u32x4 *>(d.Bf) + (long long)t * d.sBf + (long long)tile0 * (16ll * G2);
+    const uint32_t boff = (uint32_t)(w * GB) * 256u + l;
+    constexpr uint32_t tile_u4 = 16u * G2;
+    unsigned char *rdst = tile + ((l >> 3) & 7) * ROWB + (2 * GB * w + ((l >> 2) & 1)) * 64 + (l & 3) * 16;   // + p 8 ROWB + gb 128
 
     f32x4 pr[GB][4], pi[GB][4];
 #pragma unroll
@@ -188,49 +178,70 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         for (int n2 = 0; n2 < 4; ++n2) { pr[gb][n2] = f32x4{0.f, 0.f, 0.f, 0.f}; pi[gb][n2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     float kmx = 0.f, xmx = 0.f, v1mx = 0.f, zmx = 0.f, v2mx = 0.f;
 
-    const long long base = (long long)t * d.snm + 16 * nb + c16;      // + 64 m
-    const uint4 *asp = d.ASp + (long long)t * d.sAS + (long long)(kh * KSH) * 1024 + nb * 256 + l;
+    // uniform per-problem pointers (SGPR pairs) + 32-bit lane offsets: 64-bit lane addresses would not fit next to P
+    float2 *const Xt = d.X + (long long)t * d.snm, *const V1t = d.V1 + (long long)t * d.snm, *const V2t = d.V2 + (long long)t * d.snm;
+    const float2 *const sYt = d.subY + (long long)t * d.snm, *const Yt = d.Y + (long long)t * d.snm;
+    const float *const iDt = d.invD + (long long)t * d.snm;
+    const uint32_t ebase = 16 * nb + c16 + 64 * (16 * kh + 4 * q);     // + 64 (m0 + s)
+    const u32x4 *const ast = reinterpret_cast<const u32x4 *>(d.ASp) + (long long)t * d.sAS;
+    const uint32_t aoff = (uint32_t)(kh * KSH) * 1024u + nb * 256 + l;
     const int perm_sel = (c16 & 1) ? 0x07060302 : 0x05040100;
     const bool cw = (c16 & 2) != 0;
 
-    gload(tile0);
-    sstore();
+    {
+#pragma unroll
+        for (int gb = 0; gb < GB; ++gb)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = bt[boff + gb * 256 + c * 64];
+    }
     __syncthreads();
 
     for (int i = 0; i < tpw; ++i) {
         const int m0 = (tile0 + i) * 32;
         // ================= phase A: Xs^T(tile) = B^T (A S)^T, this wave: n-block nb, g-half kh, both m-blocks
+        // (A S) fragments: requested one k-step (24 products) ahead; B^T fragments of the next
+        // (k-step, m-block) are read from LDS before the products of the current one are issued
         f32x4 ar[2], ai[2];
         ar[0] = ar[1] = ai[0] = ai[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        uint4 wf[4];
+        if (!(DBG & 1)) {
+            u32x4 wr[2][4], bfb[2][4];
+            // ONE running pointer, advanced opaquely per k-step: with constant offsets the compiler materialises (and spills) a
+            // 64-bit address per (k-step, plane) outside the tile loop
+            const u32x4 *ap = ast + aoff;
+            asm volatile("" : "+v"(ap));
 #pragma unroll
-        for (int p = 0; p < 4; ++p) wf[p] = asp[p * 64];
-#pragma unroll 2
-        for (int ks = 0; ks < KSH; ++ks) {
-            uint4 wn[4];
-            const uint4 *nx = asp + (long long)min(ks + 1, KSH - 1) * 1024;
+            for (int p = 0; p < 4; ++p) wr[0][p] = ap[p * 64];
+            const int goff0 = (kh * (G2 / 2) + 8 * q) * 8 + (c16 & 3) * 16;      // micro-block (m quad, g octet), row m & 3
+            const unsigned char *arow = tile + (c16 >> 2) * ROWB + goff0;         // + p 8 ROWB + mb 4 ROWB + ks 256
 #pragma unroll
-            for (int p = 0; p < 4; ++p) wn[p] = nx[p * 64];
-            const uint4 nwi_h = negu(wf[2]), nwi_l = negu(wf[3]);
-            const int goff = (kh * (G2 / 2) + 32 * ks + 8 * q) * 8 + (c16 & 3) * 8;
+            for (int p = 0; p < 4; ++p) bfb[0][p] = *reinterpret_cast<const u32x4 *>(arow + p * 8 * ROWB);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int mq = 4 * mb + (c16 >> 2);
-                uint4 bf[4];
+            for (int st = 0; st < 2 * KSH; ++st) {
+                const int ks = st >> 1, mb = st & 1;
+                if (mb == 0 && ks + 1 < KSH) {
+                    ap += 1024;
+                    asm volatile("" : "+v"(ap));
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const unsigned char *a = tile + (p * 8 + mq) * ROWB + goff;
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(a), hi = *reinterpret_cast<const uint2 *>(a + 32);
-                    bf[p] = uint4{lo.x, lo.y, hi.x, hi.y};
+                    for (int p = 0; p < 4; ++p) wr[(ks + 1) & 1][p] = ap[p * 64];
                 }
-                // re += Br Wr - Bi Wi ; im += Br Wi + Bi Wr   (h h + h l + l h each)
-                ar[mb] = mma(bf[0], wf[0], ar[mb]); ar[mb] = mma(bf[0], wf[1], ar[mb]); ar[mb] = mma(bf[1], wf[0], ar[mb]);
-                ar[mb] = mma(bf[2], nwi_h, ar[mb]); ar[mb] = mma(bf[2], nwi_l, ar[mb]); ar[mb] = mma(bf[3], nwi_h, ar[mb]);
-                ai[mb] = mma(bf[0], wf[2], ai[mb]); ai[mb] = mma(bf[0], wf[3], ai[mb]); ai[mb] = mma(bf[1], wf[2], ai[mb]);
-                ai[mb] = mma(bf[2], wf[0], ai[mb]); ai[mb] = mma(bf[2], wf[1], ai[mb]); ai[mb] = mma(bf[3], wf[0], ai[mb]);
-            }
+                if (st + 1 < 2 * KSH) {
+                    const int ks1 = (st + 1) >> 1, mb1 = (st + 1) & 1;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) wf[p] = wn[p];
+                    for (int p = 0; p < 4; ++p)
+                        bfb[(st + 1) & 1][p] = *reinterpret_cast<const u32x4 *>(arow + (p * 8 + 4 * mb1) * ROWB + ks1 * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 *wf = wr[ks & 1], *bf = bfb[st & 1];
+                const u32x4 nwi_h = negu(wf[2]), nwi_l = negu(wf[3]);
+                // re += Br Wr - Bi Wi ; im += Br Wi + Bi Wr   (h h + h l + l h each)
+                ar[mb] = mma(bf[0], wf[0], ar[mb]); ai[mb] = mma(bf[0], wf[2], ai[mb]);
+                ar[mb] = mma(bf[0], wf[1], ar[mb]); ai[mb] = mma(bf[0], wf[3], ai[mb]);
+                ar[mb] = mma(bf[1], wf[0], ar[mb]); ai[mb] = mma(bf[1], wf[2], ai[mb]);
+                ar[mb] = mma(bf[2], nwi_h, ar[mb]); ai[mb] = mma(bf[2], wf[0], ai[mb]);
+                ar[mb] = mma(bf[2], nwi_l, ar[mb]); ai[mb] = mma(bf[2], wf[1], ai[mb]);
+                ar[mb] = mma(bf[3], nwi_h, ar[mb]); ai[mb] = mma(bf[3], wf[0], ai[mb]);
+            }
         }
         // the two g-halves meet: wave (nb, kh) keeps m-block kh and hands m-block 1 - kh to wave (nb, 1 - kh)
         {
@@ -245,8 +256,9 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         float eid[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const long long ix = base + 64ll * (m0 + 16 * kh + 4 * q + s);
-            ex[s] = d.X[ix]; ev1[s] = d.V1[ix]; ev2[s] = d.V2[ix]; esy[s] = d.subY[ix]; ey[s] = d.Y[ix]; eid[s] = d.invD[ix];
+            const uint32_t ix = ebase + 64u * (uint32_t)(m0 + s);
+            if (DBG & 2) { ex[s] = ev1[s] = ev2[s] = esy[s] = ey[s] = make_float2(1.f, 1.f); eid[s] = 1.f; continue; }
+            ex[s] = Xt[ix]; ev1[s] = V1t[ix]; ev2[s] = V2t[ix]; esy[s] = sYt[ix]; ey[s] = Yt[ix]; eid[s] = iDt[ix];
         }
         __syncthreads();
         f32x4 xr = kh ? ar[1] : ar[0], xi = kh ? ai[1] : ai[0];
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         half4 kf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const long long ix = base + 64ll * (m0 + 16 * kh + 4 * q + s);
+            const uint32_t ix = ebase + 64u * (uint32_t)(m0 + s);
             const float2 xs = make_float2(xr[s] * sxs, xi[s] * sxs);
             // V2 <- (1 - cc)(V2 - rho (X - Xs))                       (:61 + :65, C == -V2)
             const float2 v2 = make_float2(omc * (ev2[s].x - rho * (ex[s].x - xs.x)), omc * (ev2[s].y - rho * (ex[s].y - xs.y)));
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
                                          (ev1[s].y + rho * ey[s].y + esy[s].y + omr * v2.y + rho * xs.y) * eid[s]);
             const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);                  // (:43)
             const float2 v1 = make_float2(ev1[s].x + rho * (ey[s].x - x.x), ev1[s].y + rho * (ey[s].y - x.y));   // (:64)
-            d.V2[ix] = v2; d.X[ix] = x; d.V1[ix] = v1;
+            if (!(DBG & 2)) { V2t[ix] = v2; Xt[ix] = x; V1t[ix] = v1; }
             const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
             v2mx = fmaxf(v2mx, fmaxf(fabsf(v2.x), fabsf(v2.y)));
             xmx = fmaxf(xmx, fmaxf(fabsf(x.x), fabsf(x.y)));
@@ -283,47 +295,62 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         for (int p = 0; p < 4; ++p)
             *reinterpret_cast<half4 *>(xch + ((nb * 4 + p) * 64 + l) * 16 + kh * 8) = kf[p];
         __syncthreads();
-        // next tile on its way while phase B runs (the last tile is fetched again: unconditional loads)
-        gload(tile0 + min(i + 1, tpw - 1));
-        // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
+        // the next tile (the last one is fetched again: unconditional loads) replaces this one block by block: only this
+        // wave reads its rows g in phase B, so block gb is overwritten as soon as its products are issued
+        const uint32_t noff = boff + (uint32_t)min(i + 1, tpw - 1) * tile_u4;        // (< 2^32 uint4: 64 GiB per problem)
+        u32x4 rf[2][4];
+        if (!(DBG & 8)) {
 #pragma unroll
-        for (int gb = 0; gb < GB; ++gb) {
-            const int gq = (16 * GB * w + 16 * gb + c16) >> 2;
-            uint4 bf[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                uint32_t o[4];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const unsigned char *a = tile + (p * 8 + 4 * hh + q) * ROWB + gq * 32;
-                    const uint4 r01 = *reinterpret_cast<const uint4 *>(a), r23 = *reinterpret_cast<const uint4 *>(a + 16);
-                    const uint32_t w0 = cw ? r01.y : r01.x, w1 = cw ? r01.w : r01.z;
-                    const uint32_t w2 = cw ? r23.y : r23.x, w3 = cw ? r23.w : r23.z;
-                    o[2 * hh] = __builtin_amdgcn_perm(w1, w0, perm_sel);
-                    o[2 * hh + 1] = __builtin_amdgcn_perm(w3, w2, perm_sel);
-                }
-                bf[p] = uint4{o[0], o[1], o[2], o[3]};
-            }
-#pragma unroll
-            for (int n2 = 0; n2 < 4; ++n2) {
-                uint4 kq[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) kq[p] = *reinterpret_cast<const uint4 *>(xch + ((n2 * 4 + p) * 64 + l) * 16);
-                // re += Br kr + Bi ki ; im += Br ki - Bi kr
-                pr[gb][n2] = mma(bf[0], kq[0], pr[gb][n2]); pr[gb][n2] = mma(bf[0], kq[1], pr[gb][n2]);
-                pr[gb][n2] = mma(bf[1], kq[0], pr[gb][n2]);
-                pr[gb][n2] = mma(bf[2], kq[2], pr[gb][n2]); pr[gb][n2] = mma(bf[2], kq[3], pr[gb][n2]);
-                pr[gb][n2] = mma(bf[3], kq[2], pr[gb][n2]);
-                pi[gb][n2] = mma(bf[0], kq[2], pi[gb][n2]); pi[gb][n2] = mma(bf[0], kq[3], pi[gb][n2]);
-                pi[gb][n2] = mma(bf[1], kq[2], pi[gb][n2]);
-                const uint4 nh = negu(kq[0]), nl = negu(kq[1]);
-                pi[gb][n2] = mma(bf[2], nh, pi[gb][n2]); pi[gb][n2] = mma(bf[2], nl, pi[gb][n2]);
-                pi[gb][n2] = mma(bf[3], nh, pi[gb][n2]);
-            }
+            for (int c = 0; c < 4; ++c) { rf[0][c] = bt[noff + c * 64]; if (GB > 1) rf[1][c] = bt[noff + 256 + c * 64]; }
         }
-        __syncthreads();                        // the tile and the k fragments are dead
-        sstore();
-        __syncthreads();
+        // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
+        // A operand: lane = g, registers = 8 of the 32 columns m - two transposing reads (ds_read_b64_tr_b16) of the
+        // micro-block image: lane i' of a 16-lane group points at the four halves g = g0 + 4 (i' & 3) .. + 3 of row i' >> 2 and
+        // lane i receives column g0 + i of the four rows.  
+        if (!(DBG & 4)) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            const uint32_t tr0 = (uint32_t)(uintptr_t)(tile - lds) + q * ROWB + (2 * GB * w + ((c16 >> 1) & 1)) * 64 + (c16 >> 2) * 16 +
+                                 (c16 & 1) * 8;
+            auto *lbase = (__attribute__((address_space(3))) unsigned char *)lds;
+#define FUSED_BFRAG(dst, gb_)                                                                                              \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                                          \
+    {                                                                                                                      \
+        const uint32_t o_ = tr0 + p * 8 * ROWB + (gb_) * 128;                                                             \
+        const u32x2 lo_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o_)));   \
+        const u32x2 hi_ = __builtin_bit_cast(                                                                              \
+            u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o_ + 4 * ROWB)));                        \
+        dst[p] = u32x4{lo_.x, lo_.y, hi_.x, hi_.y};                                                                       \
+    }
+#pragma unroll
+            for (int gb = 0; gb < GB; ++gb) {
+                u32x4 bf[4];
+                FUSED_BFRAG(bf, gb)
+#pragma unroll
+                for (int n2 = 0; n2 < 4; ++n2) {
+                    u32x4 kq[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) kq[p] = *reinterpret_cast<const u32x4 *>(xch + ((n2 * 4 + p) * 64 + l) * 16);
+                    const u32x4 nh = negu(kq[0]), nl = negu(kq[1]);
+                    // re += Br kr + Bi ki ; im += Br ki - Bi kr
+                    pr[gb][n2] = mma(bf[0], kq[0], pr[gb][n2]); pi[gb][n2] = mma(bf[0], kq[2], pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[0], kq[1], pr[gb][n2]); pi[gb][n2] = mma(bf[0], kq[3], pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[1], kq[0], pr[gb][n2]); pi[gb][n2] = mma(bf[1], kq[2], pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[2], kq[2], pr[gb][n2]); pi[gb][n2] = mma(bf[2], nh, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[2], kq[3], pr[gb][n2]); pi[gb][n2] = mma(bf[2], nl, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[3], kq[2], pr[gb][n2]); pi[gb][n2] = mma(bf[3], nh, pi[gb][n2]);
+                }
+                if (!(DBG & 8)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = rf[gb & 1][c];
+                        if (gb + 2 < GB) rf[gb & 1][c] = bt[noff + (gb + 2) * 256 + c * 64];
+                    }
+                }
+            }
+#undef FUSED_BFRAG
+        }
+        __syncthreads();                        // next tile in place, k fragments dead
     }
 
     // ---- partial sums of this column range: Ppart[t][part][n + 64 g]
@@ -400,10 +427,24 @@ int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d)
     JSTSP_REQUIRE(fused_shape_ok(64, d.M, d.G2, d.parts), JSTSP_E_UNSUPPORTED, "fused pass: shape");
     constexpr int GB = 4;
     const size_t sh = (size_t)32 * (128 * GB * 8 + FPAD) + 16384;
-    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
+    const int dbg = getenv("JSTSP_FUSED_DBG") ? atoi(getenv("JSTSP_FUSED_DBG")) : 0;
     prof_begin(ctx, "fused_pass");
-    hipLaunchKernelGGL(fused_pass_kernel<GB>, dim3(grid), dim3(512), sh, ctx->stream, d);
+#define JSTSP_FUSED_LAUNCH(D)                                                                                                \
+    {                                                                                                                        \
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB, D>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                      (int)sh));                                                                             \
+        hipLaunchKernelGGL((fused_pass_kernel<GB, D>), dim3(grid), dim3(512), sh, ctx->stream, d);                           \
+    }
+    switch (dbg) {
+    case 1: JSTSP_FUSED_LAUNCH(1) break;
+    case 2: JSTSP_FUSED_LAUNCH(2) break;
+    case 4: JSTSP_FUSED_LAUNCH(4) break;
+    case 8: JSTSP_FUSED_LAUNCH(8) break;
+    case 15: JSTSP_FUSED_LAUNCH(15) break;
+    default: JSTSP_FUSED_LAUNCH(0) break;
+    }
+#undef JSTSP_FUSED_LAUNCH
     prof_end(ctx, "fused_pass");
     JSTSP_HIP(hipGetLastError());
     return 0;

@@ -327,7 +327,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     // Fused pass (fused.hip): after the gradient step of iteration it, ONE kernel forms Xs = A S B, the V2 / X / V1 / k
     // updates of :61-65 and of the next iteration's :38-43, and the first factor K B^H of the next :47 - the dictionary
     // is read once per iteration instead of twice.  The next iteration then starts at the gradient step.
-    const bool fusedp = want_fused && zfly && !overlap && !svt_skip;
+    const bool fusedp = want_fused && zfly && !svt_skip;
     FusedWS fw;
     if (fusedp) {
         JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts));
@@ -383,6 +383,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             StreamScope sc(ctx, s1);
             if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
             if (zfly) {
+                // (the spectral norms of the previous iteration still read the G_x, G_v1 partials this pass overwrites)
+                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_ce, 0));
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
                                         w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
@@ -390,8 +392,12 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                 JSTSP_TRY(svt_prepare(ctx, w.gz, w.X, w.prm, nullptr, true, w.zmax, svt_skip, nullptr, true));
                 if (fusedp) {       // Y of the next iteration = (I - Q) Z, consumed by the pass at the end of this one
                     JSTSP_TRY(launch_eye_minus(ctx, N, batch, w.gz.Q, w.gz.Q));
-                    JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
-                    JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{w.Zb, snm, N}, w.Y, snm, N));
+                    GemmDesc dy = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{w.X, snm, N},
+                                            w.Y, snm, N);
+                    dy.epi = EPI_UPDATE_X; dy.prm = w.prm; dy.B2 = w.V1; dy.epi_store_c = 2;    // Z formed in the panel loader
+                    dy.e_rw0 = w.V1; dy.e_w1 = w.X; dy.e_w2 = w.ZK; dy.e_r0 = w.V2; dy.e_r2 = w.Xs; dy.e_r3 = subY;
+                    dy.e_f0 = w.invD;                                                            // (alignment checks only)
+                    JSTSP_TRY(launch_cgemm(ctx, dy, GEMM_MISC));
                 }
             } else
             JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr, svt_skip));
@@ -471,6 +477,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             uint32_t *nx = kmax0 + (size_t)((it + 1) & 1) * 8 * (size_t)batch;
             JSTSP_HIP(hipMemsetAsync(nx, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
             JSTSP_TRY(fused_pack_as(ctx, fw, w.W, sng, G2, batch, w.wmax));
+            JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));          // Y of the next iteration (side stream s1)
             FusedDesc fd{fw.Bf, strideB ? fw.sBf : 0, w.Bs.bmax, strideB ? 1 : 0, fw.ASp, fw.sAS, w.wmax, w.kmax,
                          w.X, w.V1, w.V2, subY, w.Y, w.invD, snm, w.prm, fw.Ppart,
                          nx, nx + batch, nx + 2 * (size_t)batch, nx + 4 * (size_t)batch, w.nmax + 2 * (size_t)batch, fw.ovf,
