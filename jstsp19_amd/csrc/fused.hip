@@ -46,6 +46,16 @@ __device__ __forceinline__ void fsplit(float x, _Float16 &h, _Float16 &l)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // native vectors: arrays of them stay in registers
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));      // (arrays of HIP's uint4 struct were kept in scratch)
 __device__ __forceinline__ u32x4 negu(u32x4 u) { return u ^ 0x80008000u; }
+// uniform base pointer + 32-bit BYTE offset per lane: the global_load / store with an SGPR base and one VGPR of offset
+// (an element index makes hipcc build, hoist and spill a 64-bit address per access)
+template <class T> __device__ __forceinline__ T ldg(const void *base, uint32_t boff)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + boff);
+}
+template <class T> __device__ __forceinline__ void stg(void *base, uint32_t boff, T v)
+{
+    *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + boff) = v;
+}
 __device__ __forceinline__ f32x4 mma(u32x4 a, u32x4 b, f32x4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
@@ -108,6 +118,29 @@ __global__ __launch_bounds__(256) void pack_as_kernel(const float2 *W, long long
     for (int p = 0; p < 4; ++p) o[p * 64] = *reinterpret_cast<uint4 *>(&pl[p]);
 }
 
+// ---- Wq = I - Q (N x N, the SVT re-projection: Y = Wq Z) -> B-operand fragments of Wq^T: out[t][ks 2][nb 4][plane 4][lane 64],
+//      lane l: n = 16 nb + (l & 15), n' = 32 ks + 8 (l >> 4) + 0..7, value Wq[n, n'] scaled by 2^13 (|entries| <= 1)
+__global__ __launch_bounds__(256) void pack_wq_kernel(const float2 *Q, uint4 *out)
+{
+    const int t = blockIdx.x;
+    const float2 *q = Q + (long long)t * 4096;
+    for (int idx = threadIdx.x; idx < 512; idx += 256) {
+        const int lane = idx & 63, nb = (idx >> 6) & 3, ks = idx >> 8;
+        const int n = 16 * nb + (lane & 15), c0 = 32 * ks + 8 * (lane >> 4);
+        half8 pl[4];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const float2 x = q[n + 64 * (c0 + v)];
+            _Float16 h, l;
+            fsplit(((n == c0 + v) ? 1.f : 0.f) * 8192.f - x.x * 8192.f, h, l); pl[0][v] = h; pl[1][v] = l;
+            fsplit(-x.y * 8192.f, h, l); pl[2][v] = h; pl[3][v] = l;
+        }
+        uint4 *o = out + (long long)t * 2048 + (long long)((ks * 4 + nb) * 4) * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[p * 64] = *reinterpret_cast<uint4 *>(&pl[p]);
+    }
+}
+
 // ---- Tc[t] = sum over the column ranges of the partial sums
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float4 *P, int parts, long long n4, float4 *out)
 {
@@ -133,7 +166,8 @@ __global__ __launch_bounds__(256) void poison_kernel(const uint32_t *ovf, float2
 
 // DBG (timing experiments only, results are wrong): 1 skips the phase-A products, 2 the element-wise loads / stores,
 // 4 the phase-B products, 8 the tile refill
-template <int GB, int DBG>
+// YIN: Y = (I - Q) Z of the next iteration is formed here (Z from d.Zin, fragments of I - Q from d.Wqp) instead of read
+template <int GB, int DBG, bool YIN>
 __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 {
     constexpr int G2 = 128 * GB;
@@ -167,8 +201,8 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 
     // refill of the tile: wave w owns the rows g of its phase-B range, block gb of them = 256 chunks, 4 per lane (plane p = c)
     const u32x4 *const bt = reinterpret_cast<const u32x4 *>(d.Bf) + (long long)t * d.sBf + (long long)tile0 * (16ll * G2);
-    const uint32_t boff = (uint32_t)(w * GB) * 256u + l;
-    constexpr uint32_t tile_u4 = 16u * G2;
+    const uint32_t boff = 16u * ((uint32_t)(w * GB) * 256u + l);          // bytes
+    constexpr uint32_t tile_b = 256u * G2;                                // bytes per tile
     unsigned char *rdst = tile + ((l >> 3) & 7) * ROWB + (2 * GB * w + ((l >> 2) & 1)) * 64 + (l & 3) * 16;   // + p 8 ROWB + gb 128
 
     f32x4 pr[GB][4], pi[GB][4];
@@ -182,9 +216,15 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     float2 *const Xt = d.X + (long long)t * d.snm, *const V1t = d.V1 + (long long)t * d.snm, *const V2t = d.V2 + (long long)t * d.snm;
     const float2 *const sYt = d.subY + (long long)t * d.snm, *const Yt = d.Y + (long long)t * d.snm;
     const float *const iDt = d.invD + (long long)t * d.snm;
-    const uint32_t ebase = 16 * nb + c16 + 64 * (16 * kh + 4 * q);     // + 64 (m0 + s)
+    const float4 *const Zit4 = YIN ? reinterpret_cast<const float4 *>(d.Zin + (long long)t * d.snm) : nullptr;
+    float2 *const Zot = YIN ? d.Zout + (long long)t * d.snm : nullptr;
+    float2 *const Yot = d.Yout ? d.Yout + (long long)t * d.snm : nullptr;
+    const u32x4 *const wqt = YIN ? reinterpret_cast<const u32x4 *>(d.Wqp) + (long long)t * 2048 : nullptr;
+    const uint32_t wqoff = 16u * (nb * 256 + l), zoff = 16u * (32u * (uint32_t)(16 * kh + c16) + 4 * q);      // bytes
+    const float sy = YIN ? ldexpf(1.f, -(fscale_exp(d.zmax_in[t]) + 13)) : 0.f, sz = YIN ? ldexpf(1.f, fscale_exp(d.zmax_in[t])) : 0.f;
+    const uint32_t ebase = 8u * (16 * nb + c16 + 64 * (16 * kh + 4 * q));     // bytes; + 512 (m0 + s)
     const u32x4 *const ast = reinterpret_cast<const u32x4 *>(d.ASp) + (long long)t * d.sAS;
-    const uint32_t aoff = (uint32_t)(kh * KSH) * 1024u + nb * 256 + l;
+    const uint32_t aoff = 16u * ((uint32_t)(kh * KSH) * 1024u + nb * 256 + l);      // bytes
     const int perm_sel = (c16 & 1) ? 0x07060302 : 0x05040100;
     const bool cw = (c16 & 2) != 0;
 
@@ -193,9 +233,55 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         for (int gb = 0; gb < GB; ++gb)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = bt[boff + gb * 256 + c * 64];
+                *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = ldg<u32x4>(bt, boff + gb * 4096 + c * 1024);
     }
     __syncthreads();
+
+    // Y^T(block) = Z^T Wq^T for this wave's element-wise block of a tile: A operand = Z^T (lane = column m of Z, 8 consecutive
+    // rows n' per k-step: 64 contiguous bytes), B operand = the fragments of Wq^T; two k-steps of 32 rows.  The Z loads of the
+    // NEXT tile are requested in the middle of phase B and multiplied after it, so that Y costs no exposed latency.
+    float4 zz[2][4];
+    float2 ey[4];
+#define FUSED_ZLOAD(m0_, ks_)                                                                                                \
+    {                                                                                                                        \
+        const uint32_t zo_ = zoff + 512u * (uint32_t)(m0_) + 256 * (ks_);                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) zz[ks_][j] = ldg<float4>(Zit4, zo_ + 16 * j);                          \
+    }
+#define FUSED_YCOMP()                                                                                                        \
+    {                                                                                                                        \
+        f32x4 yr = f32x4{0.f, 0.f, 0.f, 0.f}, yi = yr;                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
+        {                                                                                                                    \
+            u32x4 wq[4];                                                                                                     \
+            uint32_t wo_ = wqoff + ks * 16384;          /* (opaque: else a 64-bit address per plane is built and spilled) */   \
+            asm volatile("" : "+v"(wo_));                                                                                    \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) wq[p] = ldg<u32x4>(wqt, wo_ + p * 1024);                                   \
+            half8 zp[4];                                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                    \
+            {                                                                                                                \
+                _Float16 h, lo;                                                                                              \
+                fsplit(zz[ks][j].x * sz, h, lo); zp[0][2 * j] = h; zp[1][2 * j] = lo;                                        \
+                fsplit(zz[ks][j].y * sz, h, lo); zp[2][2 * j] = h; zp[3][2 * j] = lo;                                        \
+                fsplit(zz[ks][j].z * sz, h, lo); zp[0][2 * j + 1] = h; zp[1][2 * j + 1] = lo;                                \
+                fsplit(zz[ks][j].w * sz, h, lo); zp[2][2 * j + 1] = h; zp[3][2 * j + 1] = lo;                                \
+            }                                                                                                                \
+            u32x4 zf[4];                                                                                                     \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) zf[p] = __builtin_bit_cast(u32x4, zp[p]);                          \
+            const u32x4 nwi_h = negu(wq[2]), nwi_l = negu(wq[3]);                                                            \
+            yr = mma(zf[0], wq[0], yr); yi = mma(zf[0], wq[2], yi);                                                          \
+            yr = mma(zf[0], wq[1], yr); yi = mma(zf[0], wq[3], yi);                                                          \
+            yr = mma(zf[1], wq[0], yr); yi = mma(zf[1], wq[2], yi);                                                          \
+            yr = mma(zf[2], nwi_h, yr); yi = mma(zf[2], wq[0], yi);                                                          \
+            yr = mma(zf[2], nwi_l, yr); yi = mma(zf[2], wq[1], yi);                                                          \
+            yr = mma(zf[3], nwi_h, yr); yi = mma(zf[3], wq[0], yi);                                                          \
+        }                                                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) ey[s] = make_float2(yr[s] * sy, yi[s] * sy);                           \
+    }
+    if (YIN) {
+        FUSED_ZLOAD(tile0 * 32, 0)
+        FUSED_ZLOAD(tile0 * 32, 1)
+        FUSED_YCOMP()
+    }
 
     for (int i = 0; i < tpw; ++i) {
         const int m0 = (tile0 + i) * 32;
@@ -206,12 +292,12 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         ar[0] = ar[1] = ai[0] = ai[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!(DBG & 1)) {
             u32x4 wr[2][4], bfb[2][4];
-            // ONE running pointer, advanced opaquely per k-step: with constant offsets the compiler materialises (and spills) a
-            // 64-bit address per (k-step, plane) outside the tile loop
-            const u32x4 *ap = ast + aoff;
-            asm volatile("" : "+v"(ap));
+            // ONE running offset, advanced opaquely per k-step: with constant offsets the compiler materialises (and spills) an
+            // address per (k-step, plane) outside the tile loop
+            uint32_t ao = aoff;
+            asm volatile("" : "+v"(ao));
 #pragma unroll
-            for (int p = 0; p < 4; ++p) wr[0][p] = ap[p * 64];
+            for (int p = 0; p < 4; ++p) wr[0][p] = ldg<u32x4>(ast, ao + p * 1024);
             const int goff0 = (kh * (G2 / 2) + 8 * q) * 8 + (c16 & 3) * 16;      // micro-block (m quad, g octet), row m & 3
             const unsigned char *arow = tile + (c16 >> 2) * ROWB + goff0;         // + p 8 ROWB + mb 4 ROWB + ks 256
 #pragma unroll
@@ -220,19 +306,24 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
             for (int st = 0; st < 2 * KSH; ++st) {
                 const int ks = st >> 1, mb = st & 1;
                 if (mb == 0 && ks + 1 < KSH) {
-                    ap += 1024;
-                    asm volatile("" : "+v"(ap));
+                    ao += 16384;
+                    asm volatile("" : "+v"(ao));
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) wr[(ks + 1) & 1][p] = ap[p * 64];
+                    for (int p = 0; p < 4; ++p) wr[(ks + 1) & 1][p] = ldg<u32x4>(ast, ao + p * 1024);
                 }
-                if (st + 1 < 2 * KSH) {
+                if (!YIN && st + 1 < 2 * KSH) {
                     const int ks1 = (st + 1) >> 1, mb1 = (st + 1) & 1;
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
                         bfb[(st + 1) & 1][p] = *reinterpret_cast<const u32x4 *>(arow + (p * 8 + 4 * mb1) * ROWB + ks1 * 256);
                 }
+                if (YIN && st > 0) {        // (no register room for the second fragment set next to the carried Y)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        bfb[0][p] = *reinterpret_cast<const u32x4 *>(arow + (p * 8 + 4 * mb) * ROWB + ks * 256);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                const u32x4 *wf = wr[ks & 1], *bf = bfb[st & 1];
+                const u32x4 *wf = wr[ks & 1], *bf = bfb[YIN ? 0 : (st & 1)];
                 const u32x4 nwi_h = negu(wf[2]), nwi_l = negu(wf[3]);
                 // re += Br Wr - Bi Wi ; im += Br Wi + Bi Wr   (h h + h l + l h each)
                 ar[mb] = mma(bf[0], wf[0], ar[mb]); ai[mb] = mma(bf[0], wf[2], ai[mb]);
@@ -252,13 +343,15 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
             x4[(dw * 2 + 1) * 64 + l] = si;
         }
         // the element-wise operands of this wave's block: n = 16 nb + c16, m = m0 + 16 kh + 4 q + s
-        float2 ex[4], ev1[4], ev2[4], esy[4], ey[4];
+        float2 ex[4], ev1[4], ev2[4], esy[4];
         float eid[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const uint32_t ix = ebase + 64u * (uint32_t)(m0 + s);
+            const uint32_t ix = ebase + 512u * (uint32_t)(m0 + s);
             if (DBG & 2) { ex[s] = ev1[s] = ev2[s] = esy[s] = ey[s] = make_float2(1.f, 1.f); eid[s] = 1.f; continue; }
-            ex[s] = Xt[ix]; ev1[s] = V1t[ix]; ev2[s] = V2t[ix]; esy[s] = sYt[ix]; ey[s] = Yt[ix]; eid[s] = iDt[ix];
+            ex[s] = ldg<float2>(Xt, ix); ev1[s] = ldg<float2>(V1t, ix); ev2[s] = ldg<float2>(V2t, ix); esy[s] = ldg<float2>(sYt, ix);
+            eid[s] = ldg<float>(iDt, ix >> 1);
+            if (!YIN) ey[s] = ldg<float2>(Yt, ix);
         }
         __syncthreads();
         f32x4 xr = kh ? ar[1] : ar[0], xi = kh ? ai[1] : ai[0];
@@ -270,7 +363,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         half4 kf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const uint32_t ix = ebase + 64u * (uint32_t)(m0 + s);
+            const uint32_t ix = ebase + 512u * (uint32_t)(m0 + s);
             const float2 xs = make_float2(xr[s] * sxs, xi[s] * sxs);
             // V2 <- (1 - cc)(V2 - rho (X - Xs))                       (:61 + :65, C == -V2)
             const float2 v2 = make_float2(omc * (ev2[s].x - rho * (ex[s].x - xs.x)), omc * (ev2[s].y - rho * (ex[s].y - xs.y)));
@@ -279,8 +372,10 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
                                          (ev1[s].y + rho * ey[s].y + esy[s].y + omr * v2.y + rho * xs.y) * eid[s]);
             const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);                  // (:43)
             const float2 v1 = make_float2(ev1[s].x + rho * (ey[s].x - x.x), ev1[s].y + rho * (ey[s].y - x.y));   // (:64)
-            if (!(DBG & 2)) { V2t[ix] = v2; Xt[ix] = x; V1t[ix] = v1; }
+            if (!(DBG & 2)) { stg(V2t, ix, v2); stg(Xt, ix, x); stg(V1t, ix, v1); }
             const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+            if (YIN) stg(Zot, ix, zn);
+            if (Yot) stg(Yot, ix, ey[s]);
             v2mx = fmaxf(v2mx, fmaxf(fabsf(v2.x), fabsf(v2.y)));
             xmx = fmaxf(xmx, fmaxf(fabsf(x.x), fabsf(x.y)));
             v1mx = fmaxf(v1mx, fmaxf(fabsf(v1.x), fabsf(v1.y)));
@@ -297,11 +392,11 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         __syncthreads();
         // the next tile (the last one is fetched again: unconditional loads) replaces this one block by block: only this
         // wave reads its rows g in phase B, so block gb is overwritten as soon as its products are issued
-        const uint32_t noff = boff + (uint32_t)min(i + 1, tpw - 1) * tile_u4;        // (< 2^32 uint4: 64 GiB per problem)
+        const uint32_t noff = boff + (uint32_t)min(i + 1, tpw - 1) * tile_b;         // (< 4 GiB of tiles per problem and range)
         u32x4 rf[2][4];
         if (!(DBG & 8)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { rf[0][c] = bt[noff + c * 64]; if (GB > 1) rf[1][c] = bt[noff + 256 + c * 64]; }
+            for (int c = 0; c < 4; ++c) { rf[0][c] = ldg<u32x4>(bt, noff + c * 1024); if (GB > 1) rf[1][c] = ldg<u32x4>(bt, noff + 4096 + c * 1024); }
         }
         // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
         // A operand: lane = g, registers = 8 of the 32 columns m - two transposing reads (ds_read_b64_tr_b16) of the
@@ -324,6 +419,12 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     }
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
+                // (before the products of the last block: by then one refill register set is free)
+                if (YIN && gb == GB - 1) {
+                    FUSED_ZLOAD((tile0 + min(i + 1, tpw - 1)) * 32, 0)
+                    FUSED_ZLOAD((tile0 + min(i + 1, tpw - 1)) * 32, 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 u32x4 bf[4];
                 FUSED_BFRAG(bf, gb)
 #pragma unroll
@@ -344,15 +445,18 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = rf[gb & 1][c];
-                        if (gb + 2 < GB) rf[gb & 1][c] = bt[noff + (gb + 2) * 256 + c * 64];
+                        if (gb + 2 < GB) rf[gb & 1][c] = ldg<u32x4>(bt, noff + (gb + 2) * 4096 + c * 1024);
                     }
                 }
             }
 #undef FUSED_BFRAG
         }
+        if (YIN) FUSED_YCOMP()
         __syncthreads();                        // next tile in place, k fragments dead
     }
 
+#undef FUSED_ZLOAD
+#undef FUSED_YCOMP
     // ---- partial sums of this column range: Ppart[t][part][n + 64 g]
     float2 *po = d.Ppart + ((long long)t * d.parts + part) * (64ll * G2);
 #pragma unroll
@@ -390,7 +494,7 @@ bool fused_shape_ok(int N, int M, int G2, int parts)
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts)
 {
     return rnd256((size_t)nB * (M / 32) * 16 * G2 * sizeof(uint4)) + rnd256((size_t)batch * (G2 / 32) * 1024 * sizeof(uint4)) +
-           rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256(sizeof(uint32_t));
+           rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256(sizeof(uint32_t)) + rnd256((size_t)batch * 2048 * sizeof(uint4));
 }
 
 int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts)
@@ -402,7 +506,8 @@ int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int par
     f.ASp = ar.get<uint4>((size_t)batch * f.sAS);
     f.Ppart = ar.get<float2>((size_t)batch * parts * 64 * G2);
     f.ovf = ar.get<uint32_t>(1);
-    JSTSP_REQUIRE(f.Bf && f.ASp && f.Ppart && f.ovf, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
+    f.Wqp = ar.get<uint4>((size_t)batch * 2048);
+    JSTSP_REQUIRE(f.Bf && f.ASp && f.Ppart && f.ovf && f.Wqp, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
     return 0;
 }
 
@@ -430,22 +535,32 @@ int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d)
     const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
     const int dbg = getenv("JSTSP_FUSED_DBG") ? atoi(getenv("JSTSP_FUSED_DBG")) : 0;
     prof_begin(ctx, "fused_pass");
-#define JSTSP_FUSED_LAUNCH(D)                                                                                                \
+#define JSTSP_FUSED_LAUNCH(D, Y)                                                                                             \
     {                                                                                                                        \
-        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB, D>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB, D, Y>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)sh));                                                                             \
-        hipLaunchKernelGGL((fused_pass_kernel<GB, D>), dim3(grid), dim3(512), sh, ctx->stream, d);                           \
+        hipLaunchKernelGGL((fused_pass_kernel<GB, D, Y>), dim3(grid), dim3(512), sh, ctx->stream, d);                        \
     }
+    if (d.Wqp) {
+        JSTSP_FUSED_LAUNCH(0, true)
+    } else
     switch (dbg) {
-    case 1: JSTSP_FUSED_LAUNCH(1) break;
-    case 2: JSTSP_FUSED_LAUNCH(2) break;
-    case 4: JSTSP_FUSED_LAUNCH(4) break;
-    case 8: JSTSP_FUSED_LAUNCH(8) break;
-    case 15: JSTSP_FUSED_LAUNCH(15) break;
-    default: JSTSP_FUSED_LAUNCH(0) break;
+    case 1: JSTSP_FUSED_LAUNCH(1, false) break;
+    case 2: JSTSP_FUSED_LAUNCH(2, false) break;
+    case 4: JSTSP_FUSED_LAUNCH(4, false) break;
+    case 8: JSTSP_FUSED_LAUNCH(8, false) break;
+    case 15: JSTSP_FUSED_LAUNCH(15, false) break;
+    default: JSTSP_FUSED_LAUNCH(0, false) break;
     }
 #undef JSTSP_FUSED_LAUNCH
     prof_end(ctx, "fused_pass");
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+int fused_pack_wq(jstsp_ctx *ctx, const FusedWS &f, const float2 *Q, int batch)
+{
+    hipLaunchKernelGGL(pack_wq_kernel, dim3(batch), dim3(256), 0, ctx->stream, Q, f.Wqp);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

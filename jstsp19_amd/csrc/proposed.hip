@@ -328,6 +328,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     // updates of :61-65 and of the next iteration's :38-43, and the first factor K B^H of the next :47 - the dictionary
     // is read once per iteration instead of twice.  The next iteration then starts at the gradient step.
     const bool fusedp = want_fused && zfly && !svt_skip;
+    // Y = (I - Q) Z formed inside the pass (JSTSP_FUSED_Y=0: by a GEMM before it)
+    const bool fusedy = fusedp && (getenv("JSTSP_FUSED_Y") ? atoi(getenv("JSTSP_FUSED_Y")) != 0 : true);
     FusedWS fw;
     if (fusedp) {
         JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts));
@@ -364,7 +366,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             dq.epi = EPI_UPDATE_X; dq.prm = w.prm;
             dq.e_rw0 = w.V1; dq.e_w1 = w.X; dq.e_w2 = w.ZK;
             dq.e_r0 = w.V2; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
-            dq.e_w3 = (it + 1 < Imax && !zfly) ? Zn : nullptr;
+            dq.e_w3 = (it + 1 < Imax && (!zfly || fusedy)) ? Zn : nullptr;      // (the fused pass reads the stored Z)
             if (zfly && it > 0) { dq.B = w.X; dq.B2 = w.V1; }      // Z = X - V1/rho in the panel loader (it == 0: Z = 0 in Zc)
             dq.epi_store_c = (it + 1 == Imax);          // Y itself is only an output of the last iteration
             if (w.h2) {                                 // max|K| for the split-f16 correlation, from the same epilogue
@@ -390,7 +392,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                                         w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
                 JSTSP_HIP(hipEventRecord(ev_gxv, s1));
                 JSTSP_TRY(svt_prepare(ctx, w.gz, w.X, w.prm, nullptr, true, w.zmax, svt_skip, nullptr, true));
-                if (fusedp) {       // Y of the next iteration = (I - Q) Z, consumed by the pass at the end of this one
+                if (fusedy) {       // the pass at the end of this iteration forms Y = (I - Q) Z itself: fragments of I - Q
+                    JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
+                } else if (fusedp) {       // Y of the next iteration = (I - Q) Z, consumed by the pass at the end of this one
                     JSTSP_TRY(launch_eye_minus(ctx, N, batch, w.gz.Q, w.gz.Q));
                     GemmDesc dy = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{w.X, snm, N},
                                             w.Y, snm, N);
@@ -481,7 +485,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             FusedDesc fd{fw.Bf, strideB ? fw.sBf : 0, w.Bs.bmax, strideB ? 1 : 0, fw.ASp, fw.sAS, w.wmax, w.kmax,
                          w.X, w.V1, w.V2, subY, w.Y, w.invD, snm, w.prm, fw.Ppart,
                          nx, nx + batch, nx + 2 * (size_t)batch, nx + 4 * (size_t)batch, w.nmax + 2 * (size_t)batch, fw.ovf,
-                         M, G2, batch, fparts};
+                         M, G2, batch, fparts,
+                         fusedy ? fw.Wqp : nullptr, Zbuf[(it + 1) & 1], w.zmax, Zbuf[it & 1],
+                         (fusedy && it + 2 == Imax) ? w.Y : nullptr};
             JSTSP_TRY(launch_fused_pass(ctx, fd));
             passed = true;
         } else
