@@ -135,60 +135,60 @@ def main():
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     mean_nmse = float(acc[0] / acc[1])
 
-    # ---- informational: the same step with the opt-in SVT short-cut (never the headline value)
     extra = {}
-    if world == 1 and not a.small:
-        os.environ["JSTSP_SVT_SKIP"] = "1"
-        try:
-            step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                o2 = step()
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / 2
-            nm2 = J.nmse_spectral(o2[0], J.colmajor(inp["Zbar"].to(torch.complex64)))
-            extra["opt_in_svt_shortcut"] = {"value": round(a.batch / dt2, 3), "unit": "channel-estimates/s",
-                                            "max_abs_dNMSE_vs_default_path": float((nm2 - nmse).abs().max()),
-                                            "note": "JSTSP_SVT_SKIP=1: tau_Y/rho <= 2^-27 max|Z| => Y = Z in fp32; off by default"}
-        finally:
-            os.environ.pop("JSTSP_SVT_SKIP", None)
 
     # ---- roofline of the dominant kernel: one extra untimed step with HIP events on the launch stream
     ctx.set_profiling(True)
     step()
     torch.cuda.synchronize()
+    n_f, ms_f = ctx.get_profile("fused_pass")
     n_l, ms = ctx.get_profile("correlate")
     n_s, ms_s = ctx.get_profile("synthesize")
     ctx.set_profiling(False)
-    # Dominant kernel: hgemm2_kernel<EPI_UPDATE_C> = Xs = (A S) B on the split-f16 matrix pipe with the C / V2 update
-    # in its epilogue (proposed_algorithm.m:58,:61,:65).  It is HBM-bound: algorithmic bytes per launch =
-    #   packed dictionary (4 f16 planes = 8 B per complex entry of B, read once)      G2*M*8 * nB
-    # + a operand A S                                                                   N*G2*8 * batch
-    # + epilogue: X read, V2 read + write, Xs write                                     4 * N*M*8 * batch
-    # (per trial at configs[1]: 16.0 MiB + 0.25 MiB + 8.0 MiB).
     nB = 1 if a.shared_pilots else a.batch                         # per-trial pilots in the headline workload
-    bytes_synth = 8.0 * G2 * M * nB + 8.0 * N * G2 * a.batch + 4 * 8.0 * N * M * a.batch
-    bytes_corr = 8.0 * G2 * M * nB + 8.0 * N * M * a.batch + 8.0 * N * G2 * a.batch     # K B^H: B pack + K + result
     flops_per_launch = 8.0 * N * M * G2 * a.batch              # either contraction, 8 real flops per complex MAC
     # HBM traffic of the same kernels from the committed PMC measurement (separate rocprofv3 --pmc passes,
     # FETCH_SIZE doubled as the microarch guide prescribes for gfx950); only valid for the profiled shape
-    traffic = traffic_c = None
+    pm = {}
     try:
         if not a.small and a.batch == 256:
             with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pm = json.load(f)
-            traffic = pm["synthesize_update_c"]["hbm_bytes_per_launch"]
-            traffic_c = pm["correlate"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        traffic = traffic_c = None
+    except (OSError, ValueError):
+        pm = {}
+    traffic_of = lambda key: pm.get(key, {}).get("hbm_bytes_per_launch")
     roofline = None
-    if n_s:
+    if n_f:
+        # Dominant kernel: fused_pass_kernel (csrc/fused.hip) - per iteration ONE read of the dictionary: Xs = (A S) B (:58), the
+        # V2 / X / V1 / k updates (:61-65, :38-43 of the next iteration, Y = (I - Q) Z formed in the kernel) and the first factor
+        # K B^H of the next :47.  HBM-bound by construction; algorithmic bytes per launch =
+        #   dictionary tiles (4 f16 planes = 8 B per complex entry of B, read once)                       G2*M*8 * nB
+        # + state: read X, V1, V2, subY (8 B each), invD (4 B), Z (8 B); write X, V1, V2, Z (8 B each)    76 * N*M * batch
+        # + (A S) fragments read once per column range, partial sums of K B^H written                     2 * parts * N*G2*8 * batch
+        # (per trial at configs[1]: 16.0 MiB + 19.0 MiB + 2.0 MiB).
+        parts = int(os.environ.get("JSTSP_FUSED_PARTS", "4"))
+        bytes_pass = 8.0 * G2 * M * nB + 76.0 * N * M * a.batch + 2.0 * parts * 8.0 * N * G2 * a.batch
+        avg_f = ms_f / n_f
+        ach = bytes_pass / (avg_f * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "fused_pass_kernel ((A S) B, element-wise ADMM updates incl. Y = (I - Q) Z, K B^H: one read of "
+                                              "the dictionary per iteration; split-f16 MFMA, tile in LDS)",
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic_of("fused_pass"), "avg_launch_ms": round(avg_f, 4), "launches": n_f,
+                    "bytes_per_launch": bytes_pass,
+                    "algorithmic_tflops": round(2 * flops_per_launch / (avg_f * 1e-3) / 1e12, 1),
+                    "note": "the three kernels this pass replaces (JSTSP_FUSED=0) run at 0.66-0.68 of the HBM peak each but move "
+                            "16.5 GB per iteration instead of 9.9 GB"}
+    elif n_s:
+        # Three-kernel path (JSTSP_FUSED=0 or a shape the fused pass does not take): dominant kernel hgemm2_kernel<EPI_UPDATE_C>
+        # = Xs = (A S) B with the C / V2 update in its epilogue (:58,:61,:65); algorithmic bytes per launch = packed dictionary
+        # G2*M*8 * nB + a operand N*G2*8 * batch + epilogue (X read, V2 read + write, Xs write) 4 * N*M*8 * batch
+        bytes_synth = 8.0 * G2 * M * nB + 8.0 * N * G2 * a.batch + 4 * 8.0 * N * M * a.batch
+        bytes_corr = 8.0 * G2 * M * nB + 8.0 * N * M * a.batch + 8.0 * N * G2 * a.batch     # K B^H: B pack + K + result
         avg_ms = ms_s / n_s
         ach = bytes_synth / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "hgemm2_kernel<EPI_UPDATE_C> ((A S) B + C/V2 update, split-f16 MFMA, dictionary HBM -> registers)",
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic_of("synthesize_update_c"),
                     "avg_launch_ms": round(avg_ms, 4), "launches": n_s, "bytes_per_launch": bytes_synth,
                     "algorithmic_tflops": round(flops_per_launch / (avg_ms * 1e-3) / 1e12, 1)}
         if n_l:
@@ -196,7 +196,7 @@ def main():
             roofline["correlate"] = {"kernel": "hgemm_kernel<EPI_NONE> (K B^H)", "avg_launch_ms": round(avg_c, 4),
                                      "achieved": round(bytes_corr / (avg_c * 1e-3) / 1e9, 1), "unit": "GB/s",
                                      "frac": round(bytes_corr / (avg_c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "bytes_per_launch": bytes_corr, "traffic": traffic_c,
+                                     "bytes_per_launch": bytes_corr, "traffic": traffic_of("correlate"),
                                      "algorithmic_tflops": round(flops_per_launch / (avg_c * 1e-3) / 1e12, 1)}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, single-GPU runs only) -------------
