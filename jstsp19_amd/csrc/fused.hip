@@ -52,6 +52,18 @@ template <class T> __device__ __forceinline__ T ldg(const void *base, uint32_t b
 {
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + boff);
 }
+// the same, non-temporal: lines that one CU reads once (dictionary tiles, state arrays) must not push the (A S) fragments,
+// which every tile re-reads, out of L2
+template <class T> __device__ __forceinline__ T ldg_nt(const void *base, uint32_t boff)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + boff));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 ldg_nt2(const void *base, uint32_t boff)      // (the builtin wants a native vector type)
+{
+    const f32x2 v = ldg_nt<f32x2>(base, boff);
+    return make_float2(v.x, v.y);
+}
 template <class T> __device__ __forceinline__ void stg(void *base, uint32_t boff, T v)
 {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + boff) = v;
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     constexpr int KSH = G2 / 64;               // 32-wide k-steps per g-half
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned char *tile = lds;
-    unsigned char *xch = lds + TILEB;          // 16 KiB: phase-A partial sums, then the k fragments
+    unsigned char *xch = lds + TILEB;          // 24 KiB: phase-A partial sums (16), then the k fragments (6 planes)
 
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         for (int gb = 0; gb < GB; ++gb)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = ldg<u32x4>(bt, boff + gb * 4096 + c * 1024);
+                *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = ldg_nt<u32x4>(bt, boff + gb * 4096 + c * 1024);
     }
     __syncthreads();
 
@@ -349,9 +361,9 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         for (int s = 0; s < 4; ++s) {
             const uint32_t ix = ebase + 512u * (uint32_t)(m0 + s);
             if (DBG & 2) { ex[s] = ev1[s] = ev2[s] = esy[s] = ey[s] = make_float2(1.f, 1.f); eid[s] = 1.f; continue; }
-            ex[s] = ldg<float2>(Xt, ix); ev1[s] = ldg<float2>(V1t, ix); ev2[s] = ldg<float2>(V2t, ix); esy[s] = ldg<float2>(sYt, ix);
-            eid[s] = ldg<float>(iDt, ix >> 1);
-            if (!YIN) ey[s] = ldg<float2>(Yt, ix);
+            ex[s] = ldg_nt2(Xt, ix); ev1[s] = ldg_nt2(V1t, ix); ev2[s] = ldg_nt2(V2t, ix);
+            esy[s] = ldg_nt2(sYt, ix); eid[s] = ldg_nt<float>(iDt, ix >> 1);
+            if (!YIN) ey[s] = ldg_nt2(Yt, ix);
         }
         __syncthreads();
         f32x4 xr = kh ? ar[1] : ar[0], xi = kh ? ai[1] : ai[0];
@@ -388,7 +400,10 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         __syncthreads();                        // every wave has read its partial sums: the exchange area is free
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            *reinterpret_cast<half4 *>(xch + ((nb * 4 + p) * 64 + l) * 16 + kh * 8) = kf[p];
+            *reinterpret_cast<half4 *>(xch + ((nb * 6 + p) * 64 + l) * 16 + kh * 8) = kf[p];
+        // planes 4, 5: -k_re (the imaginary part of conj(B) k needs it; negating per product costs registers)
+        *reinterpret_cast<half4 *>(xch + ((nb * 6 + 4) * 64 + l) * 16 + kh * 8) = -kf[0];
+        *reinterpret_cast<half4 *>(xch + ((nb * 6 + 5) * 64 + l) * 16 + kh * 8) = -kf[1];
         __syncthreads();
         // the next tile (the last one is fetched again: unconditional loads) replaces this one block by block: only this
         // wave reads its rows g in phase B, so block gb is overwritten as soon as its products are issued
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         u32x4 rf[2][4];
         if (!(DBG & 8)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { rf[0][c] = ldg<u32x4>(bt, noff + c * 1024); if (GB > 1) rf[1][c] = ldg<u32x4>(bt, noff + 4096 + c * 1024); }
+            for (int c = 0; c < 4; ++c) { rf[0][c] = ldg_nt<u32x4>(bt, noff + c * 1024); if (GB > 1) rf[1][c] = ldg_nt<u32x4>(bt, noff + 4096 + c * 1024); }
         }
         // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
         // A operand: lane = g, registers = 8 of the 32 columns m - two transposing reads (ds_read_b64_tr_b16) of the
@@ -429,23 +444,24 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
                 FUSED_BFRAG(bf, gb)
 #pragma unroll
                 for (int n2 = 0; n2 < 4; ++n2) {
-                    u32x4 kq[4];
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) kq[p] = *reinterpret_cast<const u32x4 *>(xch + ((n2 * 4 + p) * 64 + l) * 16);
-                    const u32x4 nh = negu(kq[0]), nl = negu(kq[1]);
+                    const unsigned char *kp = xch + (n2 * 6 * 64 + l) * 16;
+                    u32x4 k0 = *reinterpret_cast<const u32x4 *>(kp), k1 = *reinterpret_cast<const u32x4 *>(kp + 1024);
+                    const u32x4 k2 = *reinterpret_cast<const u32x4 *>(kp + 2048), k3 = *reinterpret_cast<const u32x4 *>(kp + 3072);
                     // re += Br kr + Bi ki ; im += Br ki - Bi kr
-                    pr[gb][n2] = mma(bf[0], kq[0], pr[gb][n2]); pi[gb][n2] = mma(bf[0], kq[2], pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[0], kq[1], pr[gb][n2]); pi[gb][n2] = mma(bf[0], kq[3], pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[1], kq[0], pr[gb][n2]); pi[gb][n2] = mma(bf[1], kq[2], pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[2], kq[2], pr[gb][n2]); pi[gb][n2] = mma(bf[2], nh, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[2], kq[3], pr[gb][n2]); pi[gb][n2] = mma(bf[2], nl, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[3], kq[2], pr[gb][n2]); pi[gb][n2] = mma(bf[3], nh, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[0], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k2, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[0], k1, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k3, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[1], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[1], k2, pi[gb][n2]);
+                    k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
+                    pr[gb][n2] = mma(bf[2], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k0, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[2], k3, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k1, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[3], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[3], k0, pi[gb][n2]);
+                    __builtin_amdgcn_sched_barrier(0);      // (else the fragment reads of all four n-blocks are hoisted: spills)
                 }
                 if (!(DBG & 8)) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = rf[gb & 1][c];
-                        if (gb + 2 < GB) rf[gb & 1][c] = ldg<u32x4>(bt, noff + (gb + 2) * 4096 + c * 1024);
+                        if (gb + 2 < GB) rf[gb & 1][c] = ldg_nt<u32x4>(bt, noff + (gb + 2) * 4096 + c * 1024);
                     }
                 }
             }
@@ -531,7 +547,7 @@ int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d)
 {
     JSTSP_REQUIRE(fused_shape_ok(64, d.M, d.G2, d.parts), JSTSP_E_UNSUPPORTED, "fused pass: shape");
     constexpr int GB = 4;
-    const size_t sh = (size_t)32 * (128 * GB * 8 + FPAD) + 16384;
+    const size_t sh = (size_t)32 * (128 * GB * 8 + FPAD) + 24576;
     const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
     const int dbg = getenv("JSTSP_FUSED_DBG") ? atoi(getenv("JSTSP_FUSED_DBG")) : 0;
     prof_begin(ctx, "fused_pass");
