@@ -113,7 +113,7 @@ struct jstsp_ctx {
     // residual max|I - G X|, [2] the smallest lambda_min/lambda_max of an eigen-inverted factor Gram
     uint32_t *diag = nullptr;
     hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace jstsp {

@@ -310,7 +310,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_TRY(ensure_side_streams(ctx));
     hipStream_t sm = ctx->stream, s1 = overlap ? ctx->side[0] : sm, s2 = overlap ? ctx->side[1] : sm;
     hipEvent_t ev_x = ctx->ev[0], ev_svt = ctx->ev[1], ev_gxv = ctx->ev[2], ev_c = ctx->ev[3], ev_gv2 = ctx->ev[4],
-               ev_ce = ctx->ev[5];
+               ev_ce = ctx->ev[5], ev_lxv = ctx->ev[6];
     // iteration 0's SVT preparation on the main stream (X = V1 = 0)
     if (Imax > 0) {
         JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
@@ -390,12 +390,19 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             StreamScope sc(ctx, s1);
             if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
             if (zfly) {
-                // (the spectral norms of the previous iteration still read the G_x, G_v1 partials this pass overwrites)
-                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_ce, 0));
+                // (the spectral norms of X, V1 of the previous iteration read the G_x, G_v1 partials this pass overwrites)
+                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_lxv, 0));
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
                                         w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
                 JSTSP_HIP(hipEventRecord(ev_gxv, s1));
+                if (fusedp) {       // lambda_max of G_x, G_v1 now (beside the pass), not after it with G_v2: the next Gram
+                                    // pass then never waits for them
+                    JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));
+                    StreamScope sc2(ctx, s2);
+                    JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 0, 2 * batch, w.lam, true));
+                    JSTSP_HIP(hipEventRecord(ev_lxv, s2));
+                }
                 JSTSP_TRY(svt_prepare(ctx, w.gz, w.X, w.prm, nullptr, true, w.zmax, svt_skip, nullptr, true));
                 if (fusedy) {       // the pass at the end of this iteration forms Y = (I - Q) Z itself: fragments of I - Q
                     JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
@@ -525,7 +532,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             StreamScope sc(ctx, s2);
             JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gv2, s2));
-            JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam, true));
+            if (fusedp && zfly && it + 1 < Imax) JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 2 * batch, batch, w.lam, true));
+            else JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam, true));
             JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));
             JSTSP_HIP(hipEventRecord(ev_ce, s2));
         }

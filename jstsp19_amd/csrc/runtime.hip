@@ -220,6 +220,12 @@ int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos
     return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam, lanczos);
 }
 
+int lmax_from_partials_range(jstsp_ctx *ctx, const GramWS &w, int first, int count, float *lam, bool lanczos)
+{
+    const long long sG = (long long)w.n * w.n;
+    return launch_lmax(ctx, w.n, count, w.Gpart + (long long)first * sG * w.nsplit, sG * w.nsplit, w.nsplit, sG, lam + first, lanczos);
+}
+
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
                 bool sequence, const uint32_t *amax, bool allow_skip, const float2 *Z2, bool gram_done)
 {
@@ -277,9 +283,13 @@ int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
 
 int ensure_side_streams(jstsp_ctx *ctx)
 {
+    // lowest priority: what runs there has slack, the chain on the context's stream is the critical path of an iteration
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    static const bool prio = getenv("JSTSP_SIDE_PRIO") ? atoi(getenv("JSTSP_SIDE_PRIO")) != 0 : false;      // (measured at configs[1]: 3.96 vs 3.92 ms per iteration with / without)
     for (int i = 0; i < 2; ++i)
-        if (!ctx->side[i]) JSTSP_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-    for (int i = 0; i < 6; ++i)
+        if (!ctx->side[i]) JSTSP_HIP(hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, prio ? lo : 0));
+    for (int i = 0; i < 8; ++i)
         if (!ctx->ev[i]) JSTSP_HIP(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     return 0;
 }
@@ -415,7 +425,7 @@ int jstsp_destroy(jstsp_ctx *ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned_done) (void)hipEventDestroy(ctx->pinned_done);
     for (int i = 0; i < 2; ++i) if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
-    for (int i = 0; i < 6; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->diag) (void)hipFree(ctx->diag);
     ctx->arena.release();

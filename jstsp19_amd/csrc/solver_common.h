@@ -55,6 +55,7 @@ int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long l
                         const TrialParams *zprm = nullptr);
 // lam[t] = lambda_max of the Gram partials already in the workspace, all w.batch problems
 int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos = false);
+int lmax_from_partials_range(jstsp_ctx *ctx, const GramWS &w, int first, int count, float *lam, bool lanczos);   // matrices [first, first + count)
 // Make sure the context's side streams / events exist.
 int ensure_side_streams(jstsp_ctx *ctx);
 // Temporarily route the launch helpers (which use ctx->stream) to another stream.
