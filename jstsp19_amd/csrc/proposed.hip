@@ -427,6 +427,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
         //    Tc = K B^H  (N x G2), then Res = A^H Tc - G_A V G_B
+        // (measured and dropped: 1. ONE fp32-FMA kernel for the sum of the partial sums, Res = A^H Tc - R v and G_A Res - three
+        //  launches of the chain between two passes - 3.96 -> 4.42 ms per iteration: 64 KiB of A and G_A into LDS per workgroup
+        //  and VALU products lose against the MFMA GEMM even at k = 64;  2. the last column range of a problem adding the
+        //  partial sums inside the pass: the device-scope fence it needs writes the L2 back, 3.95 -> 4.36 ms)
         if (passed) {
             JSTSP_TRY(fused_reduce(ctx, fw, G2, batch, w.Tc));
         } else if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
