@@ -64,6 +64,10 @@ __device__ __forceinline__ float2 ldg_nt2(const void *base, uint32_t boff)      
     const f32x2 v = ldg_nt<f32x2>(base, boff);
     return make_float2(v.x, v.y);
 }
+__device__ __forceinline__ void stg_nt2(void *base, uint32_t boff, float2 v)
+{
+    __builtin_nontemporal_store(f32x2{v.x, v.y}, reinterpret_cast<f32x2 *>(reinterpret_cast<char *>(base) + boff));
+}
 template <class T> __device__ __forceinline__ void stg(void *base, uint32_t boff, T v)
 {
     *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + boff) = v;
@@ -384,9 +388,9 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
                                          (ev1[s].y + rho * ey[s].y + esy[s].y + omr * v2.y + rho * xs.y) * eid[s]);
             const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);                  // (:43)
             const float2 v1 = make_float2(ev1[s].x + rho * (ey[s].x - x.x), ev1[s].y + rho * (ey[s].y - x.y));   // (:64)
-            if (!(DBG & 2)) { stg(V2t, ix, v2); stg(Xt, ix, x); stg(V1t, ix, v1); }
+            if (!(DBG & 2)) { stg_nt2(V2t, ix, v2); stg_nt2(Xt, ix, x); stg_nt2(V1t, ix, v1); }
             const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
-            if (YIN) stg(Zot, ix, zn);
+            if (YIN) stg_nt2(Zot, ix, zn);
             if (Yot) stg(Yot, ix, ey[s]);
             v2mx = fmaxf(v2mx, fmaxf(fabsf(v2.x), fabsf(v2.y)));
             xmx = fmaxf(xmx, fmaxf(fabsf(x.x), fabsf(x.y)));
