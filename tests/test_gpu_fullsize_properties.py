@@ -98,3 +98,61 @@ def test_proposed_full_size_invariants_and_oracle_sample():
         allowed = set((inp["indx_S"][t, :10 + 5 * 20] - 1).cpu().numpy().tolist())
         nz = set(np.flatnonzero(Sa[t].cpu().numpy().reshape(-1, order="F")).tolist())
         assert nz <= allowed
+
+
+def _solve_pair(inp, Imax, B=None, indx=None, **env):
+    """The same solve with the fused pass (default) and with the three kernels it replaces (JSTSP_FUSED=0)."""
+    import os
+    import torch
+    import jstsp19_amd as J
+    out = []
+    for fused in ("1", "0"):
+        os.environ["JSTSP_FUSED"] = fused
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            args = (inp["subY"], inp["Omega"], inp["A"], inp["B"] if B is None else B, Imax, inp["tau_Y"].numpy(),
+                    inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate")
+            r = J.proposed_algorithm(*args) if indx is None else J.proposed_algorithm_angles(*args[:2], indx, *args[2:], None)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("JSTSP_FUSED", None)
+            for k in env:
+                os.environ.pop(k, None)
+        out.append([x.cpu().numpy() for x in r])
+    return out
+
+
+def _close(a, b, tol):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)) < tol
+
+
+@pytest.mark.parametrize("batch,Imax", [(3, 2), (11, 7), (16, 25)])
+def test_fused_pass_equals_the_three_kernel_iteration(batch, Imax):
+    """csrc/fused.hip (one read of the dictionary per iteration) against the kernels it replaces on the same trials: S, Y and
+    convergence_error agree to fp32 rounding noise for batches that do not fill the XCD groups, for the first passes (Imax 2:
+    exactly one pass, whose Y is the output) and deeper into the iteration."""
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    inp = build_trials(SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=0.0), 0, batch, seed=5)
+    (S1, Y1, c1), (S0, Y0, c0) = _solve_pair(inp, Imax)
+    assert np.all(np.isfinite(S1))
+    assert _close(S1, S0, 3e-6) and _close(Y1, Y0, 5e-6)
+    fin = np.isfinite(c0) & np.isfinite(c1)
+    assert np.array_equal(np.isfinite(c0), np.isfinite(c1))
+    assert np.max(np.abs(c1[fin] - c0[fin]) / np.abs(c0[fin])) < 1e-4
+
+
+def test_fused_pass_with_shared_pilots_angles_and_column_ranges():
+    """One dictionary for the whole batch (strideB = 0), the _angles variant (support mask in the gradient step), and other
+    numbers of column ranges per problem."""
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=10.0)
+    inp = build_trials(p, 0, 9, seed=8, shared_pilots=True)
+    (S1, Y1, c1), (S0, Y0, c0) = _solve_pair(inp, 12, B=inp["B"][0])
+    assert _close(S1, S0, 3e-6) and _close(Y1, Y0, 5e-6)
+    (Sa1, _, _), (Sa0, _, _) = _solve_pair(inp, 12, B=inp["B"][0], indx=inp["indx_S"])
+    assert _close(Sa1, Sa0, 3e-6) and not _close(Sa1, S1, 1e-3)                 # the mask does something
+    for parts in ("1", "2", "8"):
+        (Sp, Yp, _), _ = _solve_pair(inp, 6, B=inp["B"][0], JSTSP_FUSED_PARTS=parts)
+        (Sq, Yq, _), _ = _solve_pair(inp, 6, B=inp["B"][0])
+        assert _close(Sp, Sq, 2e-6) and _close(Yp, Yq, 2e-6)
