@@ -174,7 +174,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     // one pass over the dictionary per iteration (fused.hip); JSTSP_FUSED_PARTS = column ranges per problem
     // (measured at configs[1], 8 / 4 ranges: 4.42 / 4.34 ms per iteration - fewer partial sums to write and add)
     const int fparts = std::max(1, getenv("JSTSP_FUSED_PARTS") ? atoi(getenv("JSTSP_FUSED_PARTS")) : 4);
-    const bool want_fused = (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : true) && approx && want_ce &&
+    const bool want_fused = (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : true) && approx &&
                             Imax > 1 && fused_shape_ok(N, M, G2, fparts);
     if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);
     if (memspace == JSTSP_HOST) {
@@ -332,9 +332,11 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     // Fused pass (fused.hip): after the gradient step of iteration it, ONE kernel forms Xs = A S B, the V2 / X / V1 / k
     // updates of :61-65 and of the next iteration's :38-43, and the first factor K B^H of the next :47 - the dictionary
     // is read once per iteration instead of twice.  The next iteration then starts at the gradient step.
-    const bool fusedp = want_fused && zfly && !svt_skip;
-    // Y = (I - Q) Z formed inside the pass (JSTSP_FUSED_Y=0: by a GEMM before it)
-    const bool fusedy = fusedp && (getenv("JSTSP_FUSED_Y") ? atoi(getenv("JSTSP_FUSED_Y")) != 0 : true);
+    // Y = (I - Q) Z formed inside the pass (JSTSP_FUSED_Y=0: by a GEMM before it, from X and V1)
+    const bool fy_env = getenv("JSTSP_FUSED_Y") ? atoi(getenv("JSTSP_FUSED_Y")) != 0 : true;
+    // with convergence_error: G_z comes from the three-Gram pass over X, V1 (zfly); without: from the Z the pass stores
+    const bool fusedp = want_fused && hmax && !svt_skip && (want_ce ? zfly : fy_env);
+    const bool fusedy = fusedp && fy_env;
     FusedWS fw;
     if (fusedp) {
         JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts));
@@ -415,8 +417,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                     dy.e_f0 = w.invD;                                                            // (alignment checks only)
                     JSTSP_TRY(launch_cgemm(ctx, dy, GEMM_MISC));
                 }
-            } else
-            JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr, svt_skip));
+            } else {
+                JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr, svt_skip));
+                if (fusedy) JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
+            }
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
         }
         if (want_ce && !(zfly && it + 1 < Imax)) {              // s2: Gram of [X | V1]

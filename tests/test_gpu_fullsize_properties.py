@@ -100,7 +100,7 @@ def test_proposed_full_size_invariants_and_oracle_sample():
         assert nz <= allowed
 
 
-def _solve_pair(inp, Imax, B=None, indx=None, **env):
+def _solve_pair(inp, Imax, B=None, indx=None, want_ce=True, **env):
     """The same solve with the fused pass (default) and with the three kernels it replaces (JSTSP_FUSED=0)."""
     import os
     import torch
@@ -113,13 +113,16 @@ def _solve_pair(inp, Imax, B=None, indx=None, **env):
         try:
             args = (inp["subY"], inp["Omega"], inp["A"], inp["B"] if B is None else B, Imax, inp["tau_Y"].numpy(),
                     inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate")
-            r = J.proposed_algorithm(*args) if indx is None else J.proposed_algorithm_angles(*args[:2], indx, *args[2:], None)
+            if indx is None:
+                r = J.proposed_algorithm(*args, want_ce=want_ce)
+            else:
+                r = J.proposed_algorithm_angles(*args[:2], indx, *args[2:], None, want_ce=want_ce)
             torch.cuda.synchronize()
         finally:
             os.environ.pop("JSTSP_FUSED", None)
             for k in env:
                 os.environ.pop(k, None)
-        out.append([x.cpu().numpy() for x in r])
+        out.append([None if x is None else x.cpu().numpy() for x in r])
     return out
 
 
@@ -156,3 +159,16 @@ def test_fused_pass_with_shared_pilots_angles_and_column_ranges():
         (Sp, Yp, _), _ = _solve_pair(inp, 6, B=inp["B"][0], JSTSP_FUSED_PARTS=parts)
         (Sq, Yq, _), _ = _solve_pair(inp, 6, B=inp["B"][0])
         assert _close(Sp, Sq, 2e-6) and _close(Yp, Yq, 2e-6)
+
+
+def test_fused_pass_without_convergence_error():
+    """Two outputs only (the sweep drivers' call): no three-Gram pass exists, the SVT Gram comes from the Z the pass stores."""
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    inp = build_trials(SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=5.0), 0, 10, seed=21)
+    for Imax in (2, 9):
+        (S1, Y1, c1), (S0, Y0, c0) = _solve_pair(inp, Imax, want_ce=False)
+        assert c1 is None and c0 is None
+        assert _close(S1, S0, 3e-6) and _close(Y1, Y0, 5e-6)
+    (S1, _, _), _ = _solve_pair(inp, 9, want_ce=False)
+    (Sc, _, _), _ = _solve_pair(inp, 9, want_ce=True)
+    assert _close(S1, Sc, 3e-6)                       # asking for convergence_error does not change S
