@@ -16,7 +16,8 @@
 // (lane = n, registers = 4 consecutive m) IS the B-operand layout of phase B's 16x16x32 MFMA: k goes from the
 // element-wise update to the second product through a 16-KiB LDS exchange and never touches HBM.
 //
-// Shapes: N = 64, G2 = 512, M a multiple of 32 * parts.  Everything else keeps the three-kernel path.
+// Shapes: N = 64, G2 = 128, 256, 384 or 512 (GB = G2 / 128 blocks of 16 rows g per wave), M a multiple of 32 * parts.
+// Everything else keeps the three-kernel path.
 #include "solver_common.h"
 #include <cstdlib>
 
@@ -180,8 +181,8 @@ __global__ __launch_bounds__(256) void poison_kernel(const uint32_t *ovf, float2
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) S[i] = make_float2(q, q);
 }
 
-// DBG (timing experiments only, results are wrong): 1 skips the phase-A products, 2 the element-wise loads / stores,
-// 4 the phase-B products, 8 the tile refill
+// DBG != 0 (timing experiments only, results are wrong; not instantiated by default): 1 skips the phase-A products,
+// 2 the element-wise loads / stores, 4 the phase-B products, 8 the tile refill
 // YIN: Y = (I - Q) Z of the next iteration is formed here (Z from d.Zin, fragments of I - Q from d.Wqp) instead of read
 template <int GB, int DBG, bool YIN>
 __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 
 bool fused_shape_ok(int N, int M, int G2, int parts)
 {
-    return N == 64 && G2 == 512 && parts > 0 && M % (32 * parts) == 0;
+    return N == 64 && G2 >= 128 && G2 <= 512 && G2 % 128 == 0 && parts > 0 && M % (32 * parts) == 0;
 }
 
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts)
@@ -547,33 +548,37 @@ int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long s
     return 0;
 }
 
+template <int GB, bool YIN> static int launch_fused_gb(jstsp_ctx *ctx, const FusedDesc &d)
+{
+    const size_t sh = (size_t)32 * (128 * GB * 8 + FPAD) + 24576;
+    const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
+    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB, 0, YIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL((fused_pass_kernel<GB, 0, YIN>), dim3(grid), dim3(512), sh, ctx->stream, d);
+    return 0;
+}
+
 int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d)
 {
     JSTSP_REQUIRE(fused_shape_ok(64, d.M, d.G2, d.parts), JSTSP_E_UNSUPPORTED, "fused pass: shape");
-    constexpr int GB = 4;
-    const size_t sh = (size_t)32 * (128 * GB * 8 + FPAD) + 24576;
-    const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
-    const int dbg = getenv("JSTSP_FUSED_DBG") ? atoi(getenv("JSTSP_FUSED_DBG")) : 0;
     prof_begin(ctx, "fused_pass");
-#define JSTSP_FUSED_LAUNCH(D, Y)                                                                                             \
-    {                                                                                                                        \
-        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB, D, Y>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)sh));                                                                             \
-        hipLaunchKernelGGL((fused_pass_kernel<GB, D, Y>), dim3(grid), dim3(512), sh, ctx->stream, d);                        \
-    }
+    int rc = 0;
     if (d.Wqp) {
-        JSTSP_FUSED_LAUNCH(0, true)
-    } else
-    switch (dbg) {
-    case 1: JSTSP_FUSED_LAUNCH(1, false) break;
-    case 2: JSTSP_FUSED_LAUNCH(2, false) break;
-    case 4: JSTSP_FUSED_LAUNCH(4, false) break;
-    case 8: JSTSP_FUSED_LAUNCH(8, false) break;
-    case 15: JSTSP_FUSED_LAUNCH(15, false) break;
-    default: JSTSP_FUSED_LAUNCH(0, false) break;
+        switch (d.G2 / 128) {
+        case 1: rc = launch_fused_gb<1, true>(ctx, d); break;
+        case 2: rc = launch_fused_gb<2, true>(ctx, d); break;
+        case 3: rc = launch_fused_gb<3, true>(ctx, d); break;
+        default: rc = launch_fused_gb<4, true>(ctx, d); break;
+        }
+    } else {        // Y read from memory (JSTSP_FUSED_Y=0)
+        switch (d.G2 / 128) {
+        case 1: rc = launch_fused_gb<1, false>(ctx, d); break;
+        case 2: rc = launch_fused_gb<2, false>(ctx, d); break;
+        case 3: rc = launch_fused_gb<3, false>(ctx, d); break;
+        default: rc = launch_fused_gb<4, false>(ctx, d); break;
+        }
     }
-#undef JSTSP_FUSED_LAUNCH
     prof_end(ctx, "fused_pass");
+    JSTSP_TRY(rc);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -172,3 +172,15 @@ def test_fused_pass_without_convergence_error():
     (S1, _, _), _ = _solve_pair(inp, 9, want_ce=False)
     (Sc, _, _), _ = _solve_pair(inp, 9, want_ce=True)
     assert _close(S1, Sc, 3e-6)                       # asking for convergence_error does not change S
+
+
+@pytest.mark.parametrize("L,T", [(2, 16), (4, 32), (6, 64), (8, 33)])
+def test_fused_pass_other_delay_counts_and_frames(L, T):
+    """G2 = L*Gt = 128, 256, 384 (one, two, three 16-row blocks per wave in the second product) and a frame whose M = T*Nt is
+    not a multiple of the column ranges (there the three kernels run: same answer by construction)."""
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    inp = build_trials(SweepParams(Nt=64, Nr=64, L=L, T=T, Mr=8, snr_db=5.0), 0, 5, seed=31)
+    (S1, Y1, c1), (S0, Y0, c0) = _solve_pair(inp, 8)
+    assert np.all(np.isfinite(S1)) and _close(S1, S0, 3e-6) and _close(Y1, Y0, 5e-6)
+    fin = np.isfinite(c0) & np.isfinite(c1)
+    assert np.max(np.abs(c1[fin] - c0[fin]) / np.abs(c0[fin])) < 1e-4
