@@ -398,9 +398,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                 // data, but run beside each other the spectral norm of V2 came out different in the last bits from run to run
                 // (a few of the batch x Imax values of convergence_error(:,2), up to 1.6e-4 after the Lanczos recurrence; S, Y
                 // and the other two columns bit-identical) - with this order every output is bit-reproducible again, as on
-                // the three-kernel path.  Cause not found: it is not the split-f16 Gram kernel (the fp32 GEMM in its place shows the
-                // same), not the non-temporal stores of the pass, not the order of the Lanczos launches.  No measurable cost.
-                if (fusedp && it > 0 && !(getenv("JSTSP_DBG_CE") && atoi(getenv("JSTSP_DBG_CE")) == 6)) JSTSP_HIP(hipStreamWaitEvent(s1, ev_gv2, 0));
+                // the three-kernel path in hundreds of fresh-process runs (one unexplained exception inside the test suite).  Cause not
+                // found: it is not the split-f16 Gram kernel (the fp32 GEMM in its place shows the same), not the non-temporal
+                // stores of the pass, not the order of the Lanczos launches.  No measurable cost.  JSTSP_OVERLAP=0: one stream.
+                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_gv2, 0));
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
                                         w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));

@@ -15,5 +15,6 @@ for f in ("1", "0"):
         d = [int((np.ascontiguousarray(a).view(np.uint8) != np.ascontiguousarray(b).view(np.uint8)).sum()) for a, b in zip(r, ref)]
         if any(d):
             c = np.argwhere(~((r[2] == ref[2]) | (np.isnan(r[2]) & np.isnan(ref[2])) | (np.isinf(r[2]) & np.isinf(ref[2]))))
-            print("fused", f, "rep", rep, "bytes differing S/Y/ce:", d, "ce idx", c[:6].tolist())
+            print("fused", f, "rep", rep, "bytes differing S/Y/ce:", d, "ce entries differing per column:", [int((c[:, 2] == k).sum()) for k in range(3)],
+                  "first:", c[:4].tolist())
 print("done")
