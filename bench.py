@@ -178,6 +178,9 @@ def main():
                     "algorithmic_tflops": round(2 * flops_per_launch / (avg_f * 1e-3) / 1e12, 1),
                     "note": "the three kernels this pass replaces (JSTSP_FUSED=0) run at 0.66-0.68 of the HBM peak each but move "
                             "16.5 GB per iteration instead of 9.9 GB"}
+        if roofline["traffic"]:     # measured bytes (PMC) over the same duration: what the memory system actually delivers
+            roofline["traffic_rate"] = round(roofline["traffic"] / (avg_f * 1e-3) / 1e9, 1)
+            roofline["traffic_frac"] = round(roofline["traffic"] / (avg_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     elif n_s:
         # Three-kernel path (JSTSP_FUSED=0 or a shape the fused pass does not take): dominant kernel hgemm2_kernel<EPI_UPDATE_C>
         # = Xs = (A S) B with the C / V2 update in its epilogue (:58,:61,:65); algorithmic bytes per launch = packed dictionary
