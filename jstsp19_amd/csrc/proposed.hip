@@ -394,14 +394,16 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             if (zfly) {
                 // (the spectral norms of X, V1 of the previous iteration read the G_x, G_v1 partials this pass overwrites)
                 if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_lxv, 0));
-                // The three-Gram pass also waits for the Gram of V2 of the previous iteration (side stream s2).  The two share no
-                // data, but run beside each other the spectral norm of V2 came out different in the last bits from run to run
-                // (a few of the batch x Imax values of convergence_error(:,2), up to 1.6e-4 after the Lanczos recurrence; S, Y
-                // and the other two columns bit-identical) - with this order every output is bit-reproducible again, as on
-                // the three-kernel path in hundreds of fresh-process runs (one unexplained exception inside the test suite).  Cause not
-                // found: it is not the split-f16 Gram kernel (the fp32 GEMM in its place shows the same), not the non-temporal
-                // stores of the pass, not the order of the Lanczos launches.  No measurable cost.  JSTSP_OVERLAP=0: one stream.
-                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_gv2, 0));
+                // The three-Gram pass must not run beside a lambda_max kernel: a Lanczos workgroup that shares a CU with
+                // workgroups of hgram3_kernel (246 VGPRs, long MFMA runs) now and then returns a different Ritz value (0.5 %
+                // off in the worst case seen; same input, same kernel - reproduced in isolation by tools/probe/lanczos_race.cpp:
+                // 6..28 of 3184 values beside hgram3_kernel, 0 alone, beside hgram_kernel or beside an LDS-heavy dummy, 0 when
+                // the Lanczos kernel asks for the whole LDS of a CU).  Neither kernel has an out-of-range LDS index, and the
+                // Householder + Sturm kernel is affected the same way, so this is handled as an ordering rule: the pass waits
+                // for the spectral norms of the previous iteration (ev_ce: Gram of V2, its lambda_max, the ratio); lambda_max
+                // of X, V1 of THIS iteration is launched after the pass (ev_gxv) and awaited by the next one (ev_lxv).
+                // With it every output is bit-reproducible from run to run, as on the three-kernel path.
+                if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(s1, ev_ce, 0));
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
                                         w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));

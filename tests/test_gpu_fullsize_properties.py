@@ -188,7 +188,8 @@ def test_fused_pass_other_delay_counts_and_frames(L, T):
 
 def test_default_path_is_bit_reproducible():
     """Three streams run between two fused passes: every output must still be the same bits from run to run (the order of the
-    side chains is fixed by events, nothing is accumulated with atomics; see DESIGN.md section 5, 'Reproducibility')."""
+    side chains is fixed by events, nothing is accumulated with atomics, and the three-Gram pass never runs beside a lambda_max
+    kernel: DESIGN.md section 5, 'Reproducibility'; tools/probe/lanczos_race.cpp)."""
     import torch
     import jstsp19_amd as J
     from jstsp19_amd.system_model import SweepParams, build_trials
@@ -202,11 +203,6 @@ def test_default_path_is_bit_reproducible():
 
     ref = run()
     for rep in range(5):
-        S, Y, c = run()
-        for name, a, b in (("S", S, ref[0]), ("Y", Y, ref[1]), ("ce(:,1)", c[..., 0], ref[2][..., 0]), ("ce(:,3)", c[..., 2], ref[2][..., 2])):
+        for name, a, b in zip(("S", "Y", "convergence_error"), run(), ref):
             same = (a == b) | (np.isnan(a) & np.isnan(b))
             assert same.all(), "run %d: %s differs at %s" % (rep + 1, name, np.argwhere(~same)[:6].tolist())
-        # convergence_error(:,2): the spectral norm of V2 is computed on a side stream beside the next three-Gram pass; it has been
-        # seen to differ in the last bits between runs when the two overlap - a diagnostic, not fed back
-        fin = np.isfinite(ref[2][..., 1])
-        assert np.max(np.abs(c[..., 1][fin] - ref[2][..., 1][fin]) / ref[2][..., 1][fin]) < 1e-3
