@@ -10,11 +10,18 @@
 // and keeps the N x G2 sums P of its column range in registers; the per-range partials are summed afterwards.
 //
 // The same B tile serves as an MFMA operand with g as contraction index (phase A) and with m as contraction index
-// (phase B).  Its LDS image is [plane][m/4][g/4][4 m][4 g] halves: a row of a 4 x 4 micro-block is a phase-A
-// fragment piece (ds_read_b64), a column of it — picked out of the 32-byte block with v_perm_b32 — a phase-B piece.
-// Everything is computed transposed (Xs^T = B^T (A S)^T) so that the accumulator layout of phase A
-// (lane = n, registers = 4 consecutive m) IS the B-operand layout of phase B's 16x16x32 MFMA: k goes from the
-// element-wise update to the second product through a 16-KiB LDS exchange and never touches HBM.
+// (phase B).  Its LDS image is [plane][m/4][g/8][4 m][8 g] halves: a row of a micro-block (16 bytes: 8 consecutive g of one m)
+// is a phase-A fragment (ds_read_b128); a column of four halves (4 consecutive m of one g), delivered by the transposing LDS
+// read ds_read_b64_tr_b16, is half a phase-B fragment.  Everything is computed transposed (Xs^T = B^T (A S)^T,
+// P^T = conj(B) K^T) so that the accumulator layout of phase A (lane = n, registers = 4 consecutive m) IS the B-operand
+// layout of phase B's 16x16x32 MFMA: k goes from the element-wise update to the second product through a 24-KiB LDS
+// exchange (6 planes: k_re, k_im split in two halves each, and -k_re) and never touches HBM.  Y = (I - Q) Z of the next
+// iteration is formed in the kernel as well (YIN): Z of the next tile is requested during phase B and multiplied by the
+// fragments of I - Q after it.
+//
+// The kernel lives at the register limit (256 VGPRs with the 64 x 512 complex sums of a column range in 128 of them):
+// see DESIGN.md section 5 for what made it fit without spills, and for the one ordering rule its use under three
+// streams needs (section 5, 'Reproducibility').
 //
 // Shapes: N = 64, G2 = 128, 256, 384 or 512 (GB = G2 / 128 blocks of 16 rows g per wave), M a multiple of 32 * parts.
 // Everything else keeps the three-kernel path.
