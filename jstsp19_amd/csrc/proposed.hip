@@ -173,7 +173,10 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                                   : rnd256((size_t)nB * G2 * G2 * sizeof(float2)) + hinv_bytes(G2, nB));
     // one pass over the dictionary per iteration (fused.hip); JSTSP_FUSED_PARTS = column ranges per problem
     // (measured at configs[1], 8 / 4 ranges: 4.42 / 4.34 ms per iteration - fewer partial sums to write and add)
-    const int fparts = std::max(1, getenv("JSTSP_FUSED_PARTS") ? atoi(getenv("JSTSP_FUSED_PARTS")) : 4);
+    // (when M / 32 is not a multiple of 4: 2 ranges, or 1)
+    const int ftiles = (M % 32 == 0) ? M / 32 : 0;
+    const int fparts = std::max(1, getenv("JSTSP_FUSED_PARTS") ? atoi(getenv("JSTSP_FUSED_PARTS"))
+                                                                : (ftiles % 4 == 0 ? 4 : (ftiles % 2 == 0 ? 2 : 1)));
     const bool want_fused = (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : true) && approx &&
                             Imax > 1 && fused_shape_ok(N, M, G2, fparts);
     if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);

@@ -176,8 +176,8 @@ def test_fused_pass_without_convergence_error():
 
 @pytest.mark.parametrize("L,T", [(2, 16), (4, 32), (6, 64), (8, 33)])
 def test_fused_pass_other_delay_counts_and_frames(L, T):
-    """G2 = L*Gt = 128, 256, 384 (one, two, three 16-row blocks per wave in the second product) and a frame whose M = T*Nt is
-    not a multiple of the column ranges (there the three kernels run: same answer by construction)."""
+    """G2 = L*Gt = 128, 256, 384 (one, two, three 16-row blocks per wave in the second product) and a frame whose M = T*Nt = 2112
+    is 66 tiles: two column ranges per problem instead of four."""
     from jstsp19_amd.system_model import SweepParams, build_trials
     inp = build_trials(SweepParams(Nt=64, Nr=64, L=L, T=T, Mr=8, snr_db=5.0), 0, 5, seed=31)
     (S1, Y1, c1), (S0, Y0, c0) = _solve_pair(inp, 8)
