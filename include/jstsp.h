@@ -36,6 +36,7 @@ extern "C" {
 
 typedef struct jstsp_ctx jstsp_ctx;
 typedef struct { float re, im; } jstsp_c32;
+typedef struct { double re, im; } jstsp_c64;   /* MATLAB's own element type (interleaved complex double) */
 
 enum { JSTSP_HOST = 0, JSTSP_DEVICE = 1 };
 
@@ -258,6 +259,49 @@ typedef struct jstsp_trials {
 
 int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *model, uint64_t seed, int sweep_idx,
                            long long trial0, int batch, const jstsp_trials *out, int memspace);
+
+/* ---- the reference's own element type at the boundary ------------------------------------------
+ * Same functions, same argument meaning, arrays as MATLAB holds them: interleaved complex DOUBLE, and the 0/1 masks as
+ * double (proposed_hbf.m:36-41 builds Omega with zeros()).  Inputs are narrowed and outputs widened on the device;
+ * the arithmetic in between is the _c32 path's (results agree with the float64 reference to
+ * fp32 accuracy, not beyond).  tau / rho / ce / index arrays are as in the _c32 form.  A JSTSP_HOST 'std' call
+ * reports JSTSP_E_ILLCOND like its _c32 form. */
+int jstsp_correlate_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                        const jstsp_c64 *K, const jstsp_c64 *A, long long strideA,
+                        const jstsp_c64 *B, long long strideB, jstsp_c64 *out, int memspace);
+int jstsp_synthesize_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                         const jstsp_c64 *S, const jstsp_c64 *A, long long strideA,
+                         const jstsp_c64 *B, long long strideB, jstsp_c64 *out, int memspace);
+/* proposed_algorithm.m:1 / proposed_algorithm_angles.m:1 */
+int jstsp_proposed_algorithm_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                                 const jstsp_c64 *subY, const double *Omega,
+                                 const jstsp_c64 *A, long long strideA,
+                                 const jstsp_c64 *B, long long strideB,
+                                 int Imax, const double *tau_Y, const double *tau_S,
+                                 const double *rho, int type, const int32_t *indx_S,
+                                 jstsp_c64 *S_out, jstsp_c64 *Y_out, double *ce_out, int memspace);
+/* svt.m:1 */
+int jstsp_svt_c64(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c64 *Y,
+                  const double *tau, jstsp_c64 *X, int memspace);
+/* OMP.m:1 */
+int jstsp_omp_c64(jstsp_ctx *ctx, int measures, int size_d, int batch,
+                  const jstsp_c64 *A, long long strideA, const jstsp_c64 *v, int m,
+                  jstsp_c64 *x_hat, int32_t *index_out, jstsp_c64 *target_out, int memspace);
+/* sparse_admm.m:1 */
+int jstsp_sparse_admm_c64(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int Gt, int batch,
+                          const jstsp_c64 *Htrue, const jstsp_c64 *OH,
+                          const jstsp_c64 *Dr, const jstsp_c64 *Dt, int Imax,
+                          jstsp_c64 *S_out, double *ce_out, int memspace);
+/* mc_svt.m:1, mc_admm.m:1 */
+int jstsp_mc_svt_c64(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c64 *OH,
+                     const double *Omega, int Imax, const double *tau, const double *rho,
+                     jstsp_c64 *X_out, int memspace);
+int jstsp_mc_admm_c64(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c64 *Htrue,
+                      const jstsp_c64 *OH, const double *Omega, int Imax, const double *tau,
+                      const double *rho, jstsp_c64 *X_out, double *ce_out, int memspace);
+/* vamp.m:1 */
+int jstsp_vamp_c64(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c64 *y, const jstsp_c64 *A,
+                   long long strideA, double sigma, double L, int nit, jstsp_c64 *x_out, int memspace);
 
 /* Per-kernel timing of the last proposed_algorithm call made with profiling enabled:
  * jstsp_set_profiling(ctx, 1) brackets every launch of the dominant kernel with HIP

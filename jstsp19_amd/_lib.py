@@ -81,6 +81,11 @@ SIGNATURES = {
 }
 
 
+for _n in ("correlate", "synthesize", "proposed_algorithm", "svt", "omp", "sparse_admm", "mc_svt", "mc_admm", "vamp"):
+    # the double-complex forms take the same argument lists (pointers are void* here)
+    SIGNATURES["jstsp_%s_c64" % _n] = SIGNATURES["jstsp_%s_c32" % _n]
+
+
 class JstspError(RuntimeError):
     pass
 
