@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
                                                        int nsplit, long long sGs, const TrialParams *prm,
                                                        const float *tau, float2 *Q, float *lam_out,
                                                        float2 *Uwarm, int warm, float conv_tol, int max_sweeps,
-                                                       int *sweep_stat, const uint32_t *skip_amax)
+                                                       int *sweep_stat, const uint32_t *skip_amax, int fn_aware)
 {
     constexpr int LD = NE + 1;
     constexpr int H = NE / 2;
@@ -178,6 +178,16 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
         __syncthreads();
     }
     const float dmax = red[1];
+    // How far to diagonalise.  A coupling e_ij left between eigen-directions i and j changes f(G) = tau G^(-1/2)
+    // (the projector when no singular value is clipped) by tau e_ij / (s_i s_j (s_i + s_j)), hence Q Z by
+    // tau |e_ij| / (min(s_i, s_j) (s_i + s_j)) in one singular direction (first-order perturbation of a matrix
+    // function: the divided difference of f).  Once that is below 2^-27 of ||Z||_2 = s_max >= sqrt(dmax) for every
+    // pair - a quarter of an fp32 ulp of the data - further sweeps cannot change Y.  With the reference's
+    // tau_Y = 1 / ||Y||_F^2 this is reached one to two sweeps before the plain tolerance.  The rule uses the levels a
+    // sweep STARTED from (what it leaves is lower still) and needs them below 1e-2 in the plain measure too, so that
+    // the diagonal entries it reads are eigenvalue estimates; a clipped spectrum (some s_i <= tau) keeps the plain rule.
+    const float tv0 = (mode == EIG_SVT_Q && fn_aware) ? (tau ? tau[t] : prm[t].tauY_rho) : 0.f;
+    const float fn_lim = 7.4505806e-9f * sqrtf(dmax);
 
     constexpr int NBLKS = H * H;                       // 2x2 blocks of G per round
     constexpr int BPT = (NBLKS + NT - 1) / NT;           // blocks per thread
@@ -185,8 +195,8 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
     int sweeps_done = 0;
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
         ++sweeps_done;
-        if (tid == 0) red[0] = 0.f;
-        float worst = 0.f;
+        if (tid == 0) { red[0] = 0.f; red[3] = 0.f; }
+        float worst = 0.f, worst_fn = 0.f;
         for (int s = 0; s < NE - 1; ++s) {
             // -- rotation of each of the H disjoint pairs of this round
             if (tid < H) {
@@ -199,6 +209,10 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
                 const float scale = sqrtf(fabsf(a) * fabsf(dd));
                 if (ab > 0.f && ab > 1e-8f * scale) {
                     worst = fmaxf(worst, ab / fmaxf(scale, 1e-3f * dmax));
+                    if (tv0 > 0.f) {       // min(s_i, s_j) (s_i + s_j) = s_i s_j + min(s_i, s_j)^2
+                        const float lo2 = fminf(a, dd);
+                        worst_fn = fmaxf(worst_fn, (lo2 > tv0 * tv0) ? tv0 * ab / (scale + lo2) : 3.0e38f);
+                    }
                     const float zeta = (dd - a) / (2.f * ab);
                     const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
                     c = 1.f / sqrtf(1.f + tt * tt);
@@ -263,11 +277,14 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
             }
             __syncthreads();
         }
-        if (tid < H) atomicMax(reinterpret_cast<int *>(&red[0]), __float_as_int(worst));
+        if (tid < H) {
+            atomicMax(reinterpret_cast<int *>(&red[0]), __float_as_int(worst));
+            atomicMax(reinterpret_cast<int *>(&red[3]), __float_as_int(worst_fn));
+        }
         __syncthreads();
-        const float w = red[0];
+        const float w = red[0], wf = red[3];
         __syncthreads();
-        if (w < conv_tol) break;
+        if (w < conv_tol || (tv0 > 0.f && w < 1e-2f && wf < fn_lim)) break;
     }
 
     if (sweep_stat && tid == 0) atomicAdd(sweep_stat, sweeps_done);
@@ -693,10 +710,11 @@ static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const fl
     // (|dNMSE| 1e-7 at both benchmark shapes).
     static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 1e-4f;
     static const int maxsw = getenv("JSTSP_JACOBI_SWEEPS") ? atoi(getenv("JSTSP_JACOBI_SWEEPS")) : 14;
+    static const int fn_aware = getenv("JSTSP_JACOBI_FN") ? atoi(getenv("JSTSP_JACOBI_FN")) : 1;
     static int *stat = nullptr;
     if (getenv("JSTSP_JACOBI_STAT") && !stat) { (void)hipMalloc((void **)&stat, 4); (void)hipMemset(stat, 0, 4); }
     hipLaunchKernelGGL((jacobi2_kernel<NE, NT>), dim3(batch), dim3(NT), sh, ctx->stream, mode, n, Gpart, sGt, nsplit,
-                       sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, stat, skip_amax);
+                       sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, stat, skip_amax, fn_aware);
     if (stat) {
         static int calls = 0;
         if (++calls % 100 == 0) {
