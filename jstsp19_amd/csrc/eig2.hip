@@ -204,21 +204,25 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
                 rr_pair2(NE, s, tid, p, q);
                 const float a = G[p + LD * p].x, dd = G[q + LD * q].x;
                 const float2 bq = G[p + LD * q];
-                const float ab = sqrtf(bq.x * bq.x + bq.y * bq.y);
+                // hardware sqrt / rcp / rsq (1 ulp): the chain below is the serial part of a round; a rotation that is
+                // unitary to 2 ulp instead of 1 costs the iteration nothing (Jacobi corrects itself)
+                const float ab2 = bq.x * bq.x + bq.y * bq.y;
+                const float ab = __builtin_amdgcn_sqrtf(ab2);
                 float c = 1.f, wx = 0.f, wy = 0.f;
-                const float scale = sqrtf(fabsf(a) * fabsf(dd));
+                const float scale = __builtin_amdgcn_sqrtf(fabsf(a) * fabsf(dd));
                 if (ab > 0.f && ab > 1e-8f * scale) {
-                    worst = fmaxf(worst, ab / fmaxf(scale, 1e-3f * dmax));
+                    const float iab = __builtin_amdgcn_rcpf(ab);
+                    worst = fmaxf(worst, ab * __builtin_amdgcn_rcpf(fmaxf(scale, 1e-3f * dmax)));
                     if (tv0 > 0.f) {       // min(s_i, s_j) (s_i + s_j) = s_i s_j + min(s_i, s_j)^2
                         const float lo2 = fminf(a, dd);
-                        worst_fn = fmaxf(worst_fn, (lo2 > tv0 * tv0) ? tv0 * ab / (scale + lo2) : 3.0e38f);
+                        worst_fn = fmaxf(worst_fn, (lo2 > tv0 * tv0) ? tv0 * ab * __builtin_amdgcn_rcpf(scale + lo2) : 3.0e38f);
                     }
-                    const float zeta = (dd - a) / (2.f * ab);
-                    const float tt = (zeta >= 0.f ? 1.f : -1.f) / (fabsf(zeta) + sqrtf(1.f + zeta * zeta));
-                    c = 1.f / sqrtf(1.f + tt * tt);
-                    const float sn = tt * c;
-                    wx = sn * bq.x / ab;
-                    wy = sn * bq.y / ab;
+                    const float zeta = 0.5f * (dd - a) * iab;
+                    const float tt = copysignf(__builtin_amdgcn_rcpf(fabsf(zeta) + __builtin_amdgcn_sqrtf(1.f + zeta * zeta)), zeta);
+                    c = __builtin_amdgcn_rsqf(1.f + tt * tt);
+                    const float sn = tt * c * iab;
+                    wx = sn * bq.x;
+                    wy = sn * bq.y;
                 }
                 rot[4 * tid + 0] = c; rot[4 * tid + 1] = wx; rot[4 * tid + 2] = wy;
                 rot[4 * tid + 3] = __int_as_float(p | (q << 16));
