@@ -13,8 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libjstsp_mi355x.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -packed-fp32-ops: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code.  Measured on MI355X (round 2,
+# tools/probe/lanczos_race.cpp): a kernel whose dependent fp32 chains hipcc had packed (the Lanczos lambda_max kernel)
+# returned different results from run to run whenever waves of an MFMA-heavy kernel shared its SIMDs - 5 of 3184 runs
+# beside the three-Gram pass, 3041 of 3184 beside an MFMA loop with barriers, 0 alone - and is bit-reproducible in
+# every case once compiled without the packed instructions.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc"]
+         "-fno-gpu-rdc", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _sources():
@@ -42,8 +47,10 @@ def _compile(src):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
+        # (the host half of the compilation does not know the device feature and says so: not worth showing)
+        err = "".join(l for l in r.stderr.splitlines(True) if "is not a recognized feature for this target" not in l)
+        if err.strip():
+            sys.stderr.write(err)
     return obj
 
 

@@ -397,16 +397,9 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
             if (zfly) {
                 // (the spectral norms of X, V1 of the previous iteration read the G_x, G_v1 partials this pass overwrites)
                 if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_lxv, 0));
-                // The three-Gram pass must not run beside a lambda_max kernel: a Lanczos workgroup that shares a CU with
-                // workgroups of hgram3_kernel (246 VGPRs, long MFMA runs) now and then returns a different Ritz value (0.5 %
-                // off in the worst case seen; same input, same kernel - reproduced in isolation by tools/probe/lanczos_race.cpp:
-                // 6..28 of 3184 values beside hgram3_kernel, 0 alone, beside hgram_kernel or beside an LDS-heavy dummy, 0 when
-                // the Lanczos kernel asks for the whole LDS of a CU).  Neither kernel has an out-of-range LDS index, and the
-                // Householder + Sturm kernel is affected the same way, so this is handled as an ordering rule: the pass waits
-                // for the spectral norms of the previous iteration (ev_ce: Gram of V2, its lambda_max, the ratio); lambda_max
-                // of X, V1 of THIS iteration is launched after the pass (ev_gxv) and awaited by the next one (ev_lxv).
-                // With it every output is bit-reproducible from run to run, as on the three-kernel path.
-                if (it > 0 && want_ce) JSTSP_HIP(hipStreamWaitEvent(s1, ev_ce, 0));
+                // (Until the library was compiled without packed-fp32 instructions - see build.py - this pass also had to
+                // wait for the previous iteration's lambda_max kernels: the Lanczos kernel, whose complex arithmetic hipcc had
+                // turned into v_pk_fma_f32 chains, returned different Ritz values when MFMA-heavy waves shared its SIMDs.)
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
                                         w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));

@@ -53,3 +53,28 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_device_code_has_no_packed_fp32_instructions(tmp_path):
+    """The library is built with -target-feature -packed-fp32-ops (jstsp19_amd/build.py, DESIGN.md section 5
+    'Reproducibility': dependent v_pk_fma_f32 chains returned run-to-run different results beside MFMA-heavy waves on
+    MI355X).  Checked on the code objects inside the shared library."""
+    import shutil
+    import subprocess
+    from jstsp19_amd import build as B
+    assert "-packed-fp32-ops" in B.FLAGS
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not available")
+    lib = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", lib], cwd=str(tmp_path), check=True, capture_output=True)
+    devs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert devs, "no gfx950 code object found in the library"
+    mfma = 0
+    for f in devs:
+        asm = subprocess.run([objdump, "-d", str(tmp_path / f)], capture_output=True, text=True, check=True).stdout
+        mfma += "v_mfma_f32" in asm
+        for op in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
+            assert op not in asm, "%s found in %s" % (op, f)
+    assert mfma >= 5        # the disassembly really is the kernels'

@@ -188,8 +188,9 @@ def test_fused_pass_other_delay_counts_and_frames(L, T):
 
 def test_default_path_is_bit_reproducible():
     """Three streams run between two fused passes: every output must still be the same bits from run to run (the order of the
-    side chains is fixed by events, nothing is accumulated with atomics, and the three-Gram pass never runs beside a lambda_max
-    kernel: DESIGN.md section 5, 'Reproducibility'; tools/probe/lanczos_race.cpp)."""
+    side chains is fixed by events, nothing is accumulated with atomics, and the library is compiled without packed-fp32
+    instructions, whose dependent chains misbehaved beside MFMA-heavy waves: DESIGN.md section 5, 'Reproducibility';
+    tools/probe/lanczos_race.cpp)."""
     import torch
     import jstsp19_amd as J
     from jstsp19_amd.system_model import SweepParams, build_trials

@@ -1,5 +1,9 @@
 // Is lambda_max (Lanczos kernel) bit-reproducible when other kernels run beside it?  One stream repeats launch_lmax on the SAME
-// Gram partials; a second stream runs (a) nothing, (b) the three-Gram pass, (c) a dummy LDS-heavy kernel.  Build (in jstsp19_amd/csrc):
+// Gram partials; a second stream runs (0) nothing, (1) the three-Gram pass, (2) a dummy LDS-heavy kernel, (3) the single-Gram
+// kernel, (4) a register-only MFMA loop, (5) the MFMA loop with a barrier + LDS access every 16 products.  argv[2] = 0: the
+// Householder + Sturm kernel instead.  Result (round 2): with packed-fp32 VALU instructions (v_pk_fma_f32 ...) in the Lanczos
+// kernel, modes 1 / 4 / 5 corrupt 5 / 4 / 3041 of 3184 results (a single Lanczos step is enough); compiled without them
+// (-target-feature -packed-fp32-ops, what jstsp19_amd/build.py does) every mode gives 0.  Build (in jstsp19_amd/csrc):
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -I../../include -I. ../../tools/probe/lanczos_race.cpp -L. -ljstsp_mi355x -Wl,-rpath,'$ORIGIN/../../jstsp19_amd/csrc' -o ../../tools/probe/lanczos_race.bin
 #include "solver_common.h"
 #include <cstdio>
@@ -22,9 +26,27 @@ __global__ void dummy_lds(float *out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = a;
 }
 
+// a register-only MFMA loop: matrix-pipe load without memory traffic (lds_touch: plus a barrier and an LDS round trip)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 2) void dummy_mfma(float *out, int iters, int lds_touch)
+{
+    extern __shared__ float sm[];
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(0.001f * (threadIdx.x + i)); b[i] = (_Float16)(0.002f * (threadIdx.x - i)); }
+    f16v acc0 = {0}, acc1 = {0};
+    for (int k = 0; k < iters; ++k) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc1, 0, 0, 0);
+        if (lds_touch && (k & 15) == 0) { sm[threadIdx.x] = acc0[0]; __syncthreads(); acc1[1] += sm[(threadIdx.x + 64) & 255]; }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc0[0] + acc1[3];
+}
+
 int main(int argc, char **argv)
 {
     const int mode = argc > 1 ? atoi(argv[1]) : 1, reps = 200;
+    const bool lanczos = argc > 2 ? atoi(argv[2]) != 0 : true;
     const int n = 64, batch = 16, nsplit = 4, M = 4096;
     jstsp_ctx *ctx = nullptr;
     if (jstsp_create(0, &ctx)) { printf("create failed\n"); return 1; }
@@ -70,8 +92,10 @@ int main(int argc, char **argv)
         if (mode == 1) launch_hgram3(ctx, X, V, (long long)nm, n, M, batch, nsplit, amax, amax + batch, amax + 2 * batch, prm, Gz, Gx, Gv);
         if (mode == 2) hipLaunchKernelGGL(dummy_lds, dim3(512), dim3(512), 49152, sB, dout, 200);
         if (mode == 3) launch_hgram(ctx, X, (long long)nm, n, M, batch, nsplit, amax, Gx);
+        if (mode == 4) hipLaunchKernelGGL(dummy_mfma, dim3(1024), dim3(256), 16384, sB, dout, 3000, 0);
+        if (mode == 5) hipLaunchKernelGGL(dummy_mfma, dim3(1024), dim3(256), 16384, sB, dout, 3000, 1);
         ctx->stream = sA;
-        launch_lmax(ctx, n, batch, Gw, (long long)n * n * nsplit, nsplit, (long long)n * n, lam + (size_t)r * batch, true);
+        launch_lmax(ctx, n, batch, Gw, (long long)n * n * nsplit, nsplit, (long long)n * n, lam + (size_t)r * batch, lanczos);
     }
     hipDeviceSynchronize();
     std::vector<float> hl((size_t)reps * batch);
@@ -80,6 +104,6 @@ int main(int argc, char **argv)
     for (int r = 1; r < reps; ++r)
         for (int t = 0; t < batch; ++t)
             if (memcmp(&hl[r * batch + t], &hl[t], 4)) { if (bad < 8) printf("rep %d problem %d: %.9g vs %.9g\n", r, t, hl[r * batch + t], hl[t]); ++bad; }
-    printf("mode %d: %d of %d lambda values differ from the first repetition (lambda[0] = %.6g)\n", mode, bad, (reps - 1) * batch, hl[0]);
+    printf("mode %d lanczos %d: %d of %d lambda values differ from the first repetition (lambda[0] = %.6g)\n", mode, (int)lanczos, bad, (reps - 1) * batch, hl[0]);
     return 0;
 }
