@@ -13,11 +13,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libjstsp_mi355x.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -packed-fp32-ops: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code.  Measured on MI355X (round 2,
-# tools/probe/lanczos_race.cpp): a kernel whose dependent fp32 chains hipcc had packed (the Lanczos lambda_max kernel)
-# returned different results from run to run whenever waves of an MFMA-heavy kernel shared its SIMDs - 5 of 3184 runs
-# beside the three-Gram pass, 3041 of 3184 beside an MFMA loop with barriers, 0 alone - and is bit-reproducible in
-# every case once compiled without the packed instructions.
+# -packed-fp32-ops: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code.  Measured on MI355X (round 2):
+# v_pk_fma_f32 with op_sel operand selection - what hipcc emits for complex multiplies - returns different bits from
+# run to run while waves of an MFMA-heavy kernel share the SIMD (tools/probe/pk_fp32_probe.hip: 7 % of the results
+# beside an MFMA loop, 0 alone; wait states do not help).  In this library it hit the Lanczos lambda_max kernel
+# (tools/probe/lanczos_race.cpp: 5 of 3184 runs beside the three-Gram pass, 3041 beside an MFMA loop with barriers,
+# 0 alone; 0 everywhere when built with this flag).  There is no switch for the op_sel forms alone; the flag costs
+# nothing measurable.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
