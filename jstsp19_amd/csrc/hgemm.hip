@@ -122,7 +122,6 @@ __device__ __forceinline__ half8 neg_half8(uint4 u)
 template <int EPI, bool APACK, int WJ, bool EVEN = false>
 __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmDesc d, int tiles_i, int tiles_j)
 {
-    constexpr int NT = 128 * WJ;                  // threads
     constexpr int STG = 1024 + 512 * WJ;          // uint4 per LDS stage: 16 a blocks + 8 WJ b blocks of 64
     constexpr int NA = (WJ == 2) ? 8 : 4;         // fp32 a elements per thread per stage
     // ONE LDS object indexed at run time: the compiler must then keep the stores that fill the next buffer behind
