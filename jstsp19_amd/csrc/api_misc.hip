@@ -319,7 +319,7 @@ int jstsp_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 *Y_
     JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(Y_ && tau && X_, JSTSP_E_NULL, "svt: NULL argument");
     JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0, JSTSP_E_SHAPE, "svt: bad shape");
-    JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "svt: min(Mr, Mt) = %d > 128",
+    JSTSP_REQUIRE(std::min(Mr, Mt) <= 2048, JSTSP_E_UNSUPPORTED, "svt: min(Mr, Mt) = %d > 2048",
                   std::min(Mr, Mt));
     const size_t nm = (size_t)Mr * Mt;
     size_t need = GramWS::bytes(Mr, Mt, batch, true) + rnd256(batch * sizeof(TrialParams)) +
@@ -431,7 +431,7 @@ int jstsp_mc_svt_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32 
     JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(OH_ && Omega_ && tau && rho && X_out, JSTSP_E_NULL, "mc_svt: NULL argument");
     JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0 && Imax >= 0, JSTSP_E_SHAPE, "mc_svt: bad shape");
-    JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "mc_svt: min(Mr, Mt) = %d > 128",
+    JSTSP_REQUIRE(std::min(Mr, Mt) <= 2048, JSTSP_E_UNSUPPORTED, "mc_svt: min(Mr, Mt) = %d > 2048",
                   std::min(Mr, Mt));
     const size_t nm = (size_t)Mr * Mt;
     size_t need = GramWS::bytes(Mr, Mt, batch, true) + rnd256(batch * sizeof(TrialParams)) +
@@ -471,7 +471,7 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
     JSTSP_REQUIRE(OH_ && Omega_ && tau && rho && X_out, JSTSP_E_NULL, "mc_admm: NULL argument");
     JSTSP_REQUIRE(!ce_out || Htrue_, JSTSP_E_NULL, "mc_admm: convergence_error needs Htrue");
     JSTSP_REQUIRE(Mr > 0 && Mt > 0 && batch > 0 && Imax >= 0, JSTSP_E_SHAPE, "mc_admm: bad shape");
-    JSTSP_REQUIRE(std::min(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED, "mc_admm: min(Mr, Mt) = %d > 128",
+    JSTSP_REQUIRE(std::min(Mr, Mt) <= 2048, JSTSP_E_UNSUPPORTED, "mc_admm: min(Mr, Mt) = %d > 2048",
                   std::min(Mr, Mt));
     const size_t nm = (size_t)Mr * Mt;
     const bool want_ce = ce_out != nullptr;

@@ -253,8 +253,8 @@ int launch_eig(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, 
                int nsplit, long long sGs, const TrialParams *prm, const float *tau, float2 *Q,
                float *lam_out, float2 *Vg)
 {
-    JSTSP_REQUIRE(n >= 1 && n <= 128, JSTSP_E_UNSUPPORTED,
-                  "eig: matrix order %d outside [1,128] (the SVT decomposes the min(rows,cols) Gram)", n);
+    if (n > 128) return launch_eig_large(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out);
+    JSTSP_REQUIRE(n >= 1, JSTSP_E_UNSUPPORTED, "eig: matrix order %d", n);
     const int ne = (n + 1) & ~1;
     const int ld = ne + 1;
     const size_t mat = (size_t)ne * ld * sizeof(float2);

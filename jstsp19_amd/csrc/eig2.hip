@@ -778,7 +778,8 @@ static int launch_lanczos_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpar
 int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
                 float *lam_out, bool lanczos)
 {
-    JSTSP_REQUIRE(n >= 1 && n <= 128, JSTSP_E_UNSUPPORTED, "launch_lmax: n = %d outside [1,128]", n);
+    if (n > 128) return launch_eig_large(ctx, EIG_LMAX, n, batch, Gpart, sGt, nsplit, sGs, nullptr, nullptr, nullptr, lam_out);
+    JSTSP_REQUIRE(n >= 1, JSTSP_E_UNSUPPORTED, "launch_lmax: n = %d", n);
     const bool lz = lanczos && (getenv("JSTSP_LANCZOS") ? atoi(getenv("JSTSP_LANCZOS")) != 0 : true);
     if (lz) {
         if (n <= 64) return launch_lanczos_t<64>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);

@@ -249,8 +249,6 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     const uint32_t ebase = 8u * (16 * nb + c16 + 64 * (16 * kh + 4 * q));     // bytes; + 512 (m0 + s)
     const u32x4 *const ast = reinterpret_cast<const u32x4 *>(d.ASp) + (long long)t * d.sAS;
     const uint32_t aoff = 16u * ((uint32_t)(kh * KSH) * 1024u + nb * 256 + l);      // bytes
-    const int perm_sel = (c16 & 1) ? 0x07060302 : 0x05040100;
-    const bool cw = (c16 & 2) != 0;
 
     {
 #pragma unroll

@@ -147,8 +147,8 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d",
                   memspace);
     JSTSP_REQUIRE(type == JSTSP_TYPE_APPROXIMATE || type == JSTSP_TYPE_STD, JSTSP_E_ARG, "bad type %d", type);
-    JSTSP_REQUIRE(std::min(N, M) <= 128, JSTSP_E_UNSUPPORTED,
-                  "proposed_algorithm: min(N, M) = %d > 128 (order of the SVT's Gram eigenproblem)",
+    JSTSP_REQUIRE(std::min(N, M) <= 2048, JSTSP_E_UNSUPPORTED,
+                  "proposed_algorithm: min(N, M) = %d > 2048 (order of the SVT's Gram eigenproblem)",
                   std::min(N, M));
     JSTSP_REQUIRE(strideA == 0 || strideA >= (long long)N * Gr, JSTSP_E_SHAPE, "strideA too small");
     JSTSP_REQUIRE(strideB == 0 || strideB >= (long long)G2 * M, JSTSP_E_SHAPE, "strideB too small");

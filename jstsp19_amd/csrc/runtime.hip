@@ -245,7 +245,7 @@ int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
     // orders 65..128: G in LDS, the eigenvector basis in registers (eig3.hip); JSTSP_EIG128=0: the general kernel with
     // the basis in HBM (eig.hip)
     const char *e128 = getenv("JSTSP_EIG128");
-    if (!e128 || atoi(e128) != 0) {
+    if (w.n <= 128 && (!e128 || atoi(e128) != 0)) {
         // warm start (successive calls of an ADMM loop): G <- Uw^H (G Uw) with the previous basis, two batched GEMMs
         const int warm = (sequence && w.warm && w.nsplit == 1 && w.Uwarm && w.Twarm) ? 1 : 0;
         if (warm) {

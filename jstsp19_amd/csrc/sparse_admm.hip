@@ -94,8 +94,8 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
                   "A'A - rho*eye(Mr*Mt) (:16): Gr must equal Mr and Gt must equal Mt (got %dx%d vs %dx%d)",
                   Gr, Gt, Mr, Mt);
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
-    JSTSP_REQUIRE(std::max(Mr, Mt) <= 128, JSTSP_E_UNSUPPORTED,
-                  "sparse_admm: max(Mr, Mt) = %d > 128 (order of the factor-Gram eigenproblems)", std::max(Mr, Mt));
+    JSTSP_REQUIRE(std::max(Mr, Mt) <= 2048, JSTSP_E_UNSUPPORTED,
+                  "sparse_admm: max(Mr, Mt) = %d > 2048 (order of the factor-Gram eigenproblems)", std::max(Mr, Mt));
     JSTSP_ENTER(ctx);
     const bool want_ce = ce_out != nullptr;
     const size_t nm = (size_t)Mr * Mt;

@@ -205,7 +205,7 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
     float2 *Ub = a.get<float2>((size_t)nG * G2 * G2);
     float *lamA = a.get<float>((size_t)nA * Na), *lamB = a.get<float>((size_t)nG * G2);
     const int nea = (Na + 1) & ~1, neb = (G2 + 1) & ~1;
-    float2 *Vga = a.get<float2>((size_t)nA * nea * nea), *Vgb = a.get<float2>((size_t)nG * neb * neb);
+    float2 *Vga = a.get<float2>((size_t)nA * nea * nea), *Vgb = a.get<float2>(G2 <= 128 ? (size_t)nG * neb * neb : 16);
     VampScal *sc = a.get<VampScal>(batch);
     JSTSP_REQUIRE(r1 && x1 && r2 && x2 && u3 && p1 && p2 && z2 && z2o && Ar2 && E && T1 && T2 && tq && tdq && q && dq &&
                       AAh && Ua && Ub && lamA && lamB && Vga && Vgb && sc,
@@ -257,7 +257,7 @@ static size_t vamp_bytes(int Na, int Gr, int G2, int batch, int nA, int nG)
     return 6 * rnd256(bN * sizeof(float2)) + 10 * rnd256(bM * sizeof(float2)) + 2 * rnd256(bM * sizeof(float)) +
            2 * rnd256((size_t)nA * Na * Na * sizeof(float2)) + rnd256((size_t)nG * G2 * G2 * sizeof(float2)) +
            rnd256((size_t)nA * Na * sizeof(float)) + rnd256((size_t)nG * G2 * sizeof(float)) +
-           rnd256((size_t)nA * nea * nea * sizeof(float2)) + rnd256((size_t)nG * neb * neb * sizeof(float2)) +
+           rnd256((size_t)nA * nea * nea * sizeof(float2)) + rnd256((G2 <= 128 ? (size_t)nG * neb * neb : 16) * sizeof(float2)) +
            rnd256(batch * sizeof(VampScal)) + 4096;
 }
 
@@ -275,8 +275,8 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
     JSTSP_REQUIRE(Y_ && Af_ && Gb_ && X_out, JSTSP_E_NULL, "vamp_kron: NULL array argument");
     JSTSP_REQUIRE(Na > 0 && Gr > 0 && G2 > 0 && batch > 0 && nit >= 1, JSTSP_E_SHAPE, "vamp_kron: bad shape");
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
-    JSTSP_REQUIRE(Na <= 128 && G2 <= 128, JSTSP_E_UNSUPPORTED,
-                  "vamp_kron: Na = %d, G2 = %d: the factor eigenproblems are limited to order 128", Na, G2);
+    JSTSP_REQUIRE(Na <= 128 && G2 <= 8192, JSTSP_E_UNSUPPORTED,
+                  "vamp_kron: Na = %d, G2 = %d: the factor eigenproblems are limited to orders 128 and 8192", Na, G2);
     JSTSP_REQUIRE(Na <= Gr, JSTSP_E_UNSUPPORTED,
                   "vamp: only the M <= N branch of VampGlmEst.m:399-403 is implemented (Na = %d > Gr = %d)", Na, Gr);
     JSTSP_REQUIRE(sigma > 0 && Lnz > 0 && Lnz < 2.0 * Gr * G2, JSTSP_E_ARG, "vamp: need sigma > 0 and 0 < L < nx");

@@ -41,3 +41,25 @@ S1, _, _ = J.proposed_algorithm_angles(cm(subY[:1]), cm(Om[:1]), indx[:1], A, B,
 print("batched vs single rel diff: %.2e" % float((S1[0] - S[0]).abs().max() / S[0].abs().max()))
 err = float((S - S0).abs().max() / S0.abs().max())
 print("recovery: max |S - S0| / max |S0| after 20 iterations = %.3f ; ce(20,:) = %s" % (err, ce[0, -1]))
+
+# ---- VAMP at the same shape (the drivers' call: vamp(vec(Y_hbf*B_hbf'), kron((B_hbf*B_hbf').', A_hbf), 1, L), plot_errorVSsnr.m:79-80,100):
+# Gb = B_hbf B_hbf' has order G2 = 4096 - eigen-decomposition through csrc/eig_large.hip - and is shared by the batch here.
+del subY, Om, B, S, Y
+torch.cuda.empty_cache()
+T_hbf = 8192                                           # round(T / (Nr / Mr)) * Nt = 32 * 256
+Bh = cm(rnd(G2, T_hbf) / np.sqrt(T_hbf))
+Gb = cm(Bh @ Bh.conj().T)
+Gb = cm(0.5 * (Gb + Gb.conj().T))
+del Bh
+Xs = torch.zeros(batch, Gr, G2, dtype=torch.complex64, device=dev)
+Xs.view(batch, -1).scatter_(1, idx, 3 * rnd(batch, 40))
+Yv = torch.empty(batch, N, G2, dtype=torch.complex64, device=dev)
+for t in range(batch):
+    Yv[t] = A @ Xs[t] @ Gb + 0.05 * rnd(N, G2)
+for nit in (3, 100):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    Xv = J.vamp_kron(cm(Yv), A, Gb, 1.0, 40, nit=nit)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    ok = bool(torch.isfinite(torch.view_as_real(Xv)).all())
+    e = float((Xv - Xs).abs().max() / Xs.abs().max())
+    print("vamp_kron Na=64 Gr=64 G2=4096, batch %d, %d iterations: %.2f s, finite %s, max |X - X0| / max |X0| = %.3f" % (batch, nit, dt, ok, e))
