@@ -348,7 +348,7 @@ int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp
     JSTSP_ENTER(ctx);
     JSTSP_REQUIRE(S_ && Zbar_ && nmse, JSTSP_E_NULL, "nmse: NULL argument");
     JSTSP_REQUIRE(R > 0 && C > 0 && batch > 0, JSTSP_E_SHAPE, "nmse: bad shape");
-    JSTSP_REQUIRE(std::min(R, C) <= 128, JSTSP_E_UNSUPPORTED, "nmse: min(R, C) = %d > 128", std::min(R, C));
+    JSTSP_REQUIRE(std::min(R, C) <= 2048, JSTSP_E_UNSUPPORTED, "nmse: min(R, C) = %d > 2048", std::min(R, C));
     const size_t n = (size_t)R * C;
     size_t need = GramWS::bytes(R, C, batch, false) + rnd256(batch * n * sizeof(float2)) +
                   2 * rnd256(batch * sizeof(float)) + rnd256(batch * sizeof(double));

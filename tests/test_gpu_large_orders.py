@@ -99,3 +99,13 @@ def test_proposed_algorithm_and_sparse_admm_above_128():
     Ss, ces = J.sparse_admm(H, OH, F, F, 6)
     Sso, ceso = O.sparse_admm(H, OH, F, F, 6)
     assert rel_err(Ss, Sso) < 3e-4
+
+
+def test_nmse_spectral_above_128():
+    from oracle import solvers as O
+    rng = np.random.default_rng(12)
+    Zb = _lowrank(rng, 2, 150, 170, 4, 0.1)
+    S = Zb + 0.3 * _lowrank(rng, 2, 150, 170, 2, 0.05)
+    out = np.asarray(J.nmse_spectral(S, Zb))
+    for t in range(2):
+        assert abs(out[t] - O.nmse_capped(S[t], Zb[t])) < 2e-6 * max(1.0, out[t])
