@@ -155,8 +155,37 @@ def _hip_solvers(device, metric="nmse"):
     return solve
 
 
+def _merge_key(p):
+    """Sweep points whose trials may share one solver call: same array shapes and the same trial-independent A (the
+    SNR, the number of paths and the rho rule only enter the per-trial arrays, which are built per point)."""
+    return (p.Nt, p.Nr, p.L, p.T, p.Mr, p.Mr_e, p.Gr, p.Gt, p.beamformer, p.T_prop)
+
+
+def _merge_inputs(inps):
+    """Concatenate the per-trial arrays of several ``build_trials`` results (column-major layout kept)."""
+    if len(inps) == 1:
+        return inps[0]
+    out = {}
+    for k, v0 in inps[0].items():
+        if k in ("A", "A_hbf"):                          # trial-independent: beamformer x dictionary
+            out[k] = v0
+        elif v0.is_cuda and v0.ndim == 3:
+            out[k] = torch.cat([x[k].transpose(1, 2) for x in inps], 0).transpose(1, 2)
+        else:
+            out[k] = torch.cat([x[k] for x in inps], 0)
+    return out
+
+
+def _merge_cap(p, batch, with_hbf):
+    """Trials per merged solver call: small problems are latency-bound per launch (one workgroup per matrix in the
+    eigen-decompositions), so trials of several sweep points go into one call - up to about 1.5 GB of inputs."""
+    N, M, Gr, G2 = p.solver_shape
+    per_trial = 8 * (G2 * M + 2 * N * M + 2 * Gr * G2 + ((G2 + p.Nr) * p.T_hbf if with_hbf else 0))
+    return max(batch, min(4096, int(1.5e9 // max(per_trial, 1))))
+
+
 def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=None, solve_fn=None, dist=None,
-               baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None):
+               baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None, merge=True):
     """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP, MMV-OMP
     [, TSSR]]).  ``metric="rate"``: the rate of plot_rateVSframelength.m:81 instead of the NMSE (HIP solvers only).
     ``tssr=(Imax_svt, rho_svt)`` adds the commented recipes of plot_errorVSsnr.m:151-162 as columns six and seven: TSSR
@@ -189,26 +218,43 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
     ncol = (7 if tssr is not None else 5) if baselines else 2
     lo, hi = partition(n_pts * n_trials, world, rank)
     acc = torch.zeros((n_pts, ncol + 1), dtype=torch.float64)   # sums per column, then the trial count
+    # HIP path, NMSE metric: chunks of consecutive sweep points with equal shapes are solved in ONE call (the per-trial
+    # results do not depend on what else is in the batch; a rate sweep keeps one noise variance per call)
+    merging = merge and not custom and builder == "hip" and metric == "nmse"
     item = lo
     while item < hi:
-        pt = item // n_trials
-        t0 = item % n_trials
-        t1 = min(n_trials, t0 + batch, t0 + (hi - item))
-        p = points[pt]
-        if builder == "hip":
-            inp = build_trials(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device, with_hbf=baselines)
-        else:
-            draws = draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
-            inp = build_inputs(p, draws, with_hbf=baselines)
+        chunks, inps, total = [], [], 0
+        while item < hi:
+            pt = item // n_trials
+            t0 = item % n_trials
+            t1 = min(n_trials, t0 + batch, t0 + (hi - item))
+            p = points[pt]
+            if chunks and (not merging or _merge_key(p) != _merge_key(points[chunks[0][0]])
+                           or total + (t1 - t0) > _merge_cap(p, batch, baselines)):
+                break
+            if builder == "hip":
+                inps.append(build_trials(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device, with_hbf=baselines))
+            else:
+                draws = draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
+                inps.append(build_inputs(p, draws, with_hbf=baselines))
+            chunks.append((pt, t1 - t0))
+            total += t1 - t0
+            item += t1 - t0
+        inp = _merge_inputs(inps)
+        del inps
+        p = points[chunks[0][0]]
         e, ea = solve_fn(inp, Imax) if custom else solve_fn(inp, Imax, p.noise_var)
-        acc[pt, 0] += float(torch.as_tensor(e).double().sum())
-        acc[pt, 1] += float(torch.as_tensor(ea).double().sum())
+        cols = [torch.as_tensor(e).double().cpu(), torch.as_tensor(ea).double().cpu()]
         if baselines:
             b = _hip_baselines(inp, numOfnz, metric, p.noise_var, tssr)
-            for col, key in enumerate(("ls", "vamp", "omp_mmv", "tssr", "svt")[:ncol - 2]):
-                acc[pt, 2 + col] += float(b[key].double().sum()) if key in b else float("nan")
-        acc[pt, ncol] += t1 - t0
-        item += t1 - t0
+            for key in ("ls", "vamp", "omp_mmv", "tssr", "svt")[:ncol - 2]:
+                cols.append(b[key].double().cpu() if key in b else torch.full((total,), float("nan"), dtype=torch.float64))
+        o = 0
+        for pt, cnt in chunks:
+            for col, v in enumerate(cols):
+                acc[pt, col] += float(v[o:o + cnt].sum())
+            acc[pt, ncol] += cnt
+            o += cnt
     if dist is not None:
         buf = acc.to(device) if dist.get_backend() == "nccl" else acc
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # the single collective of the sweep
