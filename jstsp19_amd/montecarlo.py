@@ -108,7 +108,7 @@ def _score(S, zb, metric, noise_var):
     return J.nmse_spectral(S, zb) if metric == "nmse" else J.rate(S, zb, noise_var)
 
 
-def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None):
+def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None, vamp_max_order=128):
     """LS, VAMP and MMV-OMP baselines of plot_errorVSsnr.m:73-121 on the conventional-HBF measurement; with
     ``tssr = (Imax, rho)`` also the commented TSSR recipe (:151,158-162) on the proposed scheme's measurement."""
     from . import solvers as J
@@ -117,7 +117,7 @@ def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None):
     out = {"ls": _score(S_ls, zb, metric, noise_var)}
     G2 = inp["B_hbf"].shape[1]
     Bh = inp["B_hbf"]
-    if G2 <= 128 and inp["A_hbf"].shape[0] <= 128:
+    if G2 <= vamp_max_order and inp["A_hbf"].shape[0] <= 128:       # (orders above 128: one rocSOLVER decomposition per trial)
         Gb = J.colmajor(Bh @ Bh.conj().transpose(1, 2))                                  # (B*B')  :79
         Ym = J.colmajor(inp["Y_hbf"] @ Bh.conj().transpose(1, 2))                        # Y_hbf*B' :80
         out["vamp"] = _score(J.vamp_kron(Ym, inp["A_hbf"], Gb, 1.0, numOfnz), zb, metric, noise_var)   # :100
@@ -185,7 +185,7 @@ def _merge_cap(p, batch, with_hbf):
 
 
 def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=None, solve_fn=None, dist=None,
-               baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None, merge=True):
+               baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None, merge=True, vamp_max_order=128):
     """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP, MMV-OMP
     [, TSSR]]).  ``metric="rate"``: the rate of plot_rateVSframelength.m:81 instead of the NMSE (HIP solvers only).
     ``tssr=(Imax_svt, rho_svt)`` adds the commented recipes of plot_errorVSsnr.m:151-162 as columns six and seven: TSSR
@@ -193,7 +193,8 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
 
     ``solve_fn(inputs, Imax) -> (nmse, nmse_angles)`` (two tensors of per-trial NMSE) defaults to the HIP path.
     ``baselines=True`` adds the LS and VAMP columns of plot_errorVSsnr.m:83-105 (HIP path only; VAMP is NaN
-    where the factor orders exceed 128).  ``dist``: ``torch.distributed`` (initialised) or None.
+    where the delay factor's order L*Gt exceeds ``vamp_max_order`` - 128 by default: above that every trial costs one
+    rocSOLVER eigen-decomposition of that order).  ``dist``: ``torch.distributed`` (initialised) or None.
     ``builder``: "hip" — inputs from the library's own kernels (``jstsp_build_trials_c32``; the default with
     the HIP solvers) or "torch" — the tensor-op builder (the default with a custom ``solve_fn``, runs on CPU too).
     The two use different generators, so their curves agree statistically, not sample by sample.
@@ -246,7 +247,7 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
         e, ea = solve_fn(inp, Imax) if custom else solve_fn(inp, Imax, p.noise_var)
         cols = [torch.as_tensor(e).double().cpu(), torch.as_tensor(ea).double().cpu()]
         if baselines:
-            b = _hip_baselines(inp, numOfnz, metric, p.noise_var, tssr)
+            b = _hip_baselines(inp, numOfnz, metric, p.noise_var, tssr, vamp_max_order)
             for key in ("ls", "vamp", "omp_mmv", "tssr", "svt")[:ncol - 2]:
                 cols.append(b[key].double().cpu() if key in b else torch.full((total,), float("nan"), dtype=torch.float64))
         o = 0

@@ -14,6 +14,7 @@ ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--builder", default="hip", choices=["hip", "torch"])
 ap.add_argument("--rate", action="store_true", help="rate metric of plot_rateVSframelength.m instead of the NMSE")
 ap.add_argument("--tssr", action="store_true", help="add the TSSR recipe (mc_svt with rho = 0.1, then joint OMP)")
+ap.add_argument("--vamp-large", action="store_true", help="VAMP column also where L*Gt > 128 (one order-L*Gt eigen-decomposition per trial)")
 ap.add_argument("--config3", action="store_true", help="BASELINE configs[3]: Nt=Nr=64, Nrf=8, K=64, L=8, 10 SNR points")
 a = ap.parse_args()
 base = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4)              # plot_errorVSsnr.m:8-23
@@ -22,7 +23,7 @@ if a.config3:
     base = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8)           # the configs[1] shape (N=64, M=4096, Gr=64, G2=512)
     snrs = list(range(-15, 15, 3))                              # 10 points
 t0 = time.perf_counter()
-out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, numOfnz=100, builder=a.builder,
+out = run_sweep(base, snrs, a.trials, Imax=100, batch=a.batch, baselines=True, numOfnz=100, builder=a.builder, vamp_max_order=8192 if a.vamp_large else 128,
                 metric="rate" if a.rate else "nmse", tssr=(100, 0.1) if a.tssr else None)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
