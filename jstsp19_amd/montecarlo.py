@@ -125,8 +125,15 @@ def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None, vamp_m
         PB = J.pinv(Bh)                                                                  # pinv(B)  :117
     except J.JstspError:
         PB = None                                                                        # factor too large for the pinv kernel
+    Ypb = None
     if PB is not None:
-        Z, _, _ = J.mmv_omp(inp["A_hbf"], J.colmajor(inp["Y_hbf"] @ PB), numOfnz)        # :116-117
+        Ypb = J.colmajor(inp["Y_hbf"] @ PB)
+    elif inp["A_hbf"].shape[0] == inp["A_hbf"].shape[1]:
+        # B too large for the pinv kernel, A square: Y*pinv(B) = A*(pinv(A)*Y*pinv(B)) = A*S_ls (A invertible: a unitary
+        # dictionary times the beamformer), with the Gram-inverse route of jstsp_ls_c32 behind S_ls
+        Ypb = J.colmajor(inp["A_hbf"].unsqueeze(0) @ S_ls)
+    if Ypb is not None:
+        Z, _, _ = J.mmv_omp(inp["A_hbf"], Ypb, numOfnz)                                  # :116-117
         out["omp_mmv"] = _score(Z, zb, metric, noise_var)
     if tssr is not None:
         try:
