@@ -179,6 +179,8 @@ def test_sweep_runner_on_hip_matches_oracle_per_point():
     hip = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev).numpy()
     ref = run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev, solve_fn=oracle_solve, builder="hip").numpy()
     np.testing.assert_allclose(hip, ref, atol=1e-6)
+    # (the HIP sweep above solved the trials of all three points in one call; point by point, batch by batch is the same)
+    np.testing.assert_allclose(run_sweep(base, [-9, 3, 15], 6, Imax=100, batch=4, device=dev, merge=False).numpy(), hip, atol=1e-6)
     assert hip.shape == (3, 2) and np.all(hip[:, 1] <= hip[:, 0] + 1e-3)      # angle information helps
     # with the conventional-HBF baselines (LS, VAMP, MMV-OMP) as extra columns, and the TSSR recipe
     full = run_sweep(base, [3], 4, Imax=100, batch=4, device=dev, baselines=True, tssr=(30, 0.1)).numpy()
