@@ -51,7 +51,34 @@ def parse():
                     help="BLAS threads for the host oracle (0 = min(32, host cores))")
     ap.add_argument("--shared-pilots", action="store_true", help="one pilot set for all trials (B shared, stride 0)")
     ap.add_argument("--small", action="store_true", help="reference-native shape (plumbing check)")
+    ap.add_argument("--sweep", action="store_true",
+                    help="BASELINE configs[3] instead of the headline step: the plot_errorVSsnr sweep at the configs[1] shape, "
+                         "10 SNR points x --sweep-trials realisations, (point, trial) pairs sharded over the ranks, ONE "
+                         "all-reduce of the NMSE sums (plot_errorVSsnr.m:48-51,170)")
+    ap.add_argument("--sweep-trials", type=int, default=500, help="realisations per SNR point in --sweep mode")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the JSTSP_HOST (PCIe-inclusive) measurement")
     return ap.parse_args()
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (torch.distributed.run, one
+    per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, pass their output through and return their exit
+    code.  Fails loudly when the node has fewer than N GPUs - it never prints a line with another n_gpus."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()            # (does not initialise the GPU on this image)
+    if have < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but this node has %d GPU(s); not running\n" % (a.gpus, have))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def make_inputs(p, trial_ids, device, shared_pilots=False):
@@ -65,11 +92,81 @@ def make_inputs(p, trial_ids, device, shared_pilots=False):
                 tau_Z=o["tau_Z"].numpy(), rho=o["rho"].numpy())
 
 
+def emit(line, dist, rank):
+    """Rank 0 prints the JSON line as the LAST line of stdout (RCCL writes its banner through C stdio, which is fully
+    buffered on a pipe and would otherwise be flushed at exit, after the line)."""
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
+
+
+def sweep_mode(a, rank, world, dist, device):
+    """BASELINE configs[3]: the plot_errorVSsnr.m:48-180 sweep at the configs[1] shape - 10 SNR points x `sweep_trials`
+    realisations, each solved by proposed_algorithm (:137) and proposed_algorithm_angles (:144), the (point, trial) pairs
+    in contiguous blocks per rank, inputs built on the device, ONE all-reduce of the per-point NMSE sums (:170)."""
+    from jstsp19_amd.montecarlo import run_sweep
+    from jstsp19_amd.system_model import SweepParams
+    if a.small:
+        base, snrs = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4), list(range(-15, 16, 3))      # plot_errorVSsnr.m:8-25
+        shape = "reference-native Nr=32 Nt=4 L=4 T=35"
+    else:
+        base, snrs = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8), list(range(-15, 15, 3))
+        shape = "Nt=Nr=64 Nrf=8 K=64 L=8 (N=64 M=4096 Gr=64 G2=512)"
+    kw = dict(Imax=IMAX, batch=a.batch, device=device, dist=dist)
+    run_sweep(base, snrs[:1], min(a.batch, 8) * world, **kw)     # priming: workspace + kernels (setup, not timed)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run_sweep(base, snrs, a.sweep_trials, **kw)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    solves = 2 * len(snrs) * a.sweep_trials
+    line = None
+    if rank == 0:
+        line = {"metric": "channel-estimates/sec (batched MC) at Nt=Nr=64,K=64; NMSE vs ref",
+                "value": round(solves / dt, 3), "unit": "channel-estimates/s", "n_gpus": world, "steps": 1, "warmup": 0,
+                "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "c32", "data": "synthetic",
+                "config": {"workload": "plot_errorVSsnr sweep (BASELINE configs[3]): %s, %d SNR points x %d realisations, "
+                                       "proposed_algorithm + proposed_algorithm_angles per realisation, Imax=%d, (point, trial) "
+                                       "pairs sharded over ranks, one all-reduce of the NMSE sums" % (shape, len(snrs),
+                                                                                                   a.sweep_trials, IMAX),
+                           "trials_per_call": a.batch, "parallelism": "trials sharded, dp%d" % world},
+                "snr_db": snrs, "mean_nmse_proposed": [round(v, 6) for v in out[:, 0].tolist()],
+                "mean_nmse_angles": [round(v, 6) for v in out[:, 1].tolist()]}
+    emit(line, dist, rank)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))               # we are the launcher: the ranks are child processes
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                 "--nproc-per-node %d ... bench.py --gpus %d), or run `python bench.py --gpus %d` without a launcher"
+                 % (a.gpus, world, a.gpus, a.gpus, a.gpus))
     # JSTSP_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL path on a 1-GPU box)
     if world > 1 or os.environ.get("JSTSP_BENCH_FORCE_DIST"):
         import torch.distributed as dist
@@ -93,6 +190,10 @@ def main():
         workload = "proposed_algorithm approximate Imax=100, Nt=Nr=64 Nrf=8 K=64 L=8 (N=64 M=4096 Gr=64 G2=512)"
     N, M, Gr, G2 = p.solver_shape
     want_ce = not a.no_ce
+
+    if a.sweep:
+        sweep_mode(a, rank, world, dist, device)
+        return
 
     ids = list(range(rank * a.batch, (rank + 1) * a.batch))
     inp = make_inputs(p, ids, device, a.shared_pilots)
@@ -247,19 +348,7 @@ def main():
             "mean_nmse": mean_nmse, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
         line.update(extra)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # The JSON line must be the last line of stdout: RCCL writes its banner ("Hostname", "Librccl path") through C
-        # stdio, which is fully buffered on a pipe and would otherwise be flushed at exit, after this line.
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+    emit(line if rank == 0 else None, dist, rank)
 
 
 if __name__ == "__main__":

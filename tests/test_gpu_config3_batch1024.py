@@ -1,0 +1,82 @@
+"""BASELINE.json configs[2] at its FULL batch: Nt=Nr=128, sparse_admm + the svt path (svt, mc_svt, mc_admm) on
+128 x 128 matrices, 1024 Monte-Carlo trials in one device-resident call each; 8 randomly chosen trials of every call
+are recomputed by the float64 oracle (benchmark_algorithms/sparse_admm.m, svt.m, mc_svt.m, mc_admm.m).
+Sampling masks have Mr/Mr_e = 1/8 of their entries set."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_, BATCH, PICK = 128, 1024, 8
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    import torch
+    import jstsp19_amd as J
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(1283)
+    rnd = lambda *s: torch.complex(torch.randn(*s, generator=g, device=dev), torch.randn(*s, generator=g, device=dev))
+    idx = torch.arange(N_, device=dev, dtype=torch.float64)
+    D = (torch.exp(-2j * np.pi * idx[:, None] * idx[None, :] / N_) / np.sqrt(N_)).to(torch.complex64)   # unitary DFT
+    Sp = torch.zeros(BATCH, N_, N_, dtype=torch.complex64, device=dev)
+    Sp[:, ::17, ::13] = rnd(BATCH, len(range(0, N_, 17)), len(range(0, N_, 13)))      # sparse beamspace channel
+    H = D @ Sp @ D.conj().T
+    OH = H + 0.05 * rnd(BATCH, N_, N_)
+    Om = (torch.rand(BATCH, N_, N_, generator=g, device=dev) < 0.125).float()
+    pick = np.sort(np.random.default_rng(5).choice(BATCH, PICK, replace=False))
+    cm = J.colmajor
+    return dict(D=cm(D), H=cm(H), OH=cm(OH), Om=cm(Om), OmOH=cm(Om * OH), pick=pick)
+
+
+def _h(x, t, dt=np.complex128):
+    return x[t].cpu().numpy().astype(dt)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_svt_1024_trials(cfg3):
+    import torch
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    sv0 = torch.linalg.svdvals(cfg3["OH"][:4].to(torch.complex128))
+    tau = np.full(BATCH, float(sv0[:, N_ // 3].mean()))              # cuts the spectrum in its middle
+    X = J.svt(cfg3["OH"], tau)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(X)).all()
+    for t in cfg3["pick"]:
+        assert _rel(_h(X, t), O.svt(_h(cfg3["OH"], t), tau[t])) < 2e-5
+
+
+def test_mc_svt_and_mc_admm_1024_trials(cfg3):
+    import torch
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    tau, rho = np.full(BATCH, 0.5), np.full(BATCH, 0.1)
+    X = J.mc_svt(cfg3["OmOH"], cfg3["Om"], 20, tau, rho)
+    Xa, ce = J.mc_admm(cfg3["H"], cfg3["OmOH"], cfg3["Om"], 20, tau, rho)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(X)).all() and torch.isfinite(torch.view_as_real(Xa)).all()
+    for t in cfg3["pick"]:
+        oh, om = _h(cfg3["OmOH"], t), _h(cfg3["Om"], t, np.float64)
+        assert _rel(_h(X, t), O.mc_svt(oh, om, 20, 0.5, 0.1)) < 2e-4
+        Xo, ceo = O.mc_admm(_h(cfg3["H"], t), oh, om, 20, 0.5, 0.1)
+        assert _rel(_h(Xa, t), Xo) < 2e-4
+        np.testing.assert_allclose(ce[t].cpu().numpy(), ceo, rtol=5e-3)
+
+
+def test_sparse_admm_1024_trials(cfg3):
+    import torch
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    Imax = 100
+    S, ce = J.sparse_admm(cfg3["H"], cfg3["OH"], cfg3["D"], cfg3["D"], Imax)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(S)).all()
+    D = cfg3["D"].cpu().numpy().astype(np.complex128)
+    for t in cfg3["pick"]:
+        So, ceo = O.sparse_admm(_h(cfg3["H"], t), _h(cfg3["OH"], t), D, D, Imax)
+        assert _rel(_h(S, t), So) < 2e-4
+        np.testing.assert_allclose(ce[t].cpu().numpy(), ceo, rtol=5e-3)

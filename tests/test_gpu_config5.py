@@ -1,0 +1,136 @@
+"""BASELINE.json configs[4]: Nt=256, Nr=64, K=256, L=16 - `proposed_algorithm_angles` + VAMP.
+
+Symbol binding: N = Mr_e = 64, Gr = 64, G2 = L*Gt = 4096, and the two frame conventions the
+survey names: M = T*Nt = 65 536 (the drivers' convention; the dictionary B is 2 GiB per pilot set, shared by the batch)
+and the small variant M = T = 256 (plot_errorVSadmmiters.m:21,49 passes T itself).  VAMP is the drivers' call
+vamp(vec(Y_hbf*B_hbf'), kron((B_hbf*B_hbf').', A_hbf), 1, L) (plot_errorVSsnr.m:79-80,100) with T_hbf = 8192.
+
+M = 256: the float64 oracle is affordable -> proposed_algorithm / _angles and the first VAMP iterations against it.
+M = 65 536: size-independent properties (adjointness, batched == single, support inside indx_S, finite outputs).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(T_prop=None, **kw):
+    from jstsp19_amd.system_model import SweepParams
+    return SweepParams(Nt=256, Nr=64, L=16, T=256, Mr=8, snr_db=5.0, T_prop=T_prop, **kw)
+
+
+def _np(x, t, dt=np.complex128):
+    return x[t].cpu().numpy().astype(dt)
+
+
+def test_cfg5_small_frame_proposed_and_angles_against_the_oracle():
+    """N=64, M=256, Gr=64, G2=4096: inputs from the library's own builder, 12 iterations, 2 trials against the float64
+    oracle (S to 2e-4 of max|S|, |dNMSE| <= 1e-6), convergence_error to 2e-3, support of _angles inside indx_S."""
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import build_trials
+    from oracle import solvers as O
+    p = _params(T_prop=256)
+    assert p.solver_shape == (64, 256, 64, 4096)
+    Imax, nb = 12, 3
+    inp = build_trials(p, 0, nb, seed=77)
+    ty, tz, rho = inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy()
+    S, Y, ce = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax, ty, tz, rho, "approximate")
+    Sa, Ya, cea = J.proposed_algorithm_angles(inp["subY"], inp["Omega"], inp["indx_S"], inp["A"], inp["B"], Imax, ty, tz,
+                                              rho, "approximate", None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(S)).all() and torch.isfinite(torch.view_as_real(Sa)).all()
+    A_h = inp["A"].cpu().numpy().astype(np.complex128)
+    for t in range(2):
+        args = (_np(inp["subY"], t), _np(inp["Omega"], t, np.float64), A_h, _np(inp["B"], t), Imax, float(ty[t]),
+                float(tz[t]), float(rho[t]), "approximate")
+        zb = _np(inp["Zbar"], t)
+        for (Sg, Yg, cg), idx in (((S, Y, ce), None), ((Sa, Ya, cea), inp["indx_S"][t].cpu().numpy())):
+            So, Yo, co = O.proposed_algorithm(*args, indx_S=idx)
+            sg = _np(Sg, t)
+            assert np.max(np.abs(sg - So)) / np.max(np.abs(So)) < 2e-4
+            assert np.max(np.abs(_np(Yg, t) - Yo)) / np.max(np.abs(Yo)) < 2e-4
+            assert abs(O.nmse_capped(sg, zb) - O.nmse_capped(So, zb)) < 1e-6
+            c = cg[t].cpu().numpy()
+            fin = np.isfinite(co)
+            assert np.array_equal(np.isfinite(c), fin)
+            assert np.max(np.abs(c[fin] - co[fin]) / np.abs(co[fin])) < 2e-3
+    for t in range(nb):
+        allowed = set((inp["indx_S"][t, :10 + 5 * Imax] - 1).cpu().numpy().tolist())
+        nz = set(np.flatnonzero(Sa[t].cpu().numpy().reshape(-1, order="F")).tolist())
+        assert nz and nz <= allowed
+    # batched == single
+    S1, _, _ = J.proposed_algorithm_angles(inp["subY"][1:2], inp["Omega"][1:2], inp["indx_S"][1:2], inp["A"],
+                                           inp["B"][1:2], Imax, ty[1:2], tz[1:2], rho[1:2], "approximate", None,
+                                           want_ce=False)
+    assert float((S1[0] - Sa[1]).abs().max() / Sa[1].abs().max()) < 1e-5
+
+
+def test_cfg5_vamp_kron_first_iterations_against_the_oracle():
+    """The drivers' VAMP call at configs[4]: Na = 64, Gr = 64, Gb = B_hbf*B_hbf' of order G2 = 4096 (T_hbf = 8192).
+    VAMP is chaotic in the reference's configuration, so parity is per iteration over the
+    first iterations; at 100 iterations the output must be finite and no worse than the all-zero estimate."""
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import build_trials
+    from oracle import vamp as OV
+    p = _params(T_prop=256)
+    assert p.T_hbf == 8192
+    inp = build_trials(p, 0, 2, seed=78, with_hbf=True)
+    Bh = inp["B_hbf"]
+    Gb = J.colmajor(Bh @ Bh.conj().transpose(1, 2))                      # (B*B')     plot_errorVSsnr.m:79
+    Ym = J.colmajor(inp["Y_hbf"] @ Bh.conj().transpose(1, 2))            # Y_hbf*B'   :80
+    A = inp["A_hbf"]
+    Lnz = 100
+    A_h = A.cpu().numpy().astype(np.complex128)
+    Gb_h, Ym_h = _np(Gb, 0), _np(Ym, 0)
+    for nit, tol in ((1, 1e-4), (3, 1e-3)):
+        X = J.vamp_kron(Ym[:1], A, Gb[:1], 1.0, Lnz, nit=nit)
+        torch.cuda.synchronize()
+        Xo = OV.vamp_kron(Ym_h, A_h, Gb_h, 1.0, Lnz, nit=nit)
+        assert np.max(np.abs(_np(X, 0) - Xo)) / np.max(np.abs(Xo)) < tol, "nit = %d" % nit
+    X = J.vamp_kron(Ym, A, Gb, 1.0, Lnz, nit=100)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(X)).all()
+    zb = J.colmajor(inp["Zbar"].to(torch.complex64))
+    assert float(J.nmse_spectral(X, zb).max()) <= 1.0
+
+
+def test_cfg5_full_frame_shared_pilots_properties():
+    """N=64, M=65 536, Gr=64, G2=4096 with one pilot set for the batch (B = 2 GiB): correlate is the adjoint of
+    synthesize, the solver's outputs are finite with ce(1,3) = Inf, _angles keeps its support inside
+    indx_S(1 : 10 + 5*Imax), and a batched solve equals the single solve."""
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import build_trials
+    p = _params()
+    assert p.solver_shape == (64, 65536, 64, 4096)
+    nb, Imax = 2, 10
+    inp = build_trials(p, 0, nb, seed=79, shared_pilots=True)
+    B = J.colmajor(inp["B"][0].clone())
+    del inp["B"]
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    rnd = lambda *s: torch.complex(torch.randn(*s, generator=g, device="cuda"), torch.randn(*s, generator=g, device="cuda"))
+    K, Sx = J.colmajor(rnd(nb, 64, 65536)), J.colmajor(rnd(nb, 64, 4096))
+    C = J.correlate(K, inp["A"], B)
+    X = J.synthesize(Sx, inp["A"], B)
+    vd = lambda a, b: torch.sum(a.conj().to(torch.complex128) * b.to(torch.complex128), dim=(1, 2))
+    lhs, rhs = vd(C, Sx), vd(K, X)
+    assert float(((lhs - rhs).abs() / rhs.abs()).max()) < 2e-5
+    del K, Sx, C, X
+    ty, tz, rho = inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy()
+    S, Y, ce = J.proposed_algorithm_angles(inp["subY"], inp["Omega"], inp["indx_S"], inp["A"], B, Imax, ty, tz, rho,
+                                           "approximate", None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(S)).all() and torch.isfinite(torch.view_as_real(Y)).all()
+    c = ce.cpu().numpy()
+    assert np.all(np.isinf(c[:, 0, 2])) and np.all(np.isfinite(c[:, 1:, :])) and np.all(c[:, :, :2] >= 0)
+    for t in range(nb):
+        allowed = set((inp["indx_S"][t, :10 + 5 * Imax] - 1).cpu().numpy().tolist())
+        nz = set(np.flatnonzero(S[t].cpu().numpy().reshape(-1, order="F")).tolist())
+        assert nz and nz <= allowed
+    S1, _, _ = J.proposed_algorithm_angles(inp["subY"][1:2], inp["Omega"][1:2], inp["indx_S"][1:2], inp["A"], B, Imax,
+                                           ty[1:2], tz[1:2], rho[1:2], "approximate", None, want_ce=False)
+    torch.cuda.synchronize()
+    assert float((S1[0] - S[1]).abs().max() / S[1].abs().max()) < 1e-5
