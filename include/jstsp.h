@@ -111,6 +111,16 @@ int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
                                  jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out,
                                  int memspace);
 
+/* Trials of the last jstsp_proposed_algorithm_c32/_c64 call on this context that were solved a second time.  The default
+ * iteration for N = 64 (one pass over the dictionary per iteration, csrc/fused.hip) forms `k` (proposed_algorithm.m:43) and
+ * consumes it in the same kernel, so the f16 scale of its split is PREDICTED from the previous iteration's max|k| with
+ * 2^6 of headroom.  A trial whose k grows faster than that raises a per-trial flag; at the end of the solve the library
+ * reads the flags (ONE stream synchronisation per call, also for JSTSP_DEVICE) and solves exactly those trials again with
+ * the three-kernel iteration, whose scales are exact maxima, writing over their S / Y / convergence_error.  No status code
+ * is involved: the call returns the same results as the three-kernel iteration for them.  *count is 0 for every input
+ * that is a measurement of the reference's system model. */
+int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count);
+
 /* S_ls = pinv(A)*Y*pinv(B)   — the LS baseline of the drivers (plot_errorVSsnr.m:83).
  * Factors that fit the in-LDS float64 pinv kernel (see jstsp_pinv_c32; every shape the reference's drivers use)
  * get MATLAB's SVD-based pinv, any rank, any aspect ratio.  Larger factors take the fp32 Gram-inverse route

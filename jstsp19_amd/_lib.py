@@ -55,6 +55,7 @@ SIGNATURES = {
                              c_void_p, c_int]),
     "jstsp_pinv_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
     "jstsp_last_conditioning": (c_int, [c_void_p, c_dp, c_dp]),
+    "jstsp_last_fused_fallbacks": (c_int, [c_void_p, c_ip]),
     "jstsp_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_dp, c_void_p, c_int]),
     "jstsp_omp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p,
                               c_void_p, c_void_p, c_int]),
@@ -163,6 +164,12 @@ class Context:
         check(self._lib.jstsp_get_profile(self.handle, kernel.encode(), C.byref(n), C.byref(ms)),
               "jstsp_get_profile")
         return n.value, ms.value
+
+    def last_fused_fallbacks(self):
+        """Trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass."""
+        n = C.c_int(0)
+        check(self._lib.jstsp_last_fused_fallbacks(self.handle, C.byref(n)), "jstsp_last_fused_fallbacks")
+        return int(n.value)
 
     def last_conditioning(self):
         """(rcond_min, ns_residual_max) of the last call that (pseudo-)inverted a dictionary factor."""

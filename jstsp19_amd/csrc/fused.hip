@@ -37,7 +37,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FPAD = 128;         // bytes of padding per LDS row: row stride = 2 (mod 4) 64-byte slots, for which the four
                                   // 16-lane groups of the phase-A ds_read_b128 each cover all 64 banks once
-constexpr int KBACK = 4;          // the k scale is taken 2^4 below the one its previous maximum would give (see fused_pass_kernel)
+// (FusedDesc::kback, 4 by default: the k scale is taken 2^4 below the one its previous maximum would give, see fused_pass_kernel)
 
 // e such that amax * 2^e lies in [2^13, 2^14)   (as hgemm.hip)
 __device__ __host__ inline int fscale_exp(uint32_t amax_bits)
@@ -180,14 +180,6 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float4 *P, int 
     out[(long long)t * n4 + i] = a;
 }
 
-// a k entry left the f16 range of its scale somewhere in the solve: the results are not to be trusted - make that loud
-__global__ __launch_bounds__(256) void poison_kernel(const uint32_t *ovf, float2 *S, long long n)
-{
-    if (!*ovf) return;
-    const float q = __builtin_nanf("");
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) S[i] = make_float2(q, q);
-}
-
 // DBG != 0 (timing experiments only, results are wrong; not instantiated by default): 1 skips the phase-A products,
 // 2 the element-wise loads / stores, 4 the phase-B products, 8 the tile refill
 // YIN: Y = (I - Q) Z of the next iteration is formed here (Z from d.Zin, fragments of I - Q from d.Wqp) instead of read
@@ -216,10 +208,10 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     const TrialParams prm = d.prm[t];
     const int eb = fscale_exp(d.bmax[(long long)t * d.sbmax]), ew = fscale_exp(d.wmax[t]);
     // k of this pass is formed and consumed here, its maximum is only known afterwards: the scale comes from the
-    // previous iteration's max|k|, backed off by 2^KBACK (room for a 2^(2+KBACK)-fold growth before f16 overflows; entries
+    // previous iteration's max|k|, backed off by 2^kback (room for a 2^(2+kback)-fold growth before f16 overflows; entries
     // keep 22 bits down to 2^-13 of the maximum and 2^-25 absolute of the scaled range below - far under the fp32 noise
     // of the sums).  An overflow raises d.ovf.
-    const int ek = fscale_exp(d.kmax_prev[t]) - KBACK;
+    const int ek = fscale_exp(d.kmax_prev[t]) - d.kback;
     const float sxs = ldexpf(1.f, -(eb + ew)), sk = ldexpf(1.f, ek), sp = ldexpf(1.f, -(eb + ek));
     const float rho = prm.rho, ir = prm.irho, omc = 1.f - prm.c_coef, omr = 1.f - rho, omir = 1.f - ir;
 
@@ -506,7 +498,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         if (d.v1max) atomicMax(&d.v1max[t], __float_as_uint(v1mx));
         if (d.zmax) atomicMax(&d.zmax[t], __float_as_uint(zmx));
         if (d.v2max) atomicMax(&d.v2max[t], __float_as_uint(v2mx));
-        if (d.ovf && !(kmx * sk < 60000.f)) atomicOr(d.ovf, 1u);
+        if (d.ovf && !(kmx * sk < 60000.f)) atomicOr(&d.ovf[t], 1u);      // per trial: the caller re-solves exactly those
     }
 }
 
@@ -520,7 +512,7 @@ bool fused_shape_ok(int N, int M, int G2, int parts)
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts)
 {
     return rnd256((size_t)nB * (M / 32) * 16 * G2 * sizeof(uint4)) + rnd256((size_t)batch * (G2 / 32) * 1024 * sizeof(uint4)) +
-           rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256(sizeof(uint32_t)) + rnd256((size_t)batch * 2048 * sizeof(uint4));
+           rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256((size_t)batch * sizeof(uint32_t)) + rnd256((size_t)batch * 2048 * sizeof(uint4));
 }
 
 int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts)
@@ -531,7 +523,7 @@ int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int par
     f.Bf = ar.get<uint4>((size_t)nB * f.sBf);
     f.ASp = ar.get<uint4>((size_t)batch * f.sAS);
     f.Ppart = ar.get<float2>((size_t)batch * parts * 64 * G2);
-    f.ovf = ar.get<uint32_t>(1);
+    f.ovf = ar.get<uint32_t>(batch);
     f.Wqp = ar.get<uint4>((size_t)batch * 2048);
     JSTSP_REQUIRE(f.Bf && f.ASp && f.Ppart && f.ovf && f.Wqp, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
     return 0;
@@ -591,13 +583,6 @@ int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d)
 int fused_pack_wq(jstsp_ctx *ctx, const FusedWS &f, const float2 *Q, int batch)
 {
     hipLaunchKernelGGL(pack_wq_kernel, dim3(batch), dim3(256), 0, ctx->stream, Q, f.Wqp);
-    JSTSP_HIP(hipGetLastError());
-    return 0;
-}
-
-int fused_poison(jstsp_ctx *ctx, const FusedWS &f, float2 *S, long long n)
-{
-    hipLaunchKernelGGL(poison_kernel, dim3(64), dim3(256), 0, ctx->stream, f.ovf, S, n);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -130,13 +130,16 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
 
 using namespace jstsp;
 
-extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
-                                            const jstsp_c32 *subY_, const float *Omega_,
-                                            const jstsp_c32 *A_, long long strideA, const jstsp_c32 *B_,
-                                            long long strideB, int Imax, const double *tau_Y,
-                                            const double *tau_S, const double *rho, int type,
-                                            const int32_t *indx_S_, jstsp_c32 *S_out, jstsp_c32 *Y_out,
-                                            double *ce_out, int memspace)
+// One batched solve.  allow_fused = false: never the fused pass (the re-solve of trials whose predicted k scale
+// overflowed in it).  overflowed != NULL: receives the indices of such trials (their outputs are not to be used); reading
+// the per-trial flags costs ONE stream synchronisation at the end of a solve that used the fused pass.
+static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                         const jstsp_c32 *subY_, const float *Omega_,
+                         const jstsp_c32 *A_, long long strideA, const jstsp_c32 *B_,
+                         long long strideB, int Imax, const double *tau_Y,
+                         const double *tau_S, const double *rho, int type,
+                         const int32_t *indx_S_, jstsp_c32 *S_out, jstsp_c32 *Y_out,
+                         double *ce_out, int memspace, bool allow_fused, std::vector<int> *overflowed)
 {
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
     JSTSP_REQUIRE(subY_ && Omega_ && A_ && B_ && tau_Y && tau_S && rho && S_out, JSTSP_E_NULL,
@@ -177,7 +180,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     const int ftiles = (M % 32 == 0) ? M / 32 : 0;
     const int fparts = std::max(1, getenv("JSTSP_FUSED_PARTS") ? atoi(getenv("JSTSP_FUSED_PARTS"))
                                                                 : (ftiles % 4 == 0 ? 4 : (ftiles % 2 == 0 ? 2 : 1)));
-    const bool want_fused = (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : true) && approx &&
+    const bool want_fused = allow_fused && (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : true) && approx &&
                             Imax > 1 && fused_shape_ok(N, M, G2, fparts);
     if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);
     if (memspace == JSTSP_HOST) {
@@ -344,8 +347,11 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     if (fusedp) {
         JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts));
         JSTSP_TRY(fused_pack_b(ctx, fw, B, strideB, G2, M, nB, w.Bs.bmax));
-        JSTSP_HIP(hipMemsetAsync(fw.ovf, 0, sizeof(uint32_t), sm));
+        JSTSP_HIP(hipMemsetAsync(fw.ovf, 0, (size_t)batch * sizeof(uint32_t), sm));
     }
+    // headroom (bits) of the k scale the pass predicts from the previous iteration's maximum; JSTSP_FUSED_KBACK is a
+    // test hook: a negative value makes every pass overflow, which must end in the per-trial re-solve below
+    const int fused_kback = getenv("JSTSP_FUSED_KBACK") ? atoi(getenv("JSTSP_FUSED_KBACK")) : 4;
     bool passed = false;                        // X, V1, k-partials of this iteration came from the previous pass
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
@@ -513,7 +519,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                          nx, nx + batch, nx + 2 * (size_t)batch, nx + 4 * (size_t)batch, w.nmax + 2 * (size_t)batch, fw.ovf,
                          M, G2, batch, fparts,
                          fusedy ? fw.Wqp : nullptr, Zbuf[(it + 1) & 1], w.zmax, Zbuf[it & 1],
-                         (fusedy && it + 2 == Imax) ? w.Y : nullptr};
+                         (fusedy && it + 2 == Imax) ? w.Y : nullptr, fused_kback};
             JSTSP_TRY(launch_fused_pass(ctx, fd));
             passed = true;
         } else
@@ -553,14 +559,61 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         }
     }
     if (want_ce && Imax > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_ce, 0));
-    if (fusedp) JSTSP_TRY(fused_poison(ctx, fw, w.S, (long long)(batch * g)));
 
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), w.S, batch * g, memspace));
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), w.Y, batch * nm, memspace));
     if (want_ce && Imax > 0) JSTSP_TRY(stage_out(ctx, ce_out, w.ce, (size_t)batch * 3 * Imax, memspace));
+    if (fusedp && overflowed) {
+        // Trials in which an entry of k left the f16 range of the scale predicted for it (growth beyond 2^(2 + kback) from
+        // one iteration to the next): their results are wrong from that pass on.  The caller re-solves exactly those.
+        std::vector<uint32_t> flags(batch);
+        JSTSP_HIP(hipMemcpyAsync(flags.data(), fw.ovf, (size_t)batch * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        JSTSP_HIP(hipStreamSynchronize(st));
+        for (int t = 0; t < batch; ++t)
+            if (flags[t]) overflowed->push_back(t);
+    }
     if (memspace == JSTSP_HOST) {
         JSTSP_HIP(hipStreamSynchronize(st));
         if (!approx) JSTSP_TRY(diag_check_host(ctx, "proposed_algorithm 'std'"));
     }
+    return 0;
+}
+
+extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                                            const jstsp_c32 *subY, const float *Omega,
+                                            const jstsp_c32 *A, long long strideA, const jstsp_c32 *B,
+                                            long long strideB, int Imax, const double *tau_Y,
+                                            const double *tau_S, const double *rho, int type,
+                                            const int32_t *indx_S, jstsp_c32 *S_out, jstsp_c32 *Y_out,
+                                            double *ce_out, int memspace)
+{
+    std::vector<int> ovf;
+    if (ctx) ctx->fused_fallbacks = 0;
+    JSTSP_TRY(proposed_impl(ctx, N, M, Gr, G2, batch, subY, Omega, A, strideA, B, strideB, Imax, tau_Y, tau_S, rho, type,
+                            indx_S, S_out, Y_out, ce_out, memspace, true, &ovf));
+    // Recovery: runs of consecutive flagged trials are solved again by the three-kernel iteration (every operand scale
+    // there is the exact maximum of data that already exists: it cannot overflow), straight into the caller's arrays -
+    // per-trial arrays are contiguous with the trial index slowest, so a sub-batch is a pointer offset in either memspace.
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2;
+    for (size_t i = 0; i < ovf.size();) {
+        size_t j = i + 1;
+        while (j < ovf.size() && ovf[j] == ovf[j - 1] + 1) ++j;
+        const int t0 = ovf[i], cnt = (int)(j - i);
+        JSTSP_TRY(proposed_impl(ctx, N, M, Gr, G2, cnt, subY + t0 * nm, Omega + t0 * nm, A + (size_t)t0 * strideA, strideA,
+                                B + (size_t)t0 * strideB, strideB, Imax, tau_Y + t0, tau_S + t0, rho + t0, type,
+                                indx_S ? indx_S + t0 * g : nullptr, S_out + t0 * g, Y_out ? Y_out + t0 * nm : nullptr,
+                                ce_out ? ce_out + (size_t)t0 * 3 * Imax : nullptr, memspace, false, nullptr));
+        ctx->fused_fallbacks += cnt;
+        i = j;
+    }
+    return 0;
+}
+
+/* Trials of the last jstsp_proposed_algorithm_* call on this context that were solved a second time by the three-kernel
+ * iteration because the fused pass's predicted operand scale overflowed for them (0 in all but pathological inputs). */
+extern "C" int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count)
+{
+    JSTSP_REQUIRE(ctx && count, JSTSP_E_NULL, "last_fused_fallbacks: NULL argument");
+    *count = ctx->fused_fallbacks;
     return 0;
 }

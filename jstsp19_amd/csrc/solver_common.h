@@ -110,7 +110,7 @@ struct FusedWS {
     uint4 *Bf = nullptr; long long sBf = 0;       // tile images of B, uint4 per problem
     uint4 *ASp = nullptr; long long sAS = 0;      // B-operand fragments of (A S)^T, re-packed every iteration
     float2 *Ppart = nullptr;                      // [batch][parts][N x G2] partial sums of K B^H
-    uint32_t *ovf = nullptr;                      // raised when a k entry left the f16 range of its scale
+    uint32_t *ovf = nullptr;                      // [batch]: raised for a trial when a k entry left the f16 range of its scale
     uint4 *Wqp = nullptr;                         // B-operand fragments of (I - Q)^T, 2048 uint4 per problem
     int parts = 0;
 };
@@ -130,6 +130,7 @@ struct FusedDesc {
     // Y formed in the pass (instead of read from Y): fragments of I - Q, the svt argument Z of the next iteration and its
     // maximum, where to put the Z after that; Yout != NULL: also store Y (the last pass: Y is an output of the solver)
     const uint4 *Wqp; const float2 *Zin; const uint32_t *zmax_in; float2 *Zout, *Yout;
+    int kback;                                    // headroom of the predicted k scale in bits (KBACK; JSTSP_FUSED_KBACK: tests)
 };
 bool fused_shape_ok(int N, int M, int G2, int parts);
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts);
@@ -139,6 +140,5 @@ int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long s
 int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d);
 int fused_reduce(jstsp_ctx *ctx, const FusedWS &f, int G2, int batch, float2 *Tc);
 int fused_pack_wq(jstsp_ctx *ctx, const FusedWS &f, const float2 *Q, int batch);      // from the raw Q of svt_prepare
-int fused_poison(jstsp_ctx *ctx, const FusedWS &f, float2 *S, long long n);    // NaN into S if a k scale overflowed
 
 }  // namespace jstsp

@@ -74,9 +74,11 @@ def test_cfg5_vamp_kron_first_iterations_against_the_oracle():
     import jstsp19_amd as J
     from jstsp19_amd.system_model import build_trials
     from oracle import vamp as OV
-    p = _params(T_prop=256)
+    p = _params()                         # (the conventional-HBF frame is cut from the proposed scheme's: full frame)
     assert p.T_hbf == 8192
-    inp = build_trials(p, 0, 2, seed=78, with_hbf=True)
+    inp = build_trials(p, 0, 2, seed=78, with_hbf=True, shared_pilots=True)
+    del inp["B"], inp["subY"], inp["Omega"]
+    torch.cuda.empty_cache()
     Bh = inp["B_hbf"]
     Gb = J.colmajor(Bh @ Bh.conj().transpose(1, 2))                      # (B*B')     plot_errorVSsnr.m:79
     Ym = J.colmajor(inp["Y_hbf"] @ Bh.conj().transpose(1, 2))            # Y_hbf*B'   :80

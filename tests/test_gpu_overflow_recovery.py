@@ -1,0 +1,89 @@
+"""The fused pass (csrc/fused.hip) predicts the f16 scale of `k` (proposed_algorithm.m:43) from the previous iteration's
+maximum.  A trial whose k outgrows the prediction must not poison anything: it is flagged, solved again by the
+three-kernel iteration inside the same call, and the call returns what that iteration returns - for that trial only."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(inp, Imax, env=None, want_ce=True, Omega=None):
+    import torch
+    import jstsp19_amd as J
+    env = env or {}
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        r = J.proposed_algorithm(inp["subY"], inp["Omega"] if Omega is None else Omega, inp["A"], inp["B"], Imax,
+                                 inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate",
+                                 want_ce=want_ce)
+        torch.cuda.synchronize()
+        n = J.default_context(0).last_fused_fallbacks()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    return [None if x is None else x.cpu().numpy() for x in r], n
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30))
+
+
+def _small():
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    p = SweepParams(Nt=16, Nr=64, L=8, T=32, Mr=8, snr_db=5.0)            # N=64, M=512, Gr=64, G2=128: fused-pass shape
+    assert p.solver_shape == (64, 512, 64, 128)
+    return build_trials(p, 0, 6, seed=41)
+
+
+def test_forced_overflow_of_every_trial_is_recovered():
+    """JSTSP_FUSED_KBACK=-20 puts the k scale 2^20 above what its previous maximum allows: every pass overflows for
+    every trial.  The call must still return the three-kernel iteration's results, and say that it re-solved them."""
+    inp = _small()
+    (S0, Y0, c0), n0 = _solve(inp, 15, {"JSTSP_FUSED": "0"})
+    (S1, Y1, c1), n1 = _solve(inp, 15)
+    assert n0 == 0 and n1 == 0                                               # nothing to recover on healthy inputs
+    (S2, Y2, c2), n2 = _solve(inp, 15, {"JSTSP_FUSED_KBACK": "-20"})
+    assert n2 == 6
+    assert np.all(np.isfinite(S2)) and np.all(np.isfinite(Y2))
+    assert _rel(S2, S0) < 1e-6 and _rel(Y2, Y0) < 1e-6                       # the same kernels as JSTSP_FUSED=0
+    fin = np.isfinite(c0)
+    assert np.array_equal(np.isfinite(c2), fin) and np.max(np.abs(c2[fin] - c0[fin]) / np.abs(c0[fin])) < 1e-4
+    assert _rel(S1, S0) < 1e-5                                               # and the healthy fused solve agrees anyway
+
+
+def test_one_trial_whose_k_jumps_is_re_solved_alone_and_matches_the_oracle():
+    """A weight matrix Omega with entries just above -2*rho where nothing was sampled makes 1/(Omega + 2 rho) = 1e3 there
+    (iK1 of proposed_algorithm.m:14-20 is defined for any Omega): X is zero at those entries after iteration 1 and
+    1e3 x (rho Xs + ...) after iteration 2 - k grows by more than two orders of magnitude between two passes, in ONE trial."""
+    import torch
+    from oracle import solvers as O
+    inp = _small()
+    bad = 3
+    inp["rho"] = torch.from_numpy(inp["rho"].numpy().astype(np.float32).astype(np.float64))   # (Omega + 2 rho exact in fp32)
+    rho = float(inp["rho"][bad])
+    Om = inp["Omega"].clone()
+    zero = (Om[bad] == 0).nonzero()
+    pick = zero[torch.linspace(0, len(zero) - 1, 7).long()]
+    for r, c in pick.tolist():
+        Om[bad, r, c] = -2.0 * rho + 1e-3
+    (S1, Y1, c1), n1 = _solve(inp, 12, Omega=Om)
+    assert n1 == 1                                                           # that trial, and only that trial
+    assert np.all(np.isfinite(S1)) and np.all(np.isfinite(Y1)) and np.all(np.isfinite(c1[:, 1:, :]))
+    (S0, Y0, c0), _ = _solve(inp, 12, {"JSTSP_FUSED": "0"}, Omega=Om)
+    assert _rel(S1[bad], S0[bad]) < 1e-6 and _rel(Y1[bad], Y0[bad]) < 1e-6
+    for t in range(6):
+        assert _rel(S1[t], S0[t]) < 1e-5
+    # against the float64 oracle: the flagged trial and a healthy neighbour
+    A_h = inp["A"].cpu().numpy().astype(np.complex128)
+    for t in (bad, bad + 1):
+        So, Yo, _ = O.proposed_algorithm(inp["subY"][t].cpu().numpy().astype(np.complex128),
+                                         Om[t].cpu().numpy().astype(np.float64), A_h,
+                                         inp["B"][t].cpu().numpy().astype(np.complex128), 12, float(inp["tau_Y"][t]),
+                                         float(inp["tau_Z"][t]), float(inp["rho"][t]), "approximate", want_ce=False)
+        assert _rel(S1[t], So) < 5e-4, t
+    # two outputs only (no three-Gram pass): same recovery
+    (S3, _, _), n3 = _solve(inp, 12, Omega=Om, want_ce=False)
+    assert n3 == 1 and _rel(S3, S1) < 1e-5
