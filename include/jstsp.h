@@ -72,6 +72,17 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
 
 /* ---- kernel-level entry points (the north-star correlation / synthesis) ------------ */
 
+/* Accuracy of the two products below (and of the same contractions inside the solvers).  Results are fp32.  Large
+ * contractions (m*n*k >= 2^22) run on the f16 matrix pipe with every fp32 operand split x = h + l into two halves of a
+ * power-of-two scaled value (22-23 significant bits) and fp32 accumulation: the error of a product is bounded like an fp32
+ * GEMM's, |err| <= c k 2^-24 max_k|a_ik| max_k|b_kj|, i.e. fp32 relative accuracy with respect to the LARGEST terms of each
+ * sum.  These two entry points scale the rows / columns along the indices that are not contracted (rows of K and of B in
+ * correlate; rows of A*S and columns of B in synthesize) by exact powers of two to a common magnitude first, so a row that
+ * is 1e-8 of the rest of its problem still comes out with fp32 relative accuracy (tests/test_gpu_hgemm.py).  Along the
+ * contracted index the bound above holds: an addend far below the largest addends of its sum contributes with fewer
+ * digits, as it does to an fp32 sum.  Inside the solvers the scales are per problem (the ADMM state has no such
+ * dynamic range; parity against the float64 oracle is norm-wise: |dNMSE| <= 1e-6, max|dS| <= 2e-4 max|S|). */
+
 /* out = A' * K * B'   (Gr x G2)   — `K2'*k` of proposed_algorithm.m:47 in structured form,
  * `A'*r` of OMP.m:17 when the dictionary is kron(B.', A).
  * K: N x M x batch.  A: N x Gr, B: G2 x M; strideA/strideB = elements between consecutive

@@ -77,6 +77,82 @@ __global__ __launch_bounds__(256) void rate_kernel(int batch, int n, int R, cons
     rate[t] = acc;
 }
 
+// ---- equilibration of the public correlate / synthesize on the split-f16 path -----------------------------------
+// The split x = h + l of hgemm.hip is exact to 2^-23 of the per-PROBLEM maximum.  A row of K (or of B) far below that
+// maximum would keep fewer digits than an fp32 product gives it, although the output row it produces depends on nothing
+// else.  Rows / columns along the indices that are NOT contracted are therefore scaled by exact powers of two to a
+// common magnitude before the split and scaled back afterwards: every output row and column then carries fp32 relative
+// accuracy with respect to its own operands.  (Along the contracted index the accuracy is that of the sum's largest terms,
+// as in any fp32 product whose addends differ in magnitude.)
+
+// e[t][i] = exponent of max(|re|, |im|) over row i (axis 0) or column i (axis 1) of the rows x cols matrix X[t]; 0 for a zero line
+__global__ __launch_bounds__(256) void axis_exp_kernel(int rows, int cols, const float2 *X, long long sXt, int axis, int32_t *e)
+{
+    const int t = blockIdx.y, tid = threadIdx.x;
+    const float2 *x = X + (long long)t * sXt;
+    __shared__ float red[256];
+    if (axis == 0) {
+        const int r = blockIdx.x * 64 + (tid & 63), ph = tid >> 6;
+        float m = 0.f;
+        if (r < rows)
+            for (int c = ph; c < cols; c += 4) {
+                const float2 v = x[r + (long long)rows * c];
+                m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+            }
+        red[tid] = m;
+        __syncthreads();
+        if (ph == 0 && r < rows) {
+            m = fmaxf(fmaxf(red[tid], red[tid + 64]), fmaxf(red[tid + 128], red[tid + 192]));
+            e[(long long)t * rows + r] = (m > 0.f && m < INFINITY) ? ilogbf(m) : 0;
+        }
+    } else {
+        const int c = blockIdx.x * 4 + (tid >> 6), l = tid & 63;
+        float m = 0.f;
+        if (c < cols)
+            for (int r = l; r < rows; r += 64) {
+                const float2 v = x[r + (long long)rows * c];
+                m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (l == 0 && c < cols) e[(long long)t * cols + c] = (m > 0.f && m < INFINITY) ? ilogbf(m) : 0;
+    }
+}
+
+// out[t][i, j] = in[t][i, j] * 2^(sign * (er[t][i] + ec[t][j]))   (er / ec may be NULL; strides 0 = shared by the batch)
+__global__ __launch_bounds__(256) void scale2_kernel(int rows, int cols, const float2 *in, long long sIn, float2 *out, long long sOut,
+                                                     const int32_t *er, long long ser, const int32_t *ec, long long sec, int sign)
+{
+    const int t = blockIdx.y;
+    const long long n = (long long)rows * cols, stride = (long long)gridDim.x * 256;
+    const float2 *x = in + (long long)t * sIn;
+    float2 *o = out + (long long)t * sOut;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i % rows), c = (int)(i / rows);
+        const int ex = sign * ((er ? er[(long long)t * ser + r] : 0) + (ec ? ec[(long long)t * sec + c] : 0));
+        const float2 v = x[i];
+        o[i] = make_float2(ldexpf(v.x, ex), ldexpf(v.y, ex));
+    }
+}
+
+static int axis_exp(jstsp_ctx *ctx, int rows, int cols, const float2 *X, long long sXt, int count, int axis, int32_t *e)
+{
+    const dim3 g(axis == 0 ? (rows + 63) / 64 : (cols + 3) / 4, count);
+    hipLaunchKernelGGL(axis_exp_kernel, g, dim3(256), 0, ctx->stream, rows, cols, X, sXt, axis, e);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+static dim3 grid2(long long n, int batch);
+static int scale2(jstsp_ctx *ctx, int rows, int cols, int count, const float2 *in, long long sIn, float2 *out, long long sOut,
+                  const int32_t *er, long long ser, const int32_t *ec, long long sec, int sign)
+{
+    hipLaunchKernelGGL(scale2_kernel, grid2((long long)rows * cols, count), dim3(256), 0, ctx->stream, rows, cols, in, sIn, out,
+                       sOut, er, ser, ec, sec, sign);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
 static dim3 grid2(long long n, int batch)
 {
     long long blocks = std::max<long long>(1, std::min<long long>((n + 255) / 256, (4096 + batch - 1) / batch));
@@ -124,7 +200,9 @@ int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
     size_t need = rnd256(batch * ng * sizeof(float2)) + rnd256(batch * g * sizeof(float2));
     const bool h2 = use_hgemm(N, G2, M);
     const int nB = strideB ? batch : 1;
-    if (h2) need += hgemm_pack_bytes(M, G2, nB) + rnd256(batch * sizeof(uint32_t));
+    if (h2) need += hgemm_pack_bytes(M, G2, nB) + rnd256(batch * sizeof(uint32_t)) + rnd256(batch * nm * sizeof(float2)) +
+                    rnd256((size_t)nB * G2 * M * sizeof(float2)) + rnd256((size_t)batch * N * sizeof(int32_t)) +
+                    rnd256((size_t)nB * G2 * sizeof(int32_t));
     if (memspace == JSTSP_HOST)
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -138,15 +216,25 @@ int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
     JSTSP_REQUIRE(Tc && O, JSTSP_E_NOMEM, "correlate: workspace exhausted");
     // A^H (K B^H): the cheaper association (N*M*G2 + Gr*N*G2 MACs)
     if (h2) {
+        // rows of K (index n) and rows of B (index g) are not contracted: equilibrate them (see axis_exp_kernel)
+        int32_t *eK = ctx->arena.get<int32_t>((size_t)batch * N), *eB = ctx->arena.get<int32_t>((size_t)nB * G2);
+        float2 *Ks = ctx->arena.get<float2>(batch * nm), *Bs = ctx->arena.get<float2>((size_t)nB * G2 * M);
+        JSTSP_REQUIRE(eK && eB && Ks && Bs, JSTSP_E_NOMEM, "correlate: workspace exhausted");
+        const long long sBs = strideB ? (long long)G2 * M : 0;
+        JSTSP_TRY(axis_exp(ctx, N, M, K, (long long)nm, batch, 0, eK));
+        JSTSP_TRY(scale2(ctx, N, M, batch, K, (long long)nm, Ks, (long long)nm, eK, N, nullptr, 0, -1));
+        JSTSP_TRY(axis_exp(ctx, G2, M, B, strideB, nB, 0, eB));
+        JSTSP_TRY(scale2(ctx, G2, M, nB, B, strideB, Bs, sBs, eB, G2, nullptr, 0, -1));
         // b(k = m, j = g) = conj(B[g + G2 m]) packed once; a = K
         HPack pk;
-        JSTSP_TRY(hgemm_pack(ctx, pk, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
+        JSTSP_TRY(hgemm_pack(ctx, pk, ctx->arena, Bs, sBs, G2, 1, 1, M, G2, nB, (long long)G2 * M));
         uint32_t *amax = ctx->arena.get<uint32_t>(batch);
         JSTSP_REQUIRE(amax, JSTSP_E_NOMEM, "correlate: workspace exhausted");
-        JSTSP_TRY(hgemm_absmax(ctx, K, (long long)nm, (long long)nm, batch, amax));
-        HGemmDesc hd{K, (long long)nm, N, amax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS, pk.JT,
+        JSTSP_TRY(hgemm_absmax(ctx, Ks, (long long)nm, (long long)nm, batch, amax));
+        HGemmDesc hd{Ks, (long long)nm, N, amax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS, pk.JT,
                      Tc, (long long)ng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
         JSTSP_TRY(launch_hgemm(ctx, hd, "correlate"));
+        JSTSP_TRY(scale2(ctx, N, G2, batch, Tc, (long long)ng, Tc, (long long)ng, eK, N, eB, strideB ? G2 : 0, +1));
     } else
     JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{K, (long long)nm, N}, Mat{B, strideB, G2}, Tc,
                    (long long)ng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
@@ -171,7 +259,8 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     size_t need = rnd256(batch * ng * sizeof(float2)) + rnd256(batch * nm * sizeof(float2));
     const bool h2 = use_hgemm(N, M, G2);
     const int nB = strideB ? batch : 1;
-    if (h2) need += hgemm_pack_bytes(G2, M, nB) + rnd256(batch * sizeof(uint32_t));
+    if (h2) need += hgemm_pack_bytes(G2, M, nB) + rnd256(batch * sizeof(uint32_t)) + rnd256((size_t)nB * G2 * M * sizeof(float2)) +
+                    rnd256((size_t)batch * N * sizeof(int32_t)) + rnd256((size_t)nB * M * sizeof(int32_t));
     if (memspace == JSTSP_HOST)
         need += rnd256(batch * g * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -186,15 +275,25 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, Gr, batch, Mat{A, strideA, N}, Mat{S, (long long)g, Gr}, W,
                    (long long)ng, N));
     if (h2) {
+        // rows of A S (index n) and columns of B (index m) are not contracted: equilibrate them (see axis_exp_kernel)
+        int32_t *eW = ctx->arena.get<int32_t>((size_t)batch * N), *eB = ctx->arena.get<int32_t>((size_t)nB * M);
+        float2 *Bs = ctx->arena.get<float2>((size_t)nB * G2 * M);
+        JSTSP_REQUIRE(eW && eB && Bs, JSTSP_E_NOMEM, "synthesize: workspace exhausted");
+        const long long sBs = strideB ? (long long)G2 * M : 0;
+        JSTSP_TRY(axis_exp(ctx, N, G2, W, (long long)ng, batch, 0, eW));
+        JSTSP_TRY(scale2(ctx, N, G2, batch, W, (long long)ng, W, (long long)ng, eW, N, nullptr, 0, -1));
+        JSTSP_TRY(axis_exp(ctx, G2, M, B, strideB, nB, 1, eB));
+        JSTSP_TRY(scale2(ctx, G2, M, nB, B, strideB, Bs, sBs, nullptr, 0, eB, M, -1));
         // b(k = g, j = m) = B[g + G2 m] packed once; a = A S
         HPack pk;
-        JSTSP_TRY(hgemm_pack(ctx, pk, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M));
+        JSTSP_TRY(hgemm_pack(ctx, pk, ctx->arena, Bs, sBs, 1, G2, 0, G2, M, nB, (long long)G2 * M));
         uint32_t *amax = ctx->arena.get<uint32_t>(batch);
         JSTSP_REQUIRE(amax, JSTSP_E_NOMEM, "synthesize: workspace exhausted");
         JSTSP_TRY(hgemm_absmax(ctx, W, (long long)ng, (long long)ng, batch, amax));
         HGemmDesc hd{W, (long long)ng, N, amax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS, pk.JT,
                      O, (long long)nm, N, N, M, G2, batch, EPI_NONE, nullptr, nullptr, nullptr};
         JSTSP_TRY(launch_hgemm(ctx, hd, "synthesize"));
+        JSTSP_TRY(scale2(ctx, N, M, batch, O, (long long)nm, O, (long long)nm, eW, N, eB, strideB ? M : 0, +1));
     } else
     JSTSP_TRY(gemm(ctx, 'N', 'N', N, M, G2, batch, Mat{W, (long long)ng, N}, Mat{B, strideB, G2}, O,
                    (long long)nm, N, 1.f, nullptr, 0, 0, 0.f, GEMM_SYNTH));

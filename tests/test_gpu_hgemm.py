@@ -223,3 +223,38 @@ def test_side_stream_overlap_is_bit_identical_through_the_split_f16_grams(force_
             os.environ.pop("JSTSP_OVERLAP", None)
         else:
             os.environ["JSTSP_OVERLAP"] = old
+
+
+def test_public_correlate_and_synthesize_keep_fp32_accuracy_per_row_under_dynamic_range():
+    """One row of K (and one row of B) 1e-8 below the rest of the problem: the output row / column it produces depends on
+    nothing else, so it must come out with fp32 relative accuracy - the split-f16 scale is per problem, the public entry
+    points equilibrate the non-contracted indices by exact powers of two first (csrc/api_misc.hip)."""
+    import torch
+    import jstsp19_amd as J
+    N, M, Gr, G2, b = 64, 4096, 64, 512, 2
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    rnd = lambda *s: torch.complex(torch.randn(*s, generator=g, device="cuda", dtype=torch.float64),
+                                   torch.randn(*s, generator=g, device="cuda", dtype=torch.float64))
+    A = torch.eye(N, dtype=torch.complex128, device="cuda")              # keeps the rows of K B^H apart in the output
+    K, B, S = rnd(b, N, M), rnd(b, G2, M), rnd(b, Gr, G2)
+    K[:, 5, :] *= 1e-8
+    B[:, 17, :] *= 1e-8
+    cm = lambda x: J.colmajor(x.to(torch.complex64))
+    K32, B32, S32, A32 = cm(K), cm(B), cm(S), cm(A)
+    ref = A.conj().T @ K32.to(torch.complex128) @ B32.to(torch.complex128).conj().transpose(1, 2)
+    out = J.correlate(K32, A32, B32).to(torch.complex128)
+    err = (out - ref).abs()
+    row = err.amax(dim=2) / ref.abs().amax(dim=2)                         # per output row (n)
+    col = err.amax(dim=1) / ref.abs().amax(dim=1)                         # per output column (g)
+    assert float(row.max()) < 1e-6 and float(col.max()) < 1e-6, (float(row.max()), float(col.max()))
+    assert float(row[:, 5].max()) < 1e-6 and float(col[:, 17].max()) < 1e-6
+    # synthesize: rows of A S (here: of S) and columns of B
+    S[:, 9, :] *= 1e-8
+    Bc = rnd(b, G2, M); Bc[:, :, 100] *= 1e-8
+    S32, Bc32 = cm(S), cm(Bc)
+    ref = A @ S32.to(torch.complex128) @ Bc32.to(torch.complex128)
+    out = J.synthesize(S32, A32, Bc32).to(torch.complex128)
+    err = (out - ref).abs()
+    assert float((err.amax(dim=2) / ref.abs().amax(dim=2)).max()) < 1e-6
+    assert float((err.amax(dim=1) / ref.abs().amax(dim=1)).max()) < 1e-6
+    torch.cuda.synchronize()
