@@ -45,10 +45,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="Monte-Carlo trials per GPU per step")
     ap.add_argument("--snr-db", type=float, default=5.0)
     ap.add_argument("--no-ce", action="store_true", help="skip convergence_error (2-output call)")
-    ap.add_argument("--cpu-trials", type=int, default=2, help="trials timed on the host oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-trials", type=int, default=-1,
+                    help="trials timed on the host baseline (rank 0, N=1); -1 = one per physical core (at most the batch), 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="BLAS threads for the host oracle (0 = min(32, host cores))")
+                    help="OpenMP threads of the host baseline (0 = physical cores = logical CPUs / 2)")
     ap.add_argument("--shared-pilots", action="store_true", help="one pilot set for all trials (B shared, stride 0)")
     ap.add_argument("--small", action="store_true", help="reference-native shape (plumbing check)")
     ap.add_argument("--sweep", action="store_true",
@@ -250,13 +251,17 @@ def main():
     flops_per_launch = 8.0 * N * M * G2 * a.batch              # either contraction, 8 real flops per complex MAC
     # HBM traffic of the same kernels from the committed PMC measurement (separate rocprofv3 --pmc passes,
     # FETCH_SIZE doubled as the microarch guide prescribes for gfx950); only valid for the profiled shape
-    pm = {}
-    try:
-        if not a.small and a.batch == 256:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                pm = json.load(f)
-    except (OSError, ValueError):
-        pm = {}
+    pm, pm_src = {}, None
+    if not a.small and a.batch == 256:
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):      # the newest committed measurement
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pm = json.load(f)
+                pm_src = "profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py` on the build " \
+                         "%s; a committed measurement, not collected in this run)" % (name, pm.get("build", "of that round"))
+                break
+            except (OSError, ValueError):
+                pm = {}
     traffic_of = lambda key: pm.get(key, {}).get("hbm_bytes_per_launch")
     roofline = None
     if n_f:
@@ -279,6 +284,7 @@ def main():
                     "algorithmic_tflops": round(2 * flops_per_launch / (avg_f * 1e-3) / 1e12, 1),
                     "note": "the three kernels this pass replaces (JSTSP_FUSED=0) run at 0.66-0.68 of the HBM peak each but move "
                             "16.5 GB per iteration instead of 9.9 GB"}
+        roofline["traffic_source"] = pm_src if roofline["traffic"] else None
         if roofline["traffic"]:     # measured bytes (PMC) over the same duration: what the memory system actually delivers
             roofline["traffic_rate"] = round(roofline["traffic"] / (avg_f * 1e-3) / 1e9, 1)
             roofline["traffic_frac"] = round(roofline["traffic"] / (avg_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -304,36 +310,86 @@ def main():
                                      "algorithmic_tflops": round(flops_per_launch / (avg_c * 1e-3) / 1e12, 1)}
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, single-GPU runs only) -------------
+    # cpu_baseline: oracle/cpu_port.cpp - the float64 C++ restatement of proposed_algorithm.m with OpenMP over the trials
+    # (the reference's parfor), one trial per core, on `cpu_trials` of the same trials.  The same
+    # outputs are the float64 side of the parity check; ONE trial is also solved by the numpy oracle to tie the two.
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.cpu_trials > 0:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.cpu_trials != 0:
+        import tempfile
+        from oracle import build_cpu_port as bp
         from oracle import solvers as O
-        nt = min(a.cpu_trials, a.batch)
+        ncore = os.cpu_count() or 1
+        phys = max(1, ncore // 2)                                  # SMT siblings do not add FMA throughput
+        nthr = a.cpu_threads or phys
+        nt = min(a.batch, a.cpu_trials if a.cpu_trials > 0 else nthr)
+        try:                                                       # tuned for the host it is timed on
+            lib = bp.load(bp.build(native=True, out=os.path.join(tempfile.mkdtemp(prefix="jstsp_cpu_"), "libjstsp_cpu_port.so")))
+            tuned = "-march=native"
+        except (RuntimeError, OSError):
+            lib = bp.load()
+            tuned = "-march=x86-64-v4 (prebuilt)"
         h = {k: inp[k][:nt].cpu().numpy() for k in ("subY", "Omega", "Zbar")}
-        Bh = inp["B"].cpu().numpy()
-        h["B"] = np.broadcast_to(Bh, (nt,) + Bh.shape) if Bh.ndim == 2 else Bh[:nt]
-        A_h = inp["A"].cpu().numpy().astype(np.complex128)
+        Bh = inp["B"].cpu().numpy() if inp["B"].ndim == 2 else inp["B"][:nt].cpu().numpy()
+        A_h = inp["A"].cpu().numpy()
         S_h = S[:nt].cpu().numpy().astype(np.complex128)
+        tY, tZ, rh = (np.asarray(inp[k][:nt], dtype=np.float64) for k in ("tau_Y", "tau_Z", "rho"))
+        bp.proposed_algorithm(lib, h["subY"][:1], h["Omega"][:1], A_h, Bh if Bh.ndim == 2 else Bh[:1], 2, tY[:1], tZ[:1], rh[:1],
+                              want_ce=want_ce, threads=1)          # load + first-touch, not timed
+        t0 = time.perf_counter()
+        Sc, Yc, cec, used = bp.proposed_algorithm(lib, h["subY"], h["Omega"], A_h, Bh, IMAX, tY, tZ, rh, want_ce=want_ce,
+                                                  threads=nthr)
+        cdt = time.perf_counter() - t0
+        try:
+            model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+        except (OSError, IndexError):
+            model = "unknown"
+        cpu = {"value": round(nt / cdt, 4), "unit": "channel-estimates/s", "cores": used, "kind": "port",
+               "cpu_model": model, "logical_cpus": ncore, "seconds": round(cdt, 2),
+               "sample": "%d of the %d trials of this workload, Imax=%d, ce=%s: float64 C++ structured restatement of "
+                         "proposed_algorithm.m (oracle/cpu_port.cpp, %s), OpenMP over trials, one trial per thread, %d "
+                         "threads; timing includes the float64 conversion of the inputs (about 2 %%)" % (nt, a.batch, IMAX,
+                                                                                                       want_ce, tuned, used)}
+        dn = [(O.nmse_capped(S_h[t], h["Zbar"][t]), O.nmse_capped(Sc[t], h["Zbar"][t]),
+               float(np.max(np.abs(S_h[t] - Sc[t])) / np.max(np.abs(Sc[t])))) for t in range(nt)]
+        parity = {"trials": nt, "against": "oracle/cpu_port.cpp (float64)",
+                  "max_abs_dNMSE": float(max(abs(x[0] - x[1]) for x in dn)),
+                  "mean_abs_dNMSE": float(np.mean([abs(x[0] - x[1]) for x in dn])),
+                  "max_rel_dS": float(max(x[2] for x in dn))}
+        if want_ce:
+            cg = ce[:nt].cpu().numpy()
+            fin = np.isfinite(cec)
+            parity["max_rel_dce"] = float(np.max(np.abs(cg[fin] - cec[fin]) / np.abs(cec[fin])))
+        # one trial by the numpy oracle (23 s): the C++ port and the line-cited restatement agree at full size
         from threadpoolctl import threadpool_limits
-        nthr = a.cpu_threads or min(32, os.cpu_count() or 1)
-        dn = []
-        with threadpool_limits(limits=nthr):
+        with threadpool_limits(limits=min(32, ncore)):
+            So, _, _ = O.proposed_algorithm(h["subY"][0].astype(np.complex128), h["Omega"][0].astype(np.float64),
+                                            A_h.astype(np.complex128), (Bh if Bh.ndim == 2 else Bh[0]).astype(np.complex128),
+                                            IMAX, float(tY[0]), float(tZ[0]), float(rh[0]), "approximate", want_ce=False)
+        parity["numpy_oracle_vs_cpu_port_rel_dS"] = float(np.max(np.abs(So - Sc[0])) / np.max(np.abs(So)))
+        parity["numpy_oracle_abs_dNMSE"] = float(abs(O.nmse_capped(S_h[0], h["Zbar"][0]) - O.nmse_capped(So, h["Zbar"][0])))
+        del h, Bh, Sc, Yc
+
+    # ---- the drop-in call: the same trials through JSTSP_HOST (host arrays in and out, PCIe inside the call) --------
+    host = None
+    if rank == 0 and world == 1 and not a.no_host_path and not a.shared_pilots:
+        hs = {k: inp[k].cpu().numpy() for k in ("subY", "Omega", "B")}      # column-major host arrays, as MATLAB holds them
+        hA = inp["A"].cpu().numpy()
+        gib = sum(v.nbytes for v in hs.values()) / 2 ** 30
+        best = None
+        for rep in range(2):                                                # (the first call grows the workspace)
             t0 = time.perf_counter()
-            for t in range(nt):
-                So, Yo, ceo = O.proposed_algorithm(h["subY"][t].astype(np.complex128),
-                                                   h["Omega"][t].astype(np.float64), A_h,
-                                                   h["B"][t].astype(np.complex128), IMAX, float(inp["tau_Y"][t]),
-                                                   float(inp["tau_Z"][t]), float(inp["rho"][t]), "approximate",
-                                                   want_ce=want_ce)
-                dn.append((O.nmse_capped(S_h[t], h["Zbar"][t]), O.nmse_capped(So, h["Zbar"][t]),
-                           float(np.max(np.abs(S_h[t] - So)) / np.max(np.abs(So)))))
-            cdt = time.perf_counter() - t0
-        cpu = {"value": round(nt / cdt, 4), "unit": "channel-estimates/s", "cores": nthr, "kind": "port",
-               "sample": "%d of the %d trials of this workload, float64 numpy/OpenBLAS structured restatement "
-                         "(oracle.solvers.proposed_algorithm, Imax=100, ce=%s)" % (nt, a.batch, want_ce)}
-        parity = {"trials": nt, "max_abs_dNMSE": float(max(abs(x[0] - x[1]) for x in dn)),
-                  "max_rel_dS": float(max(x[2] for x in dn)), "nmse_gpu": [x[0] for x in dn],
-                  "nmse_oracle": [x[1] for x in dn]}
+            So_, Yo_, ceo_ = J.proposed_algorithm(hs["subY"], hs["Omega"], hA, hs["B"], IMAX, inp["tau_Y"], inp["tau_Z"],
+                                                  inp["rho"], "approximate", want_ce=want_ce)
+            hdt = time.perf_counter() - t0
+            best = hdt if best is None else min(best, hdt)
+        same = bool(np.array_equal(np.asarray(So_), S.cpu().numpy()))
+        host = {"value": round(a.batch / best, 2), "unit": "channel-estimates/s", "seconds": round(best, 4),
+                "h2d_gib": round(gib, 3), "d2h_gib": round((So_.nbytes + Yo_.nbytes + (ceo_.nbytes if want_ce else 0)) / 2 ** 30, 3),
+                "bit_identical_to_device_call": same,
+                "note": "jstsp_proposed_algorithm_c32 with memspace JSTSP_HOST: pageable numpy arrays in (subY, Omega, B per trial), "
+                        "S, Y, convergence_error out - what a MEX call pays; never the headline value"}
+        del hs
 
     if rank == 0:
         total = a.batch * world * a.steps
@@ -345,7 +401,7 @@ def main():
             "config": {"workload": workload, "trials_per_gpu_per_step": a.batch, "Imax": IMAX,
                        "outputs": "S,Y,convergence_error" if want_ce else "S,Y", "snr_db": a.snr_db,
                        "pilots": "shared (one B)" if a.shared_pilots else "per-trial (B per trial)", "parallelism": "trials sharded, dp%d" % world},
-            "mean_nmse": mean_nmse, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "mean_nmse": mean_nmse, "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "host_path": host,
         }
         line.update(extra)
     emit(line if rank == 0 else None, dist, rank)
