@@ -326,6 +326,23 @@ int jstsp_mc_admm_c64(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c64
 int jstsp_vamp_c64(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c64 *y, const jstsp_c64 *A,
                    long long strideA, double sigma, double L, int nit, jstsp_c64 *x_out, int memspace);
 
+/* plot_errorVSsnr.m:83 (pinv(A)*Y*pinv(B)), pinv, the joint OMP of :116-117, the drivers' vamp call :79-80,100, the NMSE
+ * of :138-141 and the rate of plot_rateVSframelength.m:81 - arguments as in their _c32 forms */
+int jstsp_ls_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c64 *Y,
+                 const jstsp_c64 *A, long long strideA, const jstsp_c64 *B, long long strideB,
+                 jstsp_c64 *S_out, int memspace);
+int jstsp_pinv_c64(jstsp_ctx *ctx, int rows, int cols, int batch, const jstsp_c64 *A, jstsp_c64 *P, int memspace);
+int jstsp_mmv_omp_c64(jstsp_ctx *ctx, int N, int Gr, int S, int batch, const jstsp_c64 *A, long long strideA,
+                      const jstsp_c64 *Y, int K, int pnorm, jstsp_c64 *Z_out, int32_t *index_out,
+                      int32_t *count_out, int memspace);
+int jstsp_vamp_kron_c64(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const jstsp_c64 *Y,
+                        const jstsp_c64 *Af, long long strideA, const jstsp_c64 *Gb, long long strideG,
+                        double sigma, double L, int nit, jstsp_c64 *X_out, int memspace);
+int jstsp_nmse_spectral_c64(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c64 *S,
+                            const jstsp_c64 *Zbar, double *nmse, int memspace);
+int jstsp_rate_c64(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c64 *S, const jstsp_c64 *Zbar,
+                   double noise_var, double *rate, int memspace);
+
 /* Per-kernel timing of the last proposed_algorithm call made with profiling enabled:
  * jstsp_set_profiling(ctx, 1) brackets every launch of the dominant kernel with HIP
  * events on the context's stream; jstsp_get_profile() returns launches and total ms. */

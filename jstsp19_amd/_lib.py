@@ -82,7 +82,8 @@ SIGNATURES = {
 }
 
 
-for _n in ("correlate", "synthesize", "proposed_algorithm", "svt", "omp", "sparse_admm", "mc_svt", "mc_admm", "vamp"):
+for _n in ("correlate", "synthesize", "proposed_algorithm", "svt", "omp", "sparse_admm", "mc_svt", "mc_admm", "vamp", "ls", "pinv",
+           "mmv_omp", "vamp_kron", "nmse_spectral", "rate"):
     # the double-complex forms take the same argument lists (pointers are void* here)
     SIGNATURES["jstsp_%s_c64" % _n] = SIGNATURES["jstsp_%s_c32" % _n]
 

@@ -282,4 +282,85 @@ int jstsp_vamp_c64(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c64 *y, 
     return cv.finish();
 }
 
+int jstsp_ls_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c64 *Y, const jstsp_c64 *A,
+                 long long strideA, const jstsp_c64 *B, long long strideB, jstsp_c64 *S_out, int memspace)
+{
+    C64_BEGIN(N > 0 && M > 0 && Gr > 0 && G2 > 0 && batch > 0 && strideA >= 0 && strideB >= 0, "ls");
+    JSTSP_REQUIRE(Y && A && B && S_out, JSTSP_E_NULL, "ls: NULL argument");
+    const jstsp_c32 *y = cv.in(Y, (size_t)N * M * batch), *a = cv.in_dict(A, (size_t)N * Gr, strideA, batch),
+                    *b = cv.in_dict(B, (size_t)G2 * M, strideB, batch);
+    jstsp_c32 *s = cv.out(S_out, (size_t)Gr * G2 * batch);
+    JSTSP_TRY(cv.rc);
+    JSTSP_TRY(jstsp_ls_c32(ctx, N, M, Gr, G2, batch, y, a, strideA, b, strideB, s, JSTSP_DEVICE));
+    JSTSP_TRY(cv.finish());
+    if (memspace == JSTSP_HOST) JSTSP_TRY(diag_check_host(ctx, "ls"));
+    return 0;
+}
+
+int jstsp_pinv_c64(jstsp_ctx *ctx, int rows, int cols, int batch, const jstsp_c64 *A, jstsp_c64 *P, int memspace)
+{
+    C64_BEGIN(rows > 0 && cols > 0 && batch > 0, "pinv");
+    JSTSP_REQUIRE(A && P, JSTSP_E_NULL, "pinv: NULL argument");
+    const size_t n = (size_t)rows * cols * batch;
+    const jstsp_c32 *a = cv.in(A, n);
+    jstsp_c32 *p = cv.out(P, n);
+    JSTSP_TRY(cv.rc);
+    JSTSP_TRY(jstsp_pinv_c32(ctx, rows, cols, batch, a, p, JSTSP_DEVICE));
+    return cv.finish();
+}
+
+int jstsp_mmv_omp_c64(jstsp_ctx *ctx, int N, int Gr, int S, int batch, const jstsp_c64 *A, long long strideA,
+                      const jstsp_c64 *Y, int K, int pnorm, jstsp_c64 *Z_out, int32_t *index_out, int32_t *count_out,
+                      int memspace)
+{
+    C64_BEGIN(N > 0 && Gr > 0 && S > 0 && batch > 0 && K > 0 && strideA >= 0, "mmv_omp");
+    JSTSP_REQUIRE(A && Y && Z_out, JSTSP_E_NULL, "mmv_omp: NULL argument");
+    const jstsp_c32 *a = cv.in_dict(A, (size_t)N * Gr, strideA, batch), *y = cv.in(Y, (size_t)N * S * batch);
+    jstsp_c32 *z = cv.out(Z_out, (size_t)Gr * S * batch);
+    int32_t *ix = cv.out_raw(index_out, (size_t)K * batch), *cn = cv.out_raw(count_out, (size_t)batch);
+    JSTSP_TRY(cv.rc);
+    JSTSP_TRY(jstsp_mmv_omp_c32(ctx, N, Gr, S, batch, a, strideA, y, K, pnorm, z, ix, cn, JSTSP_DEVICE));
+    return cv.finish();
+}
+
+int jstsp_vamp_kron_c64(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const jstsp_c64 *Y, const jstsp_c64 *Af,
+                        long long strideA, const jstsp_c64 *Gb, long long strideG, double sigma, double L, int nit,
+                        jstsp_c64 *X_out, int memspace)
+{
+    C64_BEGIN(Na > 0 && Gr > 0 && G2 > 0 && batch > 0 && strideA >= 0 && strideG >= 0, "vamp_kron");
+    JSTSP_REQUIRE(Y && Af && Gb && X_out, JSTSP_E_NULL, "vamp_kron: NULL argument");
+    const jstsp_c32 *y = cv.in(Y, (size_t)Na * G2 * batch), *a = cv.in_dict(Af, (size_t)Na * Gr, strideA, batch),
+                    *g = cv.in_dict(Gb, (size_t)G2 * G2, strideG, batch);
+    jstsp_c32 *x = cv.out(X_out, (size_t)Gr * G2 * batch);
+    JSTSP_TRY(cv.rc);
+    JSTSP_TRY(jstsp_vamp_kron_c32(ctx, Na, Gr, G2, batch, y, a, strideA, g, strideG, sigma, L, nit, x, JSTSP_DEVICE));
+    return cv.finish();
+}
+
+int jstsp_nmse_spectral_c64(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c64 *S, const jstsp_c64 *Zbar,
+                            double *nmse, int memspace)
+{
+    C64_BEGIN(R > 0 && C > 0 && batch > 0, "nmse_spectral");
+    JSTSP_REQUIRE(S && Zbar && nmse, JSTSP_E_NULL, "nmse_spectral: NULL argument");
+    const size_t n = (size_t)R * C * batch;
+    const jstsp_c32 *s = cv.in(S, n), *z = cv.in(Zbar, n);
+    double *o = cv.out_raw(nmse, (size_t)batch);
+    JSTSP_TRY(cv.rc);
+    JSTSP_TRY(jstsp_nmse_spectral_c32(ctx, R, C, batch, s, z, o, JSTSP_DEVICE));
+    return cv.finish();
+}
+
+int jstsp_rate_c64(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c64 *S, const jstsp_c64 *Zbar, double noise_var,
+                   double *rate, int memspace)
+{
+    C64_BEGIN(R > 0 && C > 0 && batch > 0, "rate");
+    JSTSP_REQUIRE(S && Zbar && rate, JSTSP_E_NULL, "rate: NULL argument");
+    const size_t n = (size_t)R * C * batch;
+    const jstsp_c32 *s = cv.in(S, n), *z = cv.in(Zbar, n);
+    double *o = cv.out_raw(rate, (size_t)batch);
+    JSTSP_TRY(cv.rc);
+    JSTSP_TRY(jstsp_rate_c32(ctx, R, C, batch, s, z, noise_var, o, JSTSP_DEVICE));
+    return cv.finish();
+}
+
 }  // extern "C"

@@ -86,10 +86,11 @@ def test_cfg5_vamp_kron_first_iterations_against_the_oracle():
     Lnz = 100
     A_h = A.cpu().numpy().astype(np.complex128)
     Gb_h, Ym_h = _np(Gb, 0), _np(Ym, 0)
-    for nit, tol in ((1, 1e-4), (3, 1e-3)):
+    for nit, tol in ((2, 1e-4), (4, 2e-3)):          # (the first iteration's estimate is the denoiser of r1 = 0: all zero)
         X = J.vamp_kron(Ym[:1], A, Gb[:1], 1.0, Lnz, nit=nit)
         torch.cuda.synchronize()
         Xo = OV.vamp_kron(Ym_h, A_h, Gb_h, 1.0, Lnz, nit=nit)
+        assert np.max(np.abs(Xo)) > 0
         assert np.max(np.abs(_np(X, 0) - Xo)) / np.max(np.abs(Xo)) < tol, "nit = %d" % nit
     X = J.vamp_kron(Ym, A, Gb, 1.0, Lnz, nit=100)
     torch.cuda.synchronize()

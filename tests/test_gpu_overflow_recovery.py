@@ -71,8 +71,10 @@ def test_one_trial_whose_k_jumps_is_re_solved_alone_and_matches_the_oracle():
         Om[bad, r, c] = -2.0 * rho + 1e-3
     (S1, Y1, c1), n1 = _solve(inp, 12, Omega=Om)
     assert n1 == 1                                                           # that trial, and only that trial
-    assert np.all(np.isfinite(S1)) and np.all(np.isfinite(Y1)) and np.all(np.isfinite(c1[:, 1:, :]))
+    assert np.all(np.isfinite(S1)) and np.all(np.isfinite(Y1))
     (S0, Y0, c0), _ = _solve(inp, 12, {"JSTSP_FUSED": "0"}, Omega=Om)
+    assert np.array_equal(np.isfinite(c1), np.isfinite(c0)), np.argwhere(np.isfinite(c1) != np.isfinite(c0))[:8].tolist()
+    assert np.all(np.isfinite(c0[:, 1:, :2])), np.argwhere(~np.isfinite(c0))[:8].tolist()
     assert _rel(S1[bad], S0[bad]) < 1e-6 and _rel(Y1[bad], Y0[bad]) < 1e-6
     for t in range(6):
         assert _rel(S1[t], S0[t]) < 1e-5
