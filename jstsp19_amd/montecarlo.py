@@ -192,7 +192,8 @@ def _merge_cap(p, batch, with_hbf):
 
 
 def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=None, solve_fn=None, dist=None,
-               baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None, merge=True, vamp_max_order=128):
+               baselines=False, numOfnz=100, builder=None, metric="nmse", tssr=None, merge=True, vamp_max_order=128,
+               samples=None):
     """Mean capped NMSE per sweep point; columns (proposed_algorithm, proposed_algorithm_angles[, LS, VAMP, MMV-OMP
     [, TSSR]]).  ``metric="rate"``: the rate of plot_rateVSframelength.m:81 instead of the NMSE (HIP solvers only).
     ``tssr=(Imax_svt, rho_svt)`` adds the commented recipes of plot_errorVSsnr.m:151-162 as columns six and seven: TSSR
@@ -205,6 +206,8 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
     ``builder``: "hip" — inputs from the library's own kernels (``jstsp_build_trials_c32``; the default with
     the HIP solvers) or "torch" — the tensor-op builder (the default with a custom ``solve_fn``, runs on CPU too).
     The two use different generators, so their curves agree statistically, not sample by sample.
+    ``samples``: a list that receives, per sweep point, a float64 tensor (trials of THIS rank, ncol) of the per-trial values
+    before averaging (what plot_errorVSsnr.m:138-141 computes per realisation) - for distributional checks.
     Returns a float64 tensor (len(points), ncol) identical on every rank.
     """
     rank = dist.get_rank() if dist is not None else 0
@@ -262,6 +265,10 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
             for col, v in enumerate(cols):
                 acc[pt, col] += float(v[o:o + cnt].sum())
             acc[pt, ncol] += cnt
+            if samples is not None:
+                while len(samples) < n_pts:
+                    samples.append(torch.zeros((0, ncol), dtype=torch.float64))
+                samples[pt] = torch.cat([samples[pt], torch.stack([v[o:o + cnt] for v in cols], dim=1)], 0)
             o += cnt
     if dist is not None:
         buf = acc.to(device) if dist.get_backend() == "nccl" else acc
