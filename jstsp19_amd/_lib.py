@@ -89,7 +89,14 @@ for _n in ("correlate", "synthesize", "proposed_algorithm", "svt", "omp", "spars
 
 
 class JstspError(RuntimeError):
-    pass
+    """A failed C-ABI call; ``code`` is its status (< 0: JSTSP_E_*, > 0: hipError_t), None when raised on the Python side."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+E_UNSUPPORTED, E_ILLCOND = -3, -6          # include/jstsp.h
 
 
 _lib = None
@@ -124,7 +131,7 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().jstsp_last_error().decode("utf-8", "replace")
-        raise JstspError("%s failed with code %d: %s" % (what or "jstsp call", rc, msg))
+        raise JstspError("%s failed with code %d: %s" % (what or "jstsp call", rc, msg), rc)
 
 
 class Context:

@@ -108,41 +108,78 @@ def _score(S, zb, metric, noise_var):
     return J.nmse_spectral(S, zb) if metric == "nmse" else J.rate(S, zb, noise_var)
 
 
+def _eye(n, like):
+    from .solvers import colmajor
+    return colmajor(torch.eye(n, dtype=torch.complex64, device=like.device))
+
+
+def _times_h(Y, B):
+    """``Y*B'`` (plot_errorVSsnr.m:80; also ``B*B'`` of :79 with Y = B) on the library's correlation kernel:
+    ``jstsp_correlate_c32`` computes ``A'*K*B'``, here with A = I."""
+    from . import solvers as J
+    return J.correlate(Y, _eye(Y.shape[-2], Y), B)
+
+
+def _times(A, S, P):
+    """``A*S*P`` (``Y*pinv(B)`` of plot_errorVSsnr.m:117 with A = I; ``A*S_ls``; ``A'*Y*pinv(B)`` of plot_errorVSzy.m:73) on the
+    library's synthesis kernel (``jstsp_synthesize_c32``).  ``A`` None = identity."""
+    from . import solvers as J
+    return J.synthesize(S, _eye(S.shape[-2], S) if A is None else A, P)
+
+
 def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None, vamp_max_order=128):
     """LS, VAMP and MMV-OMP baselines of plot_errorVSsnr.m:73-121 on the conventional-HBF measurement; with
-    ``tssr = (Imax, rho)`` also the commented TSSR recipe (:151,158-162) on the proposed scheme's measurement."""
+    ``tssr = (Imax, rho)`` also the commented TSSR recipe (:151,158-162) on the proposed scheme's measurement.
+    Every product goes through the library (correlate / synthesize entry points), nothing through torch matmuls.
+
+    LS of a factor too large for the float64 pinv kernel takes the fp32 Gram-inverse route, whose accuracy is
+    ``6e-8 * cond(B B')``; the library records the conditioning on the device (``jstsp_last_conditioning``).  Where that
+    record says the digits are not there (``lambda_min/lambda_max < 1e-6`` or a Newton-Schulz residual >= 1e-2) the LS
+    column - and the MMV-OMP column when it had to be built from that LS estimate - is NaN instead of a wrong number."""
+    from . import _lib
     from . import solvers as J
     zb = J.colmajor(inp["Zbar"].to(torch.complex64))
-    S_ls = J.ls_estimate(inp["Y_hbf"], inp["A_hbf"], inp["B_hbf"])                       # :83
-    out = {"ls": _score(S_ls, zb, metric, noise_var)}
-    G2 = inp["B_hbf"].shape[1]
+    ctx = _lib.default_context(inp["Y_hbf"].device.index or 0)
+    nan = lambda: torch.full((inp["Y_hbf"].shape[0],), float("nan"), dtype=torch.float64)
     Bh = inp["B_hbf"]
-    if G2 <= vamp_max_order and inp["A_hbf"].shape[0] <= 128:       # (orders above 128: one rocSOLVER decomposition per trial)
-        Gb = J.colmajor(Bh @ Bh.conj().transpose(1, 2))                                  # (B*B')  :79
-        Ym = J.colmajor(inp["Y_hbf"] @ Bh.conj().transpose(1, 2))                        # Y_hbf*B' :80
-        out["vamp"] = _score(J.vamp_kron(Ym, inp["A_hbf"], Gb, 1.0, numOfnz), zb, metric, noise_var)   # :100
+    G2 = Bh.shape[1]
     try:
-        PB = J.pinv(Bh)                                                                  # pinv(B)  :117
-    except J.JstspError:
-        PB = None                                                                        # factor too large for the pinv kernel
+        PB = J.pinv(Bh)                                                                  # pinv(B)  :83, :117
+    except J.JstspError as e:
+        if e.code != _lib.E_UNSUPPORTED:                                                 # (too large for the in-LDS kernel)
+            raise
+        PB = None
+    S_ls = J.ls_estimate(inp["Y_hbf"], inp["A_hbf"], Bh)                                 # :83
+    ls_ok = True
+    if PB is None:                                                                       # the Gram-inverse route ran for B
+        rcond, ns_res = ctx.last_conditioning()
+        ls_ok = rcond * rcond >= 1e-6 and ns_res < 1e-2
+    out = {"ls": _score(S_ls, zb, metric, noise_var) if ls_ok else nan()}
+    if G2 <= vamp_max_order and inp["A_hbf"].shape[0] <= 128:       # (orders above 128: one rocSOLVER decomposition per trial)
+        Gb = _times_h(Bh, Bh)                                                            # (B*B')  :79
+        Ym = _times_h(inp["Y_hbf"], Bh)                                                  # Y_hbf*B' :80
+        out["vamp"] = _score(J.vamp_kron(Ym, inp["A_hbf"], Gb, 1.0, numOfnz), zb, metric, noise_var)   # :100
     Ypb = None
     if PB is not None:
-        Ypb = J.colmajor(inp["Y_hbf"] @ PB)
-    elif inp["A_hbf"].shape[0] == inp["A_hbf"].shape[1]:
+        Ypb = _times(None, inp["Y_hbf"], PB)                                             # Y_hbf_nr*pinv(B)  :117
+    elif inp["A_hbf"].shape[0] == inp["A_hbf"].shape[1] and ls_ok:
         # B too large for the pinv kernel, A square: Y*pinv(B) = A*(pinv(A)*Y*pinv(B)) = A*S_ls (A invertible: a unitary
         # dictionary times the beamformer), with the Gram-inverse route of jstsp_ls_c32 behind S_ls
-        Ypb = J.colmajor(inp["A_hbf"].unsqueeze(0) @ S_ls)
+        Ypb = _times(inp["A_hbf"], S_ls, _eye(G2, S_ls))
     if Ypb is not None:
         Z, _, _ = J.mmv_omp(inp["A_hbf"], Ypb, numOfnz)                                  # :116-117
         out["omp_mmv"] = _score(Z, zb, metric, noise_var)
+    elif not ls_ok:
+        out["omp_mmv"] = nan()
     if tssr is not None:
         try:
             St, _, Ssvt = J.tssr(inp["subY"], inp["Omega"], inp["A"], inp["B"], tssr[0], inp["tau_Y"].numpy(), tssr[1],
                                  2 * numOfnz)                                            # :151,:160-161
             out["tssr"] = _score(St, zb, metric, noise_var)
             out["svt"] = _score(Ssvt, zb, metric, noise_var)                             # :152-153
-        except J.JstspError:
-            pass
+        except J.JstspError as e:
+            if e.code != _lib.E_UNSUPPORTED:
+                raise
     return out
 
 
@@ -425,7 +462,7 @@ def run_zy(points=None, n_trials=1, *, Imax=50, batch=32, seed=20190913, device=
         S, Y, _ = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax_, inp["tau_Y"].numpy(),
                                        inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate", want_ce=False)   # :66
         zb = J.colmajor(inp["Zbar"].to(torch.complex64))
-        Sy = J.colmajor(inp["A"].conj().transpose(-1, -2) @ Y @ J.pinv(inp["B"]))                                 # :73
+        Sy = _times(J.colmajor(inp["A"].conj().transpose(-1, -2).contiguous()), Y, J.pinv(inp["B"]))             # :73
         return J.nmse_spectral(S, zb), J.nmse_spectral(Sy, zb)
 
     fn = hip if solve_fn is None else solve_fn

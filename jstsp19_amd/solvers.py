@@ -312,13 +312,15 @@ def tssr(Y_prop, Omega, A, B, Imax, tau, rho, K, *, norm="l2", ctx=None):
     ``S_svt = pinv(A)*Y_svt*pinv(B)`` the "SVT-based" estimate of :151-152."""
     Y_svt = mc_svt(Y_prop, Omega, Imax, tau, rho, ctx=ctx)
     PB = pinv(B, ctx=ctx)
-    PA = pinv(A, ctx=ctx)
+    # Y_svt*pinv(B) and pinv(A)*(...): both on the library's synthesis kernel (A*S*B with one factor the identity)
+    n = Y_svt.shape[-2]
     if _is_torch(Y_svt):
-        T = colmajor(Y_svt @ PB)
-        S_svt = colmajor(PA @ T)
+        import torch
+        eye = colmajor(torch.eye(n, dtype=torch.complex64, device=Y_svt.device))
     else:
-        T = Y_svt @ PB
-        S_svt = PA @ T
+        eye = np.eye(n, dtype=np.complex64)
+    T = synthesize(Y_svt, eye, PB, ctx=ctx)
+    S_svt = ls_estimate(Y_svt, A, B, ctx=ctx)             # pinv(A)*Y_svt*pinv(B)  (:151)
     Z, _, _ = mmv_omp(A, T, K, norm=norm, ctx=ctx)
     return Z, Y_svt, S_svt
 
