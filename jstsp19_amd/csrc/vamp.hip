@@ -56,7 +56,9 @@ __device__ __forceinline__ void bg_denoise(double r, double rvar, double var0, d
 __device__ __forceinline__ double clipg(double g) { return fmin(fmax(g, 1e-8), 1e14); }   // VampGlmOpt.m:7-8
 
 // First half of an iteration (VampGlmEst.m:354-398): one workgroup per problem.
-__global__ __launch_bounds__(256) void vamp_first_half_kernel(int Nc, int Mc, int Na, int G2, int it, double damp,
+// Dc, Da: number of entries of d and the order of its A-side factor - (Mc, Na) with d = eig(A A') for M <= N (:402-406),
+// (Nc, Gr) with d = eig(A'A) for M > N (:407-411; vamp.m passes no opt.V, so VampGlmEst.m:196-218 recomputes V and d)
+__global__ __launch_bounds__(256) void vamp_first_half_kernel(int Nc, int Mc, int Dc, int Da, int G2, int it, double damp,
                                                               double sigma, double Lnz, const float2 *y,
                                                               const float2 *r1, const float2 *p1, float2 *x1,
                                                               float2 *r2, float2 *p2, const float *lamA,
@@ -106,13 +108,14 @@ __global__ __launch_bounds__(256) void vamp_first_half_kernel(int Nc, int Mc, in
     // ---- q = 1/(d + gam2x/gam2z), alf = (1/N) d'q - eps (:397-398); d_ij = sa_i^2 lb_j^2, each counted twice
     const double ratio = gam2x / gam2z;
     double acc = 0;
-    for (int e = tid; e < Mc; e += 256) {
-        const int i = e % Na, j = e / Na;
+    const long long bd = (long long)t * Dc;
+    for (int e = tid; e < Dc; e += 256) {
+        const int i = e % Da, j = e / Da;
         const double lb = lamB[(long long)t * sLb + j];
         const double d = fmax((double)lamA[(long long)t * sLa + i], 0.0) * lb * lb;
         const double qq = 1.0 / (d + ratio);
-        q[bm + e] = (float)qq;
-        dq[bm + e] = (float)(d * qq);
+        q[bd + e] = (float)qq;
+        dq[bd + e] = (float)(d * qq);
         acc += d * qq;
     }
     acc = bsum(acc, sh);
@@ -132,6 +135,20 @@ __global__ __launch_bounds__(256) void vamp_scale_kernel(long long n, const floa
         const float2 v = Tm[i];
         tq[i] = make_float2(v.x * q[i], v.y * q[i]);
         tdq[i] = make_float2(v.x * dq[i], v.y * dq[i]);
+    }
+}
+
+// W += (gam2x / gam2z) r2   (the argument of V' in VampGlmEst.m:408; the ratio is a per-problem device scalar)
+__global__ __launch_bounds__(256) void vamp_add_ratio_kernel(int Nc, float2 *W, const float2 *r2, const VampScal *sc)
+{
+    const int t = blockIdx.y;
+    const float ratio = (float)(sc[t].gam2x / sc[t].gam2z);
+    const long long b = (long long)t * Nc;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < Nc; e += gridDim.x * 256) {
+        const float2 r = r2[b + e];
+        float2 w = W[b + e];
+        w.x += ratio * r.x; w.y += ratio * r.y;
+        W[b + e] = w;
     }
 }
 
@@ -193,6 +210,8 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
 {
     Arena &a = ctx->arena;
     const int Nc = Gr * G2, Mc = Na * G2;
+    const bool tall = Na > Gr;                     // M > N: VampGlmEst.m:407-411 with V, d from eig(A'A) (:196-218)
+    const int Da = tall ? Gr : Na, Dc = tall ? Nc : Mc;
     const int nA = sA ? batch : 1, nG = sG ? batch : 1;
     const size_t bN = (size_t)batch * Nc, bM = (size_t)batch * Mc;
     float2 *r1 = a.get<float2>(bN), *x1 = a.get<float2>(bN), *r2 = a.get<float2>(bN), *x2 = a.get<float2>(bN),
@@ -213,10 +232,11 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
     hipStream_t st = ctx->stream;
     // ---- decompositions (the `svd(B)` of vamp.m:32 in factored complex form)
     const Mat Am{Af, sA, Na}, Gm{Gb, sG, G2};
-    JSTSP_TRY(gemm(ctx, 'N', 'C', Na, Na, Gr, nA, Am, Am, AAh, (long long)Na * Na, Na));
-    JSTSP_TRY(launch_eig(ctx, EIG_VECS, Na, nA, AAh, (long long)Na * Na, 1, 0, nullptr, nullptr, Ua, lamA, Vga));
+    if (tall) JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, Na, nA, Am, Am, AAh, (long long)Gr * Gr, Gr));     // A'A = Va diag(la) Va'
+    else JSTSP_TRY(gemm(ctx, 'N', 'C', Na, Na, Gr, nA, Am, Am, AAh, (long long)Na * Na, Na));          // A A' = Ua diag(sa^2) Ua'
+    JSTSP_TRY(launch_eig(ctx, EIG_VECS, Da, nA, AAh, (long long)Da * Da, 1, 0, nullptr, nullptr, Ua, lamA, Vga));
     JSTSP_TRY(launch_eig(ctx, EIG_VECS, G2, nG, Gb, sG, 1, 0, nullptr, nullptr, Ub, lamB, Vgb));
-    const Mat Uam{Ua, sA ? (long long)Na * Na : 0, Na}, Ubm{Ub, sG ? (long long)G2 * G2 : 0, G2};
+    const Mat Uam{Ua, sA ? (long long)Da * Da : 0, Da}, Ubm{Ub, sG ? (long long)G2 * G2 : 0, G2};
     JSTSP_HIP(hipMemsetAsync(r1, 0, bN * sizeof(float2), st));            // r1init = eps*1i ~ 0 (vamp.m:45)
     JSTSP_HIP(hipMemsetAsync(p1, 0, bM * sizeof(float2), st));            // VampGlmEst.m:331
     JSTSP_HIP(hipMemsetAsync(x1, 0, bN * sizeof(float2), st));
@@ -224,8 +244,26 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
     hipLaunchKernelGGL(vamp_init_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, sc);
     const long long sN = Nc, sM = Mc;
     for (int it = 0; it < nit; ++it) {
-        hipLaunchKernelGGL(vamp_first_half_kernel, dim3(batch), dim3(256), 0, st, Nc, Mc, Na, G2, it, damp, sigma, Lnz, Y,
-                           r1, p1, x1, r2, p2, lamA, sA ? (long long)Na : 0, lamB, sG ? (long long)G2 : 0, q, dq, sc);
+        hipLaunchKernelGGL(vamp_first_half_kernel, dim3(batch), dim3(256), 0, st, Nc, Mc, Dc, Da, G2, it, damp, sigma, Lnz, Y,
+                           r1, p1, x1, r2, p2, lamA, sA ? (long long)Da : 0, lamB, sG ? (long long)G2 : 0, q, dq, sc);
+        if (tall) {
+            // Vr2Ap2 = V'(r2 gam2x/gam2z + A'p2);  x2 = V(Vr2Ap2 .* q);  z2 = A x2                 (:408-410)
+            // with Phi^H vec(Z) = vec(Af^H Z Gb),  V^H vec(X) = vec(Va^H X Ub),  V vec(T) = vec(Va T Ub^H)
+            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, Na, batch, Am, Mat{p2, sM, Na}, u3, sN, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{u3, sN, Gr}, Gm, x2, sN, Gr));
+            hipLaunchKernelGGL(vamp_add_ratio_kernel, dim3((unsigned)std::min(64, (Nc + 255) / 256), batch), dim3(256), 0, st, Nc,
+                               x2, r2, sc);
+            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, Gr, batch, Uam, Mat{x2, sN, Gr}, u3, sN, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{u3, sN, Gr}, Ubm, x2, sN, Gr));
+            hipLaunchKernelGGL(vamp_scale_kernel, gsz((long long)bN), dim3(256), 0, st, (long long)bN, x2, q, dq, u3, tdq);
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, Uam, Mat{u3, sN, Gr}, T2, sN, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'C', Gr, G2, G2, batch, Mat{T2, sN, Gr}, Ubm, x2, sN, Gr));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, Gr, batch, Am, Mat{x2, sN, Gr}, T1, sM, Na));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, G2, batch, Mat{T1, sM, Na}, Gm, z2, sM, Na));
+            hipLaunchKernelGGL(vamp_second_half_kernel, dim3(batch), dim3(256), 0, st, Nc, Mc, it, damp, x2, r2, z2, z2o, p2,
+                               r1, p1, sc);
+            continue;
+        }
         // Ar2 = Af R2 Gb                                                              (:400)
         JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, Gr, batch, Am, Mat{r2, sN, Gr}, T1, sM, Na));
         JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, G2, batch, Mat{T1, sM, Na}, Gm, Ar2, sM, Na));
@@ -275,10 +313,9 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
     JSTSP_REQUIRE(Y_ && Af_ && Gb_ && X_out, JSTSP_E_NULL, "vamp_kron: NULL array argument");
     JSTSP_REQUIRE(Na > 0 && Gr > 0 && G2 > 0 && batch > 0 && nit >= 1, JSTSP_E_SHAPE, "vamp_kron: bad shape");
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
-    JSTSP_REQUIRE(Na <= 128 && G2 <= 8192, JSTSP_E_UNSUPPORTED,
-                  "vamp_kron: Na = %d, G2 = %d: the factor eigenproblems are limited to orders 128 and 8192", Na, G2);
-    JSTSP_REQUIRE(Na <= Gr, JSTSP_E_UNSUPPORTED,
-                  "vamp: only the M <= N branch of VampGlmEst.m:399-403 is implemented (Na = %d > Gr = %d)", Na, Gr);
+    JSTSP_REQUIRE(std::min(Na, Gr) <= 128 && G2 <= 8192, JSTSP_E_UNSUPPORTED,
+                  "vamp_kron: min(Na, Gr) = %d, G2 = %d: the factor eigenproblems are limited to orders 128 and 8192",
+                  std::min(Na, Gr), G2);
     JSTSP_REQUIRE(sigma > 0 && Lnz > 0 && Lnz < 2.0 * Gr * G2, JSTSP_E_ARG, "vamp: need sigma > 0 and 0 < L < nx");
     JSTSP_ENTER(ctx);
     const int nA = strideA ? batch : 1, nG = strideG ? batch : 1;

@@ -162,6 +162,29 @@ def gen_vamp():
     save("vamp", A=A, B=B, Gb=Gb, Y=Ym, Phi=Phi, y=y, sigma=1.0, L=12, x=x_lit, Zbar=Zbar)
 
 
+def gen_vamp_tall():
+    """The M > N branch of VampGlmEst.m:407-411 (V, d from eig(A'A), :196-218): a dense 30 x 12 dictionary and a Kronecker one
+    with Na = 10 > Gr = 4.  Outputs of the LITERAL restatement (real-stacked matrix) per iteration count."""
+    from . import vamp as V
+    rng = np.random.default_rng(17)
+    r = lambda *sh: rng.standard_normal(sh) + 1j * rng.standard_normal(sh)
+    M, N = 30, 12
+    A = r(M, N) / np.sqrt(M)
+    x0 = np.zeros(N, complex); x0[[2, 7, 9]] = [2, -1j, 1 + 1j]
+    y = A @ x0 + 0.05 * r(M)
+    Na, Gr, G2 = 10, 4, 5
+    Af = r(Na, Gr) / 3
+    Bh = r(G2, 9) / 3
+    Gb = Bh @ Bh.conj().T
+    X0 = np.zeros((Gr, G2), complex); X0[1, 2] = 2; X0[3, 0] = -1.5j
+    Y = Af @ X0 @ Gb + 0.02 * r(Na, G2)
+    Phi = np.kron(Gb.T, Af)
+    nits = (2, 5, 12)
+    xd = np.stack([V.vamp_literal(y, A, 1.0, 3, nit=n) for n in nits])
+    xk = np.stack([V.vamp_literal(S.vec(Y), Phi, 1.0, 4, nit=n).reshape(Gr, G2, order="F") for n in nits])
+    save("vamp_tall", A=A, y=y, L=3, Af=Af, Gb=Gb, Y=Y, Lk=4, sigma=1.0, nits=np.array(nits), x_dense=xd, x_kron=xk)
+
+
 def gen_baselines2():
     """Joint OMP (published simultaneous OMP: sparse-plex is un-vendored, parity unpinned), pinv / LS with an
     ill-conditioned square pilot factor (plot_errorVSsnr.m:83), the TSSR / SVT-based recipes (:151-162) and the rate of
@@ -204,6 +227,7 @@ def main():
     gen_sparse_admm()
     gen_mc()
     gen_vamp()
+    gen_vamp_tall()
     gen_baselines2()
     if "--fast" not in sys.argv:
         # reference-native shape (N=32, M=140, Gr=32, G2=16): dense K1 is 4480^2, K2 4480x512

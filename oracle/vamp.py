@@ -75,6 +75,10 @@ def vamp_literal(y, A, sigma, L, nit=100, damp=0.85, trace=None):
     U, s, _ = np.linalg.svd(B)                                       # :32
     d = np.concatenate([s ** 2, np.zeros(MM - s.size)])              # :34
     M, N = MM, nx
+    if M > N:
+        # vamp.m sets opt.U and opt.d but never opt.V, so for M > N VampGlmEst recomputes BOTH from the
+        # eigen-decomposition of A'*A (VampGlmEst.m:196-218: `isempty(opt.V)` -> `[V,D] = eig(AhA); d = diag(D)`)
+        d, V = np.linalg.eigh(B.T @ B)
     dl = M / N                                                       # VampGlmEst.m:257
     r1 = EPS * 1j                                                    # vamp.m:45 (complex scalar, broadcasts)
     p1 = np.zeros(M)                                                 # VampGlmEst.m:331
@@ -105,8 +109,10 @@ def vamp_literal(y, A, sigma, L, nit=100, damp=0.85, trace=None):
             t = (U.T @ (p2 - Ar2)) * q
             x2 = r2 + B.T @ (U @ t)
             z2 = Ar2 + U @ (d * t)
-        else:                                                        # :404-408 (needs V; not reached by the drivers)
-            raise NotImplementedError("M > N branch is not exercised by any driver of the reference")
+        else:                                                        # :407-411 (not reached by any driver of the reference)
+            t = V.T @ (r2 * (gam2x / gam2z) + B.T @ p2)
+            x2 = V @ (t * q)
+            z2 = B @ x2
         if i > 1:
             z2 = damp * z2 + (1 - damp) * z2old                      # :411-413
         r1 = (x2 - r2 * (1 - alf)) / alf                             # :464
@@ -129,6 +135,10 @@ def vamp_dense(y, A, sigma, L, nit=100, damp=0.85):
     A = np.asarray(A, dtype=np.complex128)
     y = np.asarray(y, dtype=np.complex128).reshape(-1)
     Mc, Nc = A.shape
+    if Mc > Nc:                                                      # VampGlmEst.m:196-218,407-411: eig(A'A) = V diag(d) V'
+        d, V = np.linalg.eigh(A.conj().T @ A)
+        return _vamp_complex(y, lambda x: A @ x, lambda z: A.conj().T @ z, lambda t: V @ t, lambda x: V.conj().T @ x,
+                             d, Mc, Nc, sigma, L, nit, damp)
     U, s, _ = np.linalg.svd(A, full_matrices=True)
     d = np.concatenate([s ** 2, np.zeros(Mc - s.size)])              # per complex row (each counted twice below)
     return _vamp_complex(y, lambda x: A @ x, lambda z: A.conj().T @ z, lambda z: U @ z, lambda z: U.conj().T @ z,
@@ -149,8 +159,20 @@ def vamp_kron(Y, Af, Gb, sigma, L, nit=100, damp=0.85):
     Y = np.asarray(Y, dtype=np.complex128)
     Na, Gr = Af.shape
     G2 = Gb.shape[0]
-    Ua, sa, _ = np.linalg.svd(Af, full_matrices=True)               # Na x Na
     lb, Ub = np.linalg.eigh((Gb + Gb.conj().T) / 2)                 # Gb = Ub diag(lb) Ub^H
+    if Na > Gr:
+        # M > N (VampGlmEst.m:196-218,407-411): Phi'Phi = (conj(Ub) (x) Va) (lb^2 (x) la) (conj(Ub) (x) Va)^H with
+        # Af'Af = Va diag(la) Va^H;  V vec(T) = vec(Va T Ub^H),  V^H vec(X) = vec(Va^H X Ub)
+        la, Va = np.linalg.eigh(Af.conj().T @ Af)
+        Dt = np.outer(la, lb ** 2)                                   # Gr x G2
+        fAt = lambda Xv: (Af @ Xv.reshape(Gr, G2, order="F") @ Gb).reshape(-1, order="F")
+        fAht = lambda Zv: (Af.conj().T @ Zv.reshape(Na, G2, order="F") @ Gb.conj().T).reshape(-1, order="F")
+        fV = lambda Tv: (Va @ Tv.reshape(Gr, G2, order="F") @ Ub.conj().T).reshape(-1, order="F")
+        fVh = lambda Xv: (Va.conj().T @ Xv.reshape(Gr, G2, order="F") @ Ub).reshape(-1, order="F")
+        x = _vamp_complex(Y.reshape(-1, order="F"), fAt, fAht, fV, fVh, Dt.reshape(-1, order="F"), Na * G2, Gr * G2, sigma,
+                          L, nit, damp)
+        return x.reshape(Gr, G2, order="F")
+    Ua, sa, _ = np.linalg.svd(Af, full_matrices=True)               # Na x Na
     sa_full = np.concatenate([sa, np.zeros(Na - sa.size)])
     # singular values of Phi: sa_i * |lb_j|; Phi's left vectors: Ua(:,i) (x) conj(Ub(:,j)) * sign(lb_j)
     sgn = np.where(lb < 0, -1.0, 1.0)
@@ -213,10 +235,15 @@ def _vamp_complex(y, fA, fAh, fU, fUh, d, Mc, Nc, sigma, L, nit, damp):
             gam2z = damp * gam2z + (1 - damp) * gam2zold
         q = 1.0 / (d + gam2x / gam2z)
         alf = (1 / N) * dsum_w * (d @ q) - EPS
-        Ar2 = fA(r2)
-        t = fUh(p2 - Ar2) * q
-        x2 = r2 + fAh(fU(t))
-        z2 = Ar2 + fU(d * t)
+        if Mc <= Nc:                                                 # VampGlmEst.m:402-406 (fU, fUh: U, U')
+            Ar2 = fA(r2)
+            t = fUh(p2 - Ar2) * q
+            x2 = r2 + fAh(fU(t))
+            z2 = Ar2 + fU(d * t)
+        else:                                                        # :407-411 (fU, fUh: V, V'; d: eig(A'A))
+            t = fUh(r2 * (gam2x / gam2z) + fAh(p2))
+            x2 = fU(t * q)
+            z2 = fA(x2)
         if i > 1:
             z2 = damp * z2 + (1 - damp) * z2old
         r1 = (x2 - r2 * (1 - alf)) / alf

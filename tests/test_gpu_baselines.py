@@ -181,6 +181,22 @@ def test_vamp_kron_and_dense_track_the_oracle():
     assert rel_err(Xb[1], V.vamp_kron(0.5 * g["Y"], g["A"], g["Gb"], sig, L, nit=6)) < 5e-4
 
 
+def test_vamp_m_greater_n_branch():
+    """VampGlmEst.m:407-411 (M > N; V and d from eig(A'A) as :196-218 recompute them): dense 30 x 12 and Kronecker with
+    Na = 10 > Gr = 4 against the literal float64 restatement's fixture, per iteration count; batched == single."""
+    import jstsp19_amd as J
+    g = load_golden("vamp_tall")
+    sig = float(g["sigma"])
+    for k, (nit, tol) in enumerate(zip(g["nits"], (1e-5, 1e-4, 5e-3))):
+        xd = J.vamp(g["y"], g["A"], sig, int(g["L"]), nit=int(nit))
+        assert rel_err(xd, g["x_dense"][k]) < tol, (int(nit), rel_err(xd, g["x_dense"][k]))
+        xk = J.vamp_kron(g["Y"], g["Af"], g["Gb"], sig, int(g["Lk"]), nit=int(nit))
+        assert rel_err(xk, g["x_kron"][k]) < tol, (int(nit), rel_err(xk, g["x_kron"][k]))
+    Yb = np.stack([g["Y"], 0.7 * g["Y"]])
+    Xb = J.vamp_kron(Yb, g["Af"], np.stack([g["Gb"], g["Gb"]]), sig, int(g["Lk"]), nit=5)
+    assert rel_err(Xb[0], J.vamp_kron(g["Y"], g["Af"], g["Gb"], sig, int(g["Lk"]), nit=5)) < 1e-5
+
+
 def test_ls_baseline_matches_pinv():
     """S_ls = pinv(A)*Y*pinv(B) (plot_errorVSsnr.m:83)."""
     import jstsp19_amd as J

@@ -251,3 +251,17 @@ def test_oracle_reproduces_the_baselines2_fixture():
     assert np.allclose(St, g["S_tssr"], atol=1e-10) and np.allclose(Ysvt, g["Y_svt"], atol=1e-10)
     assert np.allclose(Ssvt, g["S_svt"], atol=1e-10)
     assert abs(O.rate(g["S_r"], g["Zbar_r"], float(g["noise_var"])) - float(g["rate"])) < 1e-12
+
+
+def test_vamp_m_greater_n_branch_literal_structured_and_golden():
+    """VampGlmEst.m:407-411 (M > N): vamp.m hands over opt.U / opt.d but no opt.V, so :196-218 recompute V and d from
+    eig(A'A).  The literal (real-stacked) restatement, the complex structured one and the Kronecker-factored one agree,
+    and reproduce the committed fixture."""
+    from oracle import vamp as V
+    g = load_golden("vamp_tall")
+    for k, nit in enumerate(g["nits"]):
+        lit = V.vamp_literal(g["y"], g["A"], float(g["sigma"]), int(g["L"]), nit=int(nit))
+        assert rel_err(lit, g["x_dense"][k]) < 1e-12
+        assert rel_err(V.vamp_dense(g["y"], g["A"], float(g["sigma"]), int(g["L"]), nit=int(nit)), g["x_dense"][k]) < 1e-9
+        assert rel_err(V.vamp_kron(g["Y"], g["Af"], g["Gb"], float(g["sigma"]), int(g["Lk"]), nit=int(nit)), g["x_kron"][k]) < 1e-9
+    assert np.max(np.abs(g["x_dense"][-1])) > 0.1                      # it estimates something
