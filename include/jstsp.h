@@ -256,10 +256,17 @@ typedef struct jstsp_model {
                                plot_errorVSzy.m:53) - createBeamformer.m:5 and :12-13 are the same unitary DFT matrix */
     int rho_rule;           /* JSTSP_RHO_MIN6: min(eigs(Y'*Y)) :129-130; JSTSP_RHO_MAX: max(eigs(Y'*Y))
                                (plot_errorVSdelays.m:128, plot_errorVSnrf.m:128, plot_errorVSnt.m:129, plot_errorVSpaths.m:128) */
-    double rho_scale;       /* factor on rho (0 = 1; plot_errorVSzy.m:65 halves it)                                   */
+    double rho_scale;       /* factor on rho (0 = 1; plot_errorVSzy.m:65 halves it; plot_errorVSsnr_approx.m:51-53's
+                               rho = sqrt(lambda_6 (tau_X + tau_S)/2) with tau_S = tau_X/2 is sqrt(0.75) x the :129-130 rule) */
+    int pilots;             /* JSTSP_PILOTS_QAM4: 4-QAM symbols (qam4mod.m:7-8, plot_errorVSsnr.m:63-67);
+                               JSTSP_PILOTS_GAUSS: s = 1/sqrt(2)*(randn + 1j*randn), the training of
+                               wideband_hybBF_comm_system_training.m:19-22 (the builder of plot_errorVSsnr_approx.m:46: with
+                               beamformer = JSTSP_BF_DFT (:10), Mr = round(subSamplingRatio*Nr) (:5), Mr_e = Nr, T_prop = T
+                               and rho_scale = sqrt(0.75) this call IS that function + the driver's lines :50-58) */
 } jstsp_model;
 enum { JSTSP_BF_ZC = 0, JSTSP_BF_DFT = 1 };
 enum { JSTSP_RHO_MIN6 = 0, JSTSP_RHO_MAX = 1 };
+enum { JSTSP_PILOTS_QAM4 = 0, JSTSP_PILOTS_GAUSS = 1 };
 
 /* Output arrays of jstsp_build_trials_c32 (NULL = not wanted); column-major per trial, trial index last.
  * With N = Mr_e, M = T_prop, G2 = L*Gt, Np = clusters*rays: */
@@ -280,6 +287,8 @@ typedef struct jstsp_trials {
     float *u_r, *u_t;       /* Np x batch     uniform draws of tap 1's angle samplers                         */
     jstsp_c32 *noise;       /* Nr x T_prop x batch   randn + 1j*randn, unscaled                               */
     uint8_t *qam_idx;       /* batch x Nt x T_prop (row-major), values 0..3 in the alphabet order of qam4mod.m:7 */
+    jstsp_c32 *pilot_sym;   /* batch x Nt x T_prop (row-major): the pilot symbols s (JSTSP_PILOTS_GAUSS: the draws
+                               randn + 1j*randn BEFORE the 1/sqrt(2) of ...training.m:20; QAM4: the alphabet values) */
 } jstsp_trials;
 
 int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *model, uint64_t seed, int sweep_idx,

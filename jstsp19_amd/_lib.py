@@ -15,6 +15,7 @@ HOST, DEVICE = 0, 1
 TYPE_APPROXIMATE, TYPE_STD = 0, 1
 BF_ZC, BF_DFT = 0, 1
 RHO_MIN6, RHO_MAX = 0, 1
+PILOTS_QAM4, PILOTS_GAUSS = 0, 1
 
 c_void_p, c_int, c_ll, c_dp, c_ip = C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_double), C.POINTER(C.c_int)
 
@@ -24,14 +25,15 @@ class Model(C.Structure):
     """struct jstsp_model (include/jstsp.h)."""
     _fields_ = [(n, c_int) for n in ("Nt", "Nr", "L", "T_prop", "Mr", "Mr_e", "Gr", "Gt", "clusters", "rays",
                                      "T_hbf", "shared_pilots")] + [("noise_var", C.c_double), ("beamformer", c_int),
-                                                                   ("rho_rule", c_int), ("rho_scale", C.c_double)]
+                                                                   ("rho_rule", c_int), ("rho_scale", C.c_double),
+                                                                   ("pilots", c_int)]
 
 
 class Trials(C.Structure):
     """struct jstsp_trials (include/jstsp.h): output pointers, NULL = not wanted."""
     _fields_ = [(n, c_void_p) for n in ("subY", "Omega", "A", "B", "Zbar", "H", "indx_S")] + \
                [(n, c_dp) for n in ("tau_Y", "tau_Z", "rho")] + \
-               [(n, c_void_p) for n in ("Y_hbf", "A_hbf", "B_hbf", "gains", "u_r", "u_t", "noise", "qam_idx")]
+               [(n, c_void_p) for n in ("Y_hbf", "A_hbf", "B_hbf", "gains", "u_r", "u_t", "noise", "qam_idx", "pilot_sym")]
 
 
 # name -> (restype, argtypes); mirrors include/jstsp.h one to one

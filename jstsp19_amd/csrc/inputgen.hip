@@ -20,7 +20,7 @@ using namespace jstsp;
 
 namespace {
 
-enum { ST_GAIN = 0, ST_UR = 1, ST_UT = 2, ST_NOISE = 3, ST_QAM = 4, ST_OMEGA = 5 };
+enum { ST_GAIN = 0, ST_UR = 1, ST_UT = 2, ST_NOISE = 3, ST_QAM = 4, ST_OMEGA = 5, ST_PILOT = 6 };
 
 __host__ __device__ inline uint64_t mix_key(uint64_t seed, uint64_t sweep, uint64_t trial)
 {
@@ -78,8 +78,10 @@ __global__ void draw_small_kernel(Model m, uint64_t seed, uint64_t sweep, long l
 }
 
 // noise = randn + 1j*randn (plot_errorVSsnr.m:60, unscaled) and the 4-QAM symbol indices (qam4mod.m:8)
+// gauss != 0: Gaussian pilot draws randn + 1j*randn into psym instead (wideband_hybBF_comm_system_training.m:20, before its 1/sqrt(2))
 __global__ __launch_bounds__(256) void draw_noise_qam_kernel(Model m, uint64_t seed, uint64_t sweep, long long trial0,
-                                                             float2 *noise, uint8_t *qam, int shared_pilots)
+                                                             float2 *noise, uint8_t *qam, int shared_pilots, int gauss,
+                                                             float2 *psym)
 {
     const int t = blockIdx.y;
     const uint64_t key = mix_key(seed, sweep, (uint64_t)(trial0 + t));
@@ -90,8 +92,19 @@ __global__ __launch_bounds__(256) void draw_noise_qam_kernel(Model m, uint64_t s
         const uint4 w = philox((uint64_t)i, ST_NOISE, key);
         noise[(size_t)t * nn + i] = normal2(w.x, w.y);
     }
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += stride)
-        qam[(size_t)t * nq + i] = (uint8_t)(philox((uint64_t)i, ST_QAM, qkey).x & 3u);
+    const float a = 0.70710678f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nq; i += stride) {
+        if (gauss) {
+            const uint4 w = philox((uint64_t)i, ST_PILOT, qkey);
+            psym[(size_t)t * nq + i] = normal2(w.x, w.y);
+            qam[(size_t)t * nq + i] = 0;
+        } else {
+            const uint8_t q = (uint8_t)(philox((uint64_t)i, ST_QAM, qkey).x & 3u);
+            qam[(size_t)t * nq + i] = q;
+            // alphabet order of qam4mod.m:7: (1+j), (-1+j), (1-j), (-1-j), all / sqrt(2)
+            psym[(size_t)t * nq + i] = make_float2((q & 1) ? -a : a, (q & 2) ? -a : a);
+        }
+    }
 }
 
 // Omega(:, j): ones on the Mr rows with the smallest of Mr_e uniform keys (= randperm(Mr_e)(1:Mr), proposed_hbf.m:37-40)
@@ -179,20 +192,17 @@ __global__ __launch_bounds__(256) void channel_kernel(Model m, const float2 *gai
 }
 
 // ---- pilots: Psi[t] (Nt*L x Tp), row (s + Nt*l), column j = toeplitz(s_s)(l, j): s(|j-l|), conjugated below the diagonal
-__global__ __launch_bounds__(256) void pilots_kernel(Model m, const uint8_t *qam, float2 *Psi)
+//      sym: the pilot symbols [t][s][Tp]; scale: 1 (4-QAM values) or 1/sqrt(2) (Gaussian draws, ...training.m:20)
+__global__ __launch_bounds__(256) void pilots_kernel(Model m, const float2 *sym, float scale, float2 *Psi)
 {
     const int t = blockIdx.y;
     const long long n_el = (long long)m.NtL * m.Tp;
-    const float a = 0.70710678f;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n_el; e += (long long)gridDim.x * 256) {
         const int row = (int)(e % m.NtL), j = (int)(e / m.NtL);
         const int s = row % m.Nt, l = row / m.Nt;
         const int d = j - l;
-        const int q = qam[((size_t)t * m.Nt + s) * m.Tp + (d < 0 ? -d : d)];
-        // alphabet order of qam4mod.m:7: (1+j), (-1+j), (1-j), (-1-j), all / sqrt(2)
-        float re = (q & 1) ? -a : a, im = (q & 2) ? -a : a;
-        if (d < 0) im = -im;
-        Psi[(size_t)t * n_el + e] = make_float2(re, im);
+        const float2 v = sym[((size_t)t * m.Nt + s) * m.Tp + (d < 0 ? -d : d)];
+        Psi[(size_t)t * n_el + e] = make_float2(v.x * scale, (d < 0 ? -v.y : v.y) * scale);
     }
 }
 
@@ -304,6 +314,8 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
                       (mp->rho_rule == JSTSP_RHO_MIN6 || mp->rho_rule == JSTSP_RHO_MAX) && mp->rho_scale >= 0.0,
                   JSTSP_E_ARG, "build_trials: bad beamformer / rho_rule / rho_scale");
     JSTSP_REQUIRE(mp->noise_var >= 0.0, JSTSP_E_ARG, "build_trials: negative noise variance");
+    JSTSP_REQUIRE(mp->pilots == JSTSP_PILOTS_QAM4 || mp->pilots == JSTSP_PILOTS_GAUSS, JSTSP_E_ARG, "build_trials: bad pilots kind");
+    const int gauss = mp->pilots == JSTSP_PILOTS_GAUSS;
     JSTSP_REQUIRE(mp->T_hbf >= 0 && mp->T_hbf <= m.Tp, JSTSP_E_SHAPE, "build_trials: T_hbf outside [0, T_prop]");
     m.Np = m.clusters * m.rays; m.NtL = m.Nt * m.L; m.G2 = m.L * m.Gt;
     const int N = m.Mr_e, M = m.Tp, nG = std::min(N, M), Th = mp->T_hbf;
@@ -326,7 +338,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
                                                    (const int *)nullptr, 0, 64, ctx->stream));
     size_t need = 0;
     auto acc = [&](size_t bytes) { need += rnd256(bytes); };
-    acc(b * m.L * m.Np * 8); acc(b * m.Np * 4); acc(b * m.Np * 4); acc(b * nR * 8); acc(b * nQ);       // draws
+    acc(b * m.L * m.Np * 8); acc(b * m.Np * 4); acc(b * m.Np * 4); acc(b * nR * 8); acc(b * nQ); acc(b * nQ * 8);       // draws
     acc((size_t)m.Nr * m.Gr * 8); acc((size_t)m.Nt * m.Gt * 8); acc((size_t)m.Nr * m.Nr * 8);         // Dr, Dt, W
     acc(b * nH * 8); acc(b * nPsi * 8); acc(b * nR * 8); acc(b * nY * 8); acc(b * nY * 8); acc(b * nY * 4);
     acc(nA * 8); acc(b * nB * 8); acc(b * nZ * 8); acc(b * (size_t)m.Gr * m.NtL * 8);
@@ -341,6 +353,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     float *u_r = out_or_tmp(ctx, out->u_r, b * m.Np, memspace), *u_t = out_or_tmp(ctx, out->u_t, b * m.Np, memspace);
     float2 *noise = out_or_tmp(ctx, reinterpret_cast<float2 *>(out->noise), b * nR, memspace);
     uint8_t *qam = out_or_tmp(ctx, out->qam_idx, b * nQ, memspace);
+    float2 *psym = out_or_tmp(ctx, reinterpret_cast<float2 *>(out->pilot_sym), b * nQ, memspace);
     float2 *Dr = ar.get<float2>((size_t)m.Nr * m.Gr), *Dt = ar.get<float2>((size_t)m.Nt * m.Gt),
            *W = ar.get<float2>((size_t)m.Nr * m.Nr);
     float2 *Hmat = out_or_tmp(ctx, reinterpret_cast<float2 *>(out->H), b * nH, memspace);
@@ -353,7 +366,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     float2 *T1 = ar.get<float2>(b * (size_t)m.Gr * m.NtL);
     double *hyp = ar.get<double>(b * 3);
     float *lam = ar.get<float>(b * nG);
-    JSTSP_REQUIRE(gains && u_r && u_t && noise && qam && Dr && Dt && W && Hmat && Psi && R && WR && subY && Omega &&
+    JSTSP_REQUIRE(gains && u_r && u_t && noise && qam && psym && Dr && Dt && W && Hmat && Psi && R && WR && subY && Omega &&
                       A && (B || !out->B) && Zbar && T1 && hyp && lam,
                   JSTSP_E_NOMEM, "build_trials: workspace exhausted");
     hipStream_t st = ctx->stream;
@@ -362,7 +375,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     // ---- draws ------------------------------------------------------------------------------
     draw_small_kernel<<<batch, 64, 0, st>>>(m, seed, sw, trial0, gains, u_r, u_t);
     draw_noise_qam_kernel<<<dim3(grid_for((long long)std::max(nR, nQ), 1024), batch), 256, 0, st>>>(m, seed, sw, trial0,
-                                                                                                      noise, qam, mp->shared_pilots);
+                                                                                                      noise, qam, mp->shared_pilots, gauss, psym);
     omega_kernel<<<dim3(m.Tp, batch), 256, (size_t)m.Mr_e * 4, st>>>(m, seed, sw, trial0, Omega);
     // ---- dictionaries -------------------------------------------------------------------------
     dict_kernel<<<grid_for((long long)m.Nr * m.Gr), 256, 0, st>>>(m.Nr, m.Gr, 0, Dr);
@@ -371,7 +384,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
     dict_kernel<<<grid_for((long long)m.Nr * m.Nr), 256, 0, st>>>(m.Nr, m.Nr, mp->beamformer == JSTSP_BF_ZC ? 1 : 0, W);
     // ---- channel, pilots ------------------------------------------------------------------------
     channel_kernel<<<dim3(grid_for((long long)nH, 64), batch), 256, lds_ch, st>>>(m, gains, u_r, u_t, Hmat);
-    pilots_kernel<<<dim3(grid_for((long long)nPsi, 1024), batch), 256, 0, st>>>(m, qam, Psi);
+    pilots_kernel<<<dim3(grid_for((long long)nPsi, 1024), batch), 256, 0, st>>>(m, psym, gauss ? 0.70710678f : 1.f, Psi);
     JSTSP_HIP(hipGetLastError());
     // R = [H_1..H_L] Psi + sqrt(var/2) noise                                     proposed_hbf.m:19-22
     JSTSP_TRY(gemm(ctx, 'N', 'N', m.Nr, m.Tp, m.NtL, batch, Mat{Hmat, (long long)nH, m.Nr}, Mat{Psi, (long long)nPsi, m.NtL},
@@ -445,6 +458,7 @@ extern "C" int jstsp_build_trials_c32(jstsp_ctx *ctx, const jstsp_model *mp, uin
         JSTSP_TRY(stage_out(ctx, out->u_t, u_t, b * m.Np, memspace));
         JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(out->noise), noise, b * nR, memspace));
         JSTSP_TRY(stage_out(ctx, out->qam_idx, qam, b * nQ, memspace));
+        JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(out->pilot_sym), psym, b * nQ, memspace));
         JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(out->H), Hmat, b * nH, memspace));
         JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(out->subY), subY, b * nY, memspace));
         JSTSP_TRY(stage_out(ctx, out->Omega, Omega, b * nY, memspace));

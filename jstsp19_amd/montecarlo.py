@@ -14,8 +14,8 @@ from __future__ import annotations
 
 import torch
 
-from .system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, build_trials, draw_trials,
-                           draw_trials_training)
+from .system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, build_trials,
+                           build_trials_training, draw_trials, draw_trials_training)
 
 __all__ = ["partition", "run_sweep", "run_points", "sweep_points", "run_approx_sweep", "driver", "run_driver",
            "admmiters_points", "run_convergence_curves", "zy_points", "run_zy"]
@@ -333,7 +333,7 @@ def _hip_alg12(inp, Imax):
 
 
 def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, batch=64, seed=20190913, device=None,
-                     solve_fn=None, dist=None):
+                     solve_fn=None, dist=None, builder=None):
     """The Alg.1-vs-Alg.2 sweep of plot_errorVSsnr_approx.m:34-85: for each SNR and each Imax, ``n_trials`` fresh
     realisations of wideband_hybBF_comm_system_training, both solver variants, capped NMSE of
     ``pinv(A)*Y*pinv(B)``, mean then ``min(., 1)`` (:76-77).
@@ -341,11 +341,15 @@ def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, 
     Returns a float64 tensor (len(Imax_list), len(snr_db_list), 2) — ``[..., 0]`` is mean_error_proposed,
     ``[..., 1]`` mean_error_proposed_approx — identical on every rank.  ``solve_fn(inputs, Imax) -> (e_std, e_approx)``
     defaults to the HIP path; the (sweep point, trial) pairs are sharded over ranks as in ``run_points``.
+    ``builder``: "hip" - the inputs from the library's own kernels (``jstsp_build_trials_c32`` with the training model
+    fields; the default with the HIP solvers) or "torch" - the tensor-op builder (default with a custom ``solve_fn``).
     """
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
+    if builder is None:
+        builder = "hip" if solve_fn is None else "torch"
     if solve_fn is None:
         solve_fn = _hip_alg12
     pts = [(si, ii) for si in range(len(snr_db_list)) for ii in range(len(Imax_list))]    # loop order of :34-38
@@ -358,8 +362,11 @@ def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, 
         t1 = min(n_trials, t0 + batch, t0 + (hi - item))
         si, ii = pts[pt]
         p = TrainingParams(base.Nt, base.Nr, base.L, base.T, base.ratio, base.clusters, base.rays, float(snr_db_list[si]))
-        draws = draw_trials_training(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
-        e1, e2 = solve_fn(build_inputs_training(p, draws), int(Imax_list[ii]))
+        if builder == "hip":
+            inp = build_trials_training(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device)
+        else:
+            inp = build_inputs_training(p, draw_trials_training(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device))
+        e1, e2 = solve_fn(inp, int(Imax_list[ii]))
         acc[pt, 0] += float(torch.as_tensor(e1).double().sum())
         acc[pt, 1] += float(torch.as_tensor(e2).double().sum())
         acc[pt, 2] += t1 - t0

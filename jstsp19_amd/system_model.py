@@ -18,7 +18,7 @@ import math
 import torch
 
 __all__ = ["SweepParams", "draw_trials", "build_inputs", "build_trials", "zc_beamformer", "dft_dictionary",
-           "TrainingParams", "draw_trials_training", "build_inputs_training"]
+           "TrainingParams", "draw_trials_training", "build_inputs_training", "build_trials_training"]
 
 
 class SweepParams:
@@ -306,8 +306,25 @@ def build_inputs_training(p: TrainingParams, draws, out_dtype=torch.complex64):
                 tau_X=tau_X.cpu(), tau_S=tau_S.cpu(), rho=rho.cpu())
 
 
+def build_trials_training(p: TrainingParams, trial0, batch, *, seed=20190913, sweep_idx=0, device=None, want_draws=False,
+                          want_H=False, ctx=None):
+    """wideband_hybBF_comm_system_training.m:1-58 + plot_errorVSsnr_approx.m:45-58 for trials [trial0, trial0 + batch) on
+    the HIP path: the same library call as ``build_trials`` with the model fields that make it that builder — Gaussian
+    Hermitian-Toeplitz pilots (:19-22), the unitary DFT combiner over all Nr outputs (:10), ``Lr = round(ratio*Nr)``
+    of them kept per column (:5,:48-53), the frame T itself, ``rho = sqrt(lambda_6 (tau_X + tau_S)/2)`` (:51-53).
+    Same dict as ``build_inputs_training`` (tau_X, tau_S, rho; Zbar complex64, column-major)."""
+    q = SweepParams(p.Nt, p.Nr, p.L, p.T, p.Lr, Mr_e=p.Nr, Gr=p.Gr, Gt=p.Gt, clusters=p.clusters, rays=p.rays,
+                    snr_db=p.snr_db, beamformer="fft", rho_rule="min", rho_scale=math.sqrt(0.75), T_prop=p.T)
+    o = build_trials(q, trial0, batch, seed=seed, sweep_idx=sweep_idx, device=device, want_draws=want_draws, want_H=want_H,
+                     ctx=ctx, pilots="gauss")
+    o["tau_X"] = o.pop("tau_Y")                                                 # plot_errorVSsnr_approx.m:50
+    o["tau_S"] = o["tau_X"] / 2.0                                               # :51
+    del o["tau_Z"]
+    return o
+
+
 def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, device=None, with_hbf=False,
-                 want_draws=False, want_H=False, shared_pilots=False, ctx=None):
+                 want_draws=False, want_H=False, shared_pilots=False, ctx=None, pilots="qam4"):
     """plot_errorVSsnr.m:57-136 for trials [trial0, trial0 + batch) on the HIP path
     (``jstsp_build_trials_c32``, csrc/inputgen.hip): draws, channel, pilots, measurement, A, B,
     hyper-parameters and indx_S are produced by the library's own kernels — nothing but the output
@@ -330,7 +347,8 @@ def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, d
     Th = p.T_hbf if with_hbf else 0
     model = _lib.Model(p.Nt, p.Nr, p.L, p.T_prop, p.Mr, p.Mr_e, p.Gr, p.Gt, p.clusters, p.rays, Th,
                        1 if shared_pilots else 0, p.noise_var, _lib.BF_ZC if p.beamformer == "ZC" else _lib.BF_DFT,
-                       _lib.RHO_MAX if p.rho_rule == "max" else _lib.RHO_MIN6, p.rho_scale)
+                       _lib.RHO_MAX if p.rho_rule == "max" else _lib.RHO_MIN6, p.rho_scale,
+                       _lib.PILOTS_GAUSS if pilots == "gauss" else _lib.PILOTS_QAM4)
     c64, f32 = torch.complex64, torch.float32
     out = dict(subY=empty_colmajor(batch, N, M, c64, device), Omega=empty_colmajor(batch, N, M, f32, device),
                A=empty_colmajor(1, N, Gr, c64, device)[0], B=empty_colmajor(batch, G2, M, c64, device),
@@ -348,6 +366,7 @@ def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, d
         out["u_t"] = torch.empty((batch, Np), dtype=f32, device=device)
         out["noise"] = empty_colmajor(batch, p.Nr, p.T_prop, c64, device)
         out["qam_idx"] = torch.empty((batch, p.Nt, p.T_prop), dtype=torch.uint8, device=device)
+        out["pilot_sym"] = torch.empty((batch, p.Nt, p.T_prop), dtype=c64, device=device)
     hyp = {k: np.empty(batch, dtype=np.float64) for k in ("tau_Y", "tau_Z", "rho")}
     tr = _lib.Trials()
     for k, v in out.items():

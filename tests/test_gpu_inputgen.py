@@ -130,3 +130,52 @@ def test_solver_runs_on_hip_built_inputs_and_recovers_the_channel():
                                            "approximate", None, want_ce=False)
     e = J.nmse_spectral(Sa, inp["Zbar"])
     assert float(e.mean()) < 0.2
+
+
+@pytest.mark.parametrize("kw", [dict(Nt=4, Nr=32, L=4, T=70, ratio=0.75, snr_db=5.0),        # plot_errorVSsnr_approx.m:8-20
+                                dict(Nt=3, Nr=16, L=2, T=24, ratio=0.5, snr_db=-5.0, clusters=3, rays=2)])
+def test_training_builder_mode_matches_oracle_on_its_own_draws(kw):
+    """wideband_hybBF_comm_system_training.m:1-58 + plot_errorVSsnr_approx.m:45-58 as a mode of jstsp_build_trials_c32
+    (Gaussian Hermitian-Toeplitz pilots, unitary DFT combiner, round(ratio*Nr) rows per column, rho of :51-53) against the
+    oracle's restatement on the library's own draws."""
+    from jstsp19_amd.system_model import TrainingParams, build_trials_training
+    from oracle import system_model as osm
+    p = TrainingParams(**kw)
+    out = build_trials_training(p, 3, 3, seed=11, sweep_idx=1, want_draws=True, want_H=True)
+    torch.cuda.synchronize()
+    Np = p.clusters * p.rays
+    params = dict(Nt=p.Nt, Nr=p.Nr, L=p.L, T=p.T, clusters=p.clusters, rays=p.rays, ratio=p.ratio, noise_var=p.noise_var)
+    for t in range(3):
+        u_r = np.zeros((p.L, Np)); u_r[0] = out["u_r"][t].cpu().numpy()
+        u_t = np.zeros((p.L, Np)); u_t[0] = out["u_t"][t].cpu().numpy()
+        om = out["Omega"][t].cpu().numpy()
+        assert np.all(om.sum(axis=0) == p.Lr)
+        rows = np.stack([np.flatnonzero(om[:, j]) for j in range(om.shape[1])])
+        d = dict(gains=out["gains"][t].cpu().numpy().astype(complex), u_r=u_r, u_t=u_t,
+                 noise=out["noise"][t].cpu().numpy().astype(complex),
+                 pilots=out["pilot_sym"][t].cpu().numpy().astype(complex), omega_rows=rows)
+        ref = osm.training_inputs_errorVSsnr_approx(params, d)
+        np.testing.assert_array_equal(om, ref["Omega"])
+        assert rel_err(out["subY"][t].cpu().numpy(), ref["subY"]) < 5e-6
+        assert rel_err(out["A"].cpu().numpy(), ref["A"]) < 2e-6
+        assert rel_err(out["B"][t].cpu().numpy(), ref["B"]) < 5e-6
+        assert rel_err(out["Zbar"][t].cpu().numpy(), ref["Zbar"]) < 5e-6
+        np.testing.assert_allclose(float(out["tau_X"][t]), ref["tau_X"], rtol=2e-6)
+        np.testing.assert_allclose(float(out["tau_S"][t]), ref["tau_S"], rtol=2e-6)
+        np.testing.assert_allclose(float(out["rho"][t]), ref["rho"], rtol=5e-5)
+    # Gaussian pilots: unit-variance parts, and the 4-QAM path still reports its alphabet values
+    ps = torch.view_as_real(out["pilot_sym"]).double()
+    assert abs(float(ps.var()) - 1.0) < 0.2
+
+
+def test_alg1_vs_alg2_sweep_on_library_built_inputs():
+    """run_approx_sweep with its default builder (the library's) gives the curves of the tensor-op builder statistically:
+    different generators, same distribution."""
+    from jstsp19_amd.montecarlo import run_approx_sweep
+    from jstsp19_amd.system_model import TrainingParams
+    base = TrainingParams(Nt=4, Nr=32, L=4, T=70, ratio=0.75)
+    a = run_approx_sweep(base, [0.0, 10.0], [20], 48, batch=48)
+    b = run_approx_sweep(base, [0.0, 10.0], [20], 48, batch=48, builder="torch")
+    assert a.shape == (1, 2, 2) and torch.isfinite(a).all()
+    assert float((a - b).abs().max()) < 0.35 * float(b.max())
+    assert float(a[0, 1, 0]) < float(a[0, 0, 0])                # higher SNR, lower error (Alg. 1)
