@@ -46,10 +46,10 @@ def parse():
     ap.add_argument("--snr-db", type=float, default=5.0)
     ap.add_argument("--no-ce", action="store_true", help="skip convergence_error (2-output call)")
     ap.add_argument("--cpu-trials", type=int, default=-1,
-                    help="trials timed on the host baseline (rank 0, N=1); -1 = one per physical core (at most the batch), 0 = none")
+                    help="trials timed on the host baseline (rank 0, N=1); -1 = three per thread (at most the batch), 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="OpenMP threads of the host baseline (0 = physical cores = logical CPUs / 2)")
+                    help="OpenMP threads of the host baseline (0 = min(physical cores, the cgroup's CPU quota))")
     ap.add_argument("--shared-pilots", action="store_true", help="one pilot set for all trials (B shared, stride 0)")
     ap.add_argument("--small", action="store_true", help="reference-native shape (plumbing check)")
     ap.add_argument("--sweep", action="store_true",
@@ -321,8 +321,15 @@ def main():
         from oracle import solvers as O
         ncore = os.cpu_count() or 1
         phys = max(1, ncore // 2)                                  # SMT siblings do not add FMA throughput
-        nthr = a.cpu_threads or phys
-        nt = min(a.batch, a.cpu_trials if a.cpu_trials > 0 else nthr)
+        quota = None                                               # CPU time this process may use (cgroup v2 cpu.max)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                quota = max(1, int(int(q) / int(per)))
+        except (OSError, ValueError):
+            pass
+        nthr = a.cpu_threads or (min(phys, quota) if quota else phys)
+        nt = min(a.batch, a.cpu_trials if a.cpu_trials > 0 else 3 * nthr)     # about 15-20 s of host work
         try:                                                       # tuned for the host it is timed on
             lib = bp.load(bp.build(native=True, out=os.path.join(tempfile.mkdtemp(prefix="jstsp_cpu_"), "libjstsp_cpu_port.so")))
             tuned = "-march=native"
@@ -345,7 +352,7 @@ def main():
         except (OSError, IndexError):
             model = "unknown"
         cpu = {"value": round(nt / cdt, 4), "unit": "channel-estimates/s", "cores": used, "kind": "port",
-               "cpu_model": model, "logical_cpus": ncore, "seconds": round(cdt, 2),
+               "cpu_model": model, "logical_cpus": ncore, "cgroup_cpu_quota": quota, "seconds": round(cdt, 2),
                "sample": "%d of the %d trials of this workload, Imax=%d, ce=%s: float64 C++ structured restatement of "
                          "proposed_algorithm.m (oracle/cpu_port.cpp, %s), OpenMP over trials, one trial per thread, %d "
                          "threads; timing includes the float64 conversion of the inputs (about 2 %%)" % (nt, a.batch, IMAX,

@@ -69,10 +69,14 @@ def test_one_trial_whose_k_jumps_is_re_solved_alone_and_matches_the_oracle():
     pick = zero[torch.linspace(0, len(zero) - 1, 7).long()]
     for r, c in pick.tolist():
         Om[bad, r, c] = -2.0 * rho + 1e-3
-    (S1, Y1, c1), n1 = _solve(inp, 12, Omega=Om)
+    # (negative weights make the iteration itself unstable: X grows 170-fold per iteration in the float64 oracle too, so
+    #  the comparison stops at 6 iterations, where everything - including the squared norms of convergence_error - is
+    #  still far inside the fp32 range)
+    IM = 6
+    (S1, Y1, c1), n1 = _solve(inp, IM, Omega=Om)
     assert n1 == 1                                                           # that trial, and only that trial
     assert np.all(np.isfinite(S1)) and np.all(np.isfinite(Y1))
-    (S0, Y0, c0), _ = _solve(inp, 12, {"JSTSP_FUSED": "0"}, Omega=Om)
+    (S0, Y0, c0), _ = _solve(inp, IM, {"JSTSP_FUSED": "0"}, Omega=Om)
     assert np.array_equal(np.isfinite(c1), np.isfinite(c0)), np.argwhere(np.isfinite(c1) != np.isfinite(c0))[:8].tolist()
     assert np.all(np.isfinite(c0[:, 1:, :2])), np.argwhere(~np.isfinite(c0))[:8].tolist()
     assert _rel(S1[bad], S0[bad]) < 1e-6 and _rel(Y1[bad], Y0[bad]) < 1e-6
@@ -83,9 +87,9 @@ def test_one_trial_whose_k_jumps_is_re_solved_alone_and_matches_the_oracle():
     for t in (bad, bad + 1):
         So, Yo, _ = O.proposed_algorithm(inp["subY"][t].cpu().numpy().astype(np.complex128),
                                          Om[t].cpu().numpy().astype(np.float64), A_h,
-                                         inp["B"][t].cpu().numpy().astype(np.complex128), 12, float(inp["tau_Y"][t]),
+                                         inp["B"][t].cpu().numpy().astype(np.complex128), IM, float(inp["tau_Y"][t]),
                                          float(inp["tau_Z"][t]), float(inp["rho"][t]), "approximate", want_ce=False)
         assert _rel(S1[t], So) < 5e-4, t
     # two outputs only (no three-Gram pass): same recovery
-    (S3, _, _), n3 = _solve(inp, 12, Omega=Om, want_ce=False)
+    (S3, _, _), n3 = _solve(inp, IM, Omega=Om, want_ce=False)
     assert n3 == 1 and _rel(S3, S1) < 1e-5
