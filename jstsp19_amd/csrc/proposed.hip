@@ -27,7 +27,7 @@ struct ProposedWS {
     int32_t *rank;
     double *ce;
     float *lam;            // 3 * batch
-    GramWS gz, gn;         // SVT of Z; spectral norms of V1, V2, X
+    GramWS gz, gn, gn2;    // SVT of Z; spectral norms of V1, V2, X (gn2: the second buffer of their Gram partials, by iteration parity)
     // split-f16 path (hgemm.hip): B packed once per solve in both orientations, per-problem operand maxima
     bool h2 = false;
     HPack Bc, Bs;          // b(k = m, j = g) = conj(B) for K B^H ;  b(k = g, j = m) = B for (A S) B
@@ -66,7 +66,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     b += rnd256(3 * (size_t)batch * sizeof(float));
     const int ns3 = gram3_nsplit(N, M, G2, want_ce);
     b += GramWS::bytes(N, M, batch, true, ns3);
-    if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false, ns3);
+    if (want_ce) b += 2 * GramWS::bytes(N, M, 3 * batch, false, ns3);
     if (use_hgemm(N, G2, M))
         b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(8 * batch * sizeof(uint32_t)) +
              hgemm_pack_bytes(G2, N, batch);
@@ -101,7 +101,7 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
                   JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     const int ns3 = gram3_nsplit(N, M, G2, want_ce);
     JSTSP_TRY(w.gz.alloc(a, N, M, batch, true, ns3));
-    if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false, ns3));
+    if (want_ce) { JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false, ns3)); JSTSP_TRY(w.gn2.alloc(a, N, M, 3 * batch, false, ns3)); }
     w.h2 = use_hgemm(N, G2, M);
     if (w.h2) {
         // operand maxima of one iteration, one block zeroed once per iteration: kmax | X | V1 | V2 | Znext | wmax | pmax x2.
@@ -353,6 +353,31 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // test hook: a negative value makes every pass overflow, which must end in the per-trial re-solve below
     const int fused_kback = getenv("JSTSP_FUSED_KBACK") ? atoi(getenv("JSTSP_FUSED_KBACK")) : 4;
     bool passed = false;                        // X, V1, k-partials of this iteration came from the previous pass
+    // Order inside the window between two passes (round 3).  Three chains start when a pass ends: the gradient step (critical:
+    // the next pass waits for its A S), the three-Gram pass -> eigen-decomposition (the next pass waits for I - Q), and the norms
+    // of convergence_error (Gram of V2 -> lambda_max; only the Gram must be done before the next pass overwrites V2).  Started
+    // together, the two Gram passes (1.6 GB) and the first products of the gradient step fight for HBM and the critical chain's
+    // first 70-us product takes 500 us (profiles/r03_windows_before.txt).  JSTSP_CE_GATE=1 (default): the Gram of V2 of iteration
+    // `it` is issued in the NEXT loop iteration, behind the three-Gram pass of that window; 0: as in round 2.
+    // With that, the Gram partials of the three norms are double-buffered by iteration parity (gn / gn2) and ALL three
+    // lambda_max of an iteration are ONE launch (3 x batch matrices fill the chip once) instead of two half-empty ones.
+    const int ce_gate = getenv("JSTSP_CE_GATE") ? atoi(getenv("JSTSP_CE_GATE")) : 1;
+    const bool dbuf = ce_gate && fusedp && zfly && want_ce;
+    auto gn_of = [&](int i) -> GramWS & { return (dbuf && (i & 1)) ? w.gn2 : w.gn; };
+    int ce_pending = -1;
+    const uint32_t *ce_nmax = nullptr;
+    auto issue_ce_v2 = [&](int itc, const uint32_t *nmax_it, hipEvent_t gate) -> int {
+        JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
+        if (gate) JSTSP_HIP(hipStreamWaitEvent(s2, gate, 0));
+        StreamScope sc(ctx, s2);
+        JSTSP_TRY(gram_partials_range(ctx, gn_of(itc), w.X, snm, 2 * batch, batch, nmax_it));
+        JSTSP_HIP(hipEventRecord(ev_gv2, s2));
+        if (dbuf) JSTSP_TRY(lmax_from_partials(ctx, gn_of(itc), w.lam, true));
+        else JSTSP_TRY(lmax_from_partials_range(ctx, gn_of(itc), 2 * batch, batch, w.lam, true));
+        JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, itc));
+        JSTSP_HIP(hipEventRecord(ev_ce, s2));
+        return 0;
+    };
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
         // every operand maximum of this iteration starts from zero (one memset instead of four)
@@ -402,15 +427,20 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
             if (zfly) {
                 // (the spectral norms of X, V1 of the previous iteration read the G_x, G_v1 partials this pass overwrites)
-                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_lxv, 0));
+                // (double-buffered: the buffer of this parity was last read by the lambda_max launch of iteration it - 2)
+                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, dbuf ? ev_ce : ev_lxv, 0));
                 // (Until the library was compiled without packed-fp32 instructions - see build.py - this pass also had to
                 // wait for the previous iteration's lambda_max kernels: the Lanczos kernel, whose complex arithmetic hipcc had
                 // turned into v_pk_fma_f32 chains, returned different Ritz values when MFMA-heavy waves shared its SIMDs.)
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
-                                        w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
+                                        w.prm, w.gz.Gpart, gn_of(it).Gpart, gn_of(it).Gpart + (size_t)batch * N * N * w.gn.nsplit));
                 JSTSP_HIP(hipEventRecord(ev_gxv, s1));
-                if (fusedp) {       // lambda_max of G_x, G_v1 now (beside the pass), not after it with G_v2: the next Gram
+                if (ce_pending >= 0) {      // the previous iteration's Gram of V2, lambda_max and ratio: behind this Gram pass
+                    JSTSP_TRY(issue_ce_v2(ce_pending, ce_nmax, ev_gxv));
+                    ce_pending = -1;
+                }
+                if (fusedp && !dbuf) {       // lambda_max of G_x, G_v1 now (beside the pass), not after it with G_v2: the next Gram
                                     // pass then never waits for them
                     JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));
                     StreamScope sc2(ctx, s2);
@@ -438,7 +468,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         if (want_ce && !(zfly && it + 1 < Imax)) {              // s2: Gram of [X | V1]
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_x, 0));
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr));
+            JSTSP_TRY(gram_partials_range(ctx, gn_of(it), w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gxv, s2));
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
@@ -545,15 +575,21 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
         }
         // -- convergence_error(i,1:2) = norm(V1)^2/norm(X)^2, norm(V2)^2/norm(X)^2           (:67,:69)
+        if (want_ce && ce_gate && passed && fusedp && zfly && it + 2 < Imax) {
+            // (a pass has just been launched and another window with a three-Gram pass follows: issue it there)
+            JSTSP_HIP(hipEventRecord(ev_c, sm));
+            ce_pending = it;
+            ce_nmax = hmax ? w.nmax : nullptr;
+        } else
         if (want_ce) {
             JSTSP_HIP(hipEventRecord(ev_c, sm));
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
             if (zfly) JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));      // G_x, G_v1 came from the side stream s1
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
+            JSTSP_TRY(gram_partials_range(ctx, gn_of(it), w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gv2, s2));
-            if (fusedp && zfly && it + 1 < Imax) JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 2 * batch, batch, w.lam, true));
-            else JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam, true));
+            if (fusedp && zfly && it + 1 < Imax && !dbuf) JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 2 * batch, batch, w.lam, true));
+            else JSTSP_TRY(lmax_from_partials(ctx, gn_of(it), w.lam, true));
             JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));
             JSTSP_HIP(hipEventRecord(ev_ce, s2));
         }
