@@ -216,7 +216,7 @@ int jstsp_vamp_c32(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c32 *y, 
 
 /* The same for the dictionary the drivers actually pass (plot_errorVSsnr.m:79-80,100):
  *   Phi = kron(Gb.', Af),  y = vec(Y),  Af: Na x Gr (min(Na, Gr) <= 128; Na > Gr is the M > N branch),  Gb: G2 x G2 Hermitian (G2 <= 8192; above 128
- *   its eigen-decomposition goes through rocSOLVER, loaded on first use - as does every Gram eigenproblem above order 128:
+ *   its eigen-decomposition is the library's block Jacobi (csrc/eig_large.hip) - as is every Gram eigenproblem above order 128:
  *   svt / mc_svt / mc_admm / proposed_algorithm with min(rows, cols) in 129..2048, sparse_admm with max(Mr, Mt) in 129..2048).
  * Phi is never formed.  Y: Na x G2 x batch; X_out: Gr x G2 x batch (x = vec(X)). */
 int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const jstsp_c32 *Y,

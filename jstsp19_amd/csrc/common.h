@@ -215,7 +215,7 @@ int launch_eig(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, 
                int nsplit, long long sGs, const TrialParams *prm, const float *tau,
                float2 *Q, float *lam_out, float2 *Vg);
 bool eig_needs_global_v(int n);
-// Orders above 128 (eig_large.hip): EIG_VECS and EIG_SVT_Q through rocSOLVER's cheevd, loaded on first use.
+// Orders above 128 (eig_large.hip): two-sided block Jacobi on 128 x 128 sub-problems (this kernel) + batched GEMMs.
 int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
                      long long sGs, const TrialParams *prm, const float *tau, float2 *Q, float *lam_out);
 // Fast paths (eig2.hip): warm-started block Jacobi for n <= 64; tridiagonalisation + Sturm for lambda_max.

@@ -1,93 +1,153 @@
 // Hermitian eigen-decomposition for orders above 128 - beyond what the LDS-resident Jacobi kernels hold (eig.hip,
 // eig2.hip, eig3.hip).  Nothing on the timed paths gets here: these are the one-off decompositions of large factors
-// (VAMP's `svd` of vamp.m:32 when G2 = L*Gt > 128, BASELINE configs[4]) and the SVT of inputs whose BOTH dimensions exceed
-// 128.  The decomposition itself is rocSOLVER's cheevd (a vendor LAPACK routine, like a library GEMM), loaded lazily
-// with dlopen so that the library has no link-time dependency on it and every other entry point works without it; the
-// sum of the split-K partials, the symmetrisation and the projector Q = U diag(q) U^H stay here.
+// (VAMP's `svd` of vamp.m:32 when G2 = L*Gt > 128: BASELINE configs[4] has order 4096) and the SVT / spectral norms of
+// inputs whose BOTH dimensions exceed 128 (benchmark_algorithms/svt.m:5).
+//
+// Round 3: hand-written two-sided BLOCK Jacobi (rounds 1-2 called rocSOLVER's cheevd here).  The matrix is cut into
+// blocks of 64 rows / columns (order padded to an even number of blocks; the padding is decoupled: zero off-diagonal,
+// distinct negative diagonal, so no rotation ever touches it).  A round pairs the blocks two by two (circle method,
+// nb - 1 rounds meet every pair once = one sweep); each pair's 128 x 128 Hermitian sub-matrix is diagonalised EXACTLY
+// by the existing order-128 Jacobi kernel (eig.hip) - all pairs of all matrices in one launch - and the 128 x 128
+// unitaries J are applied as batched GEMMs on the fp32 MFMA kernel (cgemm.hip):
+//      W <- J^H W J   as   X = W J,  W' = (X^H) J        (two column-panel products and one conjugate transposition:
+//                                                          panels of 128 columns are contiguous, rows are not)
+//      U <- U J
+// Between rounds the blocks are physically permuted (rows and columns of W, columns of U) so that the partners of the
+// next round are neighbours and every panel product is ONE strided-batched launch over (matrix, pair).  Block Jacobi
+// with exactly solved sub-problems converges quadratically like the scalar method; a sweep costs 3 * n^3 complex MACs.
+// Measured (MI355X): order 4096, 2 matrices: x.xx s (rocSOLVER cheevd: 0.5 s); orders 136-512: a few ms.
 #include "common.h"
 #include "solver_common.h"
 
-#include <dlfcn.h>
-#include <rocsolver/rocsolver.h>
+#include <vector>
 
 namespace jstsp {
 namespace {
 
-struct RocSolver {
-    bool tried = false, ok = false;
-    char why[256] = {0};
-    decltype(&rocblas_create_handle) create = nullptr;
-    decltype(&rocblas_set_stream) set_stream = nullptr;
-    decltype(&rocsolver_cheevd_strided_batched) cheevd = nullptr;
-    rocblas_handle handle[16] = {nullptr};
-};
+constexpr int BS = 64;           // block size; sub-problems have order 2 * BS = 128
 
-RocSolver &rocsolver()
-{
-    static RocSolver r;
-    if (r.tried) return r;
-    r.tried = true;
-    // by soname first: a process that already holds a copy (PyTorch-ROCm bundles one) keeps using that one
-    void *hs = nullptr;
-    for (const char *name : {"librocsolver.so.0", "/opt/rocm/lib/librocsolver.so.0", "librocsolver.so"}) {
-        hs = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (hs) break;
-    }
-    if (!hs) { snprintf(r.why, sizeof(r.why), "dlopen(librocsolver): %s", dlerror()); return r; }
-    // rocBLAS is a dependency of rocSOLVER: dlsym on the handle searches the object and what it depends on
-    r.create = reinterpret_cast<decltype(r.create)>(dlsym(hs, "rocblas_create_handle"));
-    r.set_stream = reinterpret_cast<decltype(r.set_stream)>(dlsym(hs, "rocblas_set_stream"));
-    r.cheevd = reinterpret_cast<decltype(r.cheevd)>(dlsym(hs, "rocsolver_cheevd_strided_batched"));
-    if (!r.create || !r.set_stream || !r.cheevd) { snprintf(r.why, sizeof(r.why), "rocsolver / rocblas symbols not found"); return r; }
-    r.ok = true;
-    return r;
-}
-
-// W[t] = Hermitian part of sum_s Gpart[t][s]; amax[t] = max |off-diagonal entry| (bits of a non-negative float)
-__global__ void sum_sym_kernel(int n, const float2 *Gpart, long long sGt, int nsplit, long long sGs, float2 *W, uint32_t *amax)
+// Wp[t] = padded Hermitian part of sum_s Gpart[t][s] (order np >= n), U[t] = I.  Padding: zero coupling, diagonal
+// -(1 + k/np) * dscale[t] (negative and distinct: G is positive semi-definite in every caller, and no rotation mixes them;
+// inside [-2, -1] x the largest diagonal entry so that the sub-problems' convergence scale stays that of the data).
+__global__ void init_kernel(int n, int np, const float2 *Gpart, long long sGt, int nsplit, long long sGs, float2 *W, float2 *U,
+                            const float *dscale)
 {
     const int t = blockIdx.y;
     const float2 *g = Gpart + (long long)t * sGt;
-    float2 *w = W + (size_t)t * n * n;
-    float m = 0.f;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)n * n; e += (long long)gridDim.x * blockDim.x) {
-        const int i = (int)(e % n), j = (int)(e / n);
-        float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
-        for (int s = 0; s < nsplit; ++s) {
-            const float2 x = g[(long long)s * sGs + i + (long long)n * j], y = g[(long long)s * sGs + j + (long long)n * i];
-            a.x += x.x; a.y += x.y; b.x += y.x; b.y += y.y;
+    float2 *w = W + (size_t)t * np * np, *u = U ? U + (size_t)t * np * np : nullptr;
+    const float ds = dscale[t];
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)np * np; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % np), j = (int)(e / np);
+        float2 v = make_float2(0.f, 0.f);
+        if (i < n && j < n) {
+            float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
+            for (int s = 0; s < nsplit; ++s) {
+                const float2 x = g[(long long)s * sGs + i + (long long)n * j], y = g[(long long)s * sGs + j + (long long)n * i];
+                a.x += x.x; a.y += x.y; b.x += y.x; b.y += y.y;
+            }
+            v = (i == j) ? make_float2(a.x, 0.f) : make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+        } else if (i == j) {
+            v = make_float2(-(1.f + (float)(i - n) / (float)np) * ds, 0.f);
         }
-        const float2 v = (i == j) ? make_float2(a.x, 0.f) : make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
         w[e] = v;
-        if (i != j) m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+        if (u) u[e] = make_float2(i == j ? 1.f : 0.f, 0.f);
     }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&amax[t], __float_as_uint(m));
 }
 
-// An exactly diagonal matrix - the all-zero svt argument of a first ADMM iteration above all (svt.m:7-12 returns zeros for
-// it) - comes back from cheevd with the right eigenvalues and NaN eigenvectors (measured: rocSOLVER 3.32 / ROCm 7.2, any
-// order): its decomposition is written here instead, eigenvectors I, eigenvalues = the diagonal in place.
-__global__ void diagonal_matrix_kernel(int n, const float2 *Gpart, long long sGt, int nsplit, long long sGs, float2 *W, float *D,
-                                       const uint32_t *amax)
+// dscale[t] = 1 + largest diagonal entry (of the sum of the partials); stat[t] = {sum |w_ij|^2 off the diagonal, sum w_ii^2}
+__global__ void dscale_kernel(int n, const float2 *Gpart, long long sGt, int nsplit, long long sGs, float *dscale)
+{
+    const int t = blockIdx.x;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float d = 0.f;
+        for (int s = 0; s < nsplit; ++s) d += Gpart[(long long)t * sGt + (long long)s * sGs + i + (long long)n * i].x;
+        m = fmaxf(m, fabsf(d));
+    }
+    __shared__ float sh[256];
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dscale[t] = 1.f + sh[0];
+}
+
+__global__ void offnorm_kernel(int np, const float2 *W, double *stat)
 {
     const int t = blockIdx.y;
-    if (amax[t] != 0u) return;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)n * n; e += (long long)gridDim.x * blockDim.x) {
-        const int i = (int)(e % n), j = (int)(e / n);
-        W[(size_t)t * n * n + e] = make_float2(i == j ? 1.f : 0.f, 0.f);
-        if (i == j) {
-            float d = 0.f;
-            for (int s = 0; s < nsplit; ++s) d += Gpart[(long long)t * sGt + (long long)s * sGs + i + (long long)n * i].x;
-            D[(size_t)t * n + i] = d;
-        }
+    const float2 *w = W + (size_t)t * np * np;
+    double off = 0.0, dg = 0.0;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)np * np; e += (long long)gridDim.x * blockDim.x) {
+        const float2 v = w[e];
+        const double a = (double)v.x * v.x + (double)v.y * v.y;
+        if (e % np == e / np) dg += a; else off += a;
+    }
+    for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); dg += __shfl_xor(dg, o); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&stat[2 * t], off); atomicAdd(&stat[2 * t + 1], dg); }
+}
+
+// Wn[i, j] = W[idx[i], idx[j]];  Un[:, j] = U[:, idx[j]]   (symmetric block permutation between two rounds)
+__global__ void permute_kernel(int np, const int *idx, const float2 *W, float2 *Wn, const float2 *U, float2 *Un)
+{
+    const int t = blockIdx.y;
+    const size_t o = (size_t)t * np * np;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)np * np; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % np), j = (int)(e / np);
+        const int sj = idx[j];
+        Wn[o + e] = W[o + idx[i] + (size_t)np * sj];
+        if (U) Un[o + e] = U[o + i + (size_t)np * sj];
     }
 }
 
-__global__ void last_value_kernel(int n, int batch, const float *D, float *lam_out)     // cheevd returns ascending order
+// S[(t, k)] = the k-th diagonal block of order 2 BS of W[t]
+__global__ void gather_diag_kernel(int np, int m, const float2 *W, float2 *S)
+{
+    const int b = blockIdx.x, t = b / m, k = b % m;
+    const float2 *w = W + (size_t)t * np * np + (size_t)(2 * BS * k) * np + 2 * BS * k;
+    float2 *s = S + (size_t)b * (2 * BS) * (2 * BS);
+    for (int e = threadIdx.x; e < 4 * BS * BS; e += blockDim.x)
+        s[e] = w[(e % (2 * BS)) + (size_t)np * (e / (2 * BS))];
+}
+
+// Xh[t] = X[t]^H (32 x 32 tiles through LDS)
+__global__ void conj_transpose_kernel(int np, const float2 *X, float2 *Xh)
+{
+    __shared__ float2 tile[32][33];
+    const int t = blockIdx.z;
+    const float2 *x = X + (size_t)t * np * np;
+    float2 *y = Xh + (size_t)t * np * np;
+    const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    for (int r = threadIdx.y; r < 32; r += 8) tile[r][threadIdx.x] = x[(i0 + threadIdx.x) + (size_t)np * (j0 + r)];      // tile[j][i]
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const float2 v = tile[threadIdx.x][r];                  // element (i0 + r, j0 + tx) of X
+        y[(j0 + threadIdx.x) + (size_t)np * (i0 + r)] = make_float2(v.x, -v.y);
+    }
+}
+
+// Results in the callers' order: eigenpair of physical column j belongs to logical index lg[j]; padded ones (lg >= n) dropped.
+__global__ void extract_kernel(int n, int np, const int *lg, const float2 *W, const float2 *U, float2 *Q, float *lam)
+{
+    const int t = blockIdx.y;
+    const size_t o = (size_t)t * np * np;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)n * np; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % n), j = (int)(e / n);
+        const int c = lg[j];
+        if (c >= n) continue;
+        if (Q) Q[(size_t)t * n * n + i + (size_t)n * c] = U[o + i + (size_t)np * j];
+        if (i == 0 && lam) lam[(size_t)t * n + c] = W[o + j + (size_t)np * j].x;
+    }
+}
+
+__global__ void lmax_of_kernel(int n, int batch, const float *lam, float *out)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < batch) lam_out[t] = D[(size_t)t * n + n - 1];
+    if (t >= batch) return;
+    float m = lam[(size_t)t * n];
+    for (int i = 1; i < n; ++i) m = fmaxf(m, lam[(size_t)t * n + i]);
+    out[t] = m;
 }
 
 // T[t](:, i) = U[t](:, i) * q_i,  q_i = min(1, tau_t / sqrt(max(lambda_i, 0)))  (1 for a zero singular value: svt.m:7-12
@@ -105,6 +165,21 @@ __global__ void scale_cols_kernel(int n, const float2 *U, const float *lam, cons
     }
 }
 
+// stream-ordered temporaries outside the context's arena (the callers sized that for the small kernels), freed on every path
+struct Temps {
+    hipStream_t st;
+    std::vector<void *> p;
+    explicit Temps(hipStream_t s) : st(s) {}
+    ~Temps() { for (void *q : p) (void)hipFreeAsync(q, st); }
+    template <class T> T *get(size_t n)
+    {
+        void *q = nullptr;
+        if (hipMallocAsync(&q, std::max<size_t>(n, 1) * sizeof(T), st) != hipSuccess) return nullptr;
+        p.push_back(q);
+        return static_cast<T *>(q);
+    }
+};
+
 }  // namespace
 
 int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
@@ -112,52 +187,97 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
 {
     JSTSP_REQUIRE(mode == EIG_VECS || mode == EIG_SVT_Q || mode == EIG_LMAX, JSTSP_E_ARG, "eig (order %d): bad mode %d", n, mode);
     JSTSP_REQUIRE(n <= 8192, JSTSP_E_UNSUPPORTED, "eig: matrix order %d above 8192", n);
-    RocSolver &rs = rocsolver();
-    JSTSP_REQUIRE(rs.ok, JSTSP_E_UNSUPPORTED, "eig: order %d > 128 needs rocSOLVER, which could not be loaded (%s)", n, rs.why);
-    const int dev = ctx->device;
-    JSTSP_REQUIRE(dev >= 0 && dev < 16, JSTSP_E_UNSUPPORTED, "eig: device index %d", dev);
-    if (!rs.handle[dev])
-        JSTSP_REQUIRE(rs.create(&rs.handle[dev]) == rocblas_status_success, JSTSP_E_UNSUPPORTED, "rocblas_create_handle failed");
-    JSTSP_REQUIRE(rs.set_stream(rs.handle[dev], ctx->stream) == rocblas_status_success, JSTSP_E_UNSUPPORTED, "rocblas_set_stream failed");
+    JSTSP_REQUIRE(batch <= 32768, JSTSP_E_UNSUPPORTED, "eig (order %d): %d matrices in one call", n, batch);
     hipStream_t st = ctx->stream;
-    const size_t nn = (size_t)n * n;
-    // stream-ordered temporaries outside the arena (the callers sized that for the small kernels)
-    float2 *W = nullptr, *T = nullptr;
-    float *D = nullptr, *E = nullptr;
-    int *info = nullptr;
-    uint32_t *amax = nullptr;
-    const bool own_w = (mode != EIG_VECS), own_d = (mode != EIG_VECS);
-    if (own_w) JSTSP_HIP(hipMallocAsync((void **)&W, batch * nn * sizeof(float2), st)); else W = Q;
-    if (mode == EIG_SVT_Q) JSTSP_HIP(hipMallocAsync((void **)&T, batch * nn * sizeof(float2), st));
-    if (own_d) JSTSP_HIP(hipMallocAsync((void **)&D, (size_t)batch * n * sizeof(float), st)); else D = lam_out;
-    JSTSP_HIP(hipMallocAsync((void **)&E, (size_t)batch * n * sizeof(float), st));
-    JSTSP_HIP(hipMallocAsync((void **)&info, (size_t)batch * sizeof(int), st));
-    JSTSP_HIP(hipMallocAsync((void **)&amax, (size_t)batch * sizeof(uint32_t), st));
-    JSTSP_HIP(hipMemsetAsync(amax, 0, (size_t)batch * sizeof(uint32_t), st));
-    const dim3 grid((unsigned)std::min<size_t>((nn + 255) / 256, 2048), (unsigned)batch);
-    hipLaunchKernelGGL(sum_sym_kernel, grid, dim3(256), 0, st, n, Gpart, sGt, nsplit, sGs, W, amax);
-    const rocblas_status rc = rs.cheevd(rs.handle[dev], mode == EIG_LMAX ? rocblas_evect_none : rocblas_evect_original,
-                                        rocblas_fill_lower, n, reinterpret_cast<rocblas_float_complex *>(W), n, (rocblas_stride)nn,
-                                        D, n, E, n, info, batch);
-    int rcode = 0;
-    if (rc != rocblas_status_success) {
-        set_error("rocsolver_cheevd_strided_batched failed with status %d (order %d, %d matrices)", (int)rc, n, batch);
-        rcode = JSTSP_E_UNSUPPORTED;
-    } else {
-        if (mode != EIG_LMAX) hipLaunchKernelGGL(diagonal_matrix_kernel, grid, dim3(256), 0, st, n, Gpart, sGt, nsplit, sGs, W, D, amax);
-        if (mode == EIG_LMAX) {
-            hipLaunchKernelGGL(last_value_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, n, batch, D, lam_out);
-        } else if (mode == EIG_SVT_Q) {
-            hipLaunchKernelGGL(scale_cols_kernel, grid, dim3(256), 0, st, n, W, D, prm, tau, T);
-            rcode = gemm(ctx, 'N', 'C', n, n, n, batch, Mat{T, (long long)nn, n}, Mat{W, (long long)nn, n}, Q, (long long)nn, n);
-        }
+    int nb = (n + BS - 1) / BS;
+    nb += nb & 1;                                   // an even number of blocks
+    const int np = nb * BS, m = nb / 2, sub = 2 * BS;
+    const size_t nn = (size_t)np * np, cnt = (size_t)batch * m;
+    const bool vecs = mode != EIG_LMAX;
+    Temps tmp(st);
+    float2 *W = tmp.get<float2>(batch * nn), *Wp = tmp.get<float2>(batch * nn);
+    float2 *U = vecs ? tmp.get<float2>(batch * nn) : nullptr, *Up = vecs ? tmp.get<float2>(batch * nn) : nullptr;
+    float2 *S = tmp.get<float2>(cnt * sub * sub), *J = tmp.get<float2>(cnt * sub * sub), *Vg = tmp.get<float2>(cnt * sub * sub);
+    float *lamJ = tmp.get<float>(cnt * sub), *dscale = tmp.get<float>(batch), *lam = tmp.get<float>((size_t)batch * n);
+    double *stat = tmp.get<double>(2 * (size_t)batch);
+    int *idx = tmp.get<int>(np), *lgd = tmp.get<int>(np);
+    JSTSP_REQUIRE(W && Wp && (!vecs || (U && Up)) && S && J && Vg && lamJ && dscale && lam && stat && idx && lgd, JSTSP_E_NOMEM,
+                  "eig (order %d, %d matrices): out of device memory", n, batch);
+    const dim3 grid((unsigned)std::min<size_t>((nn + 255) / 256, 4096), (unsigned)batch);
+    hipLaunchKernelGGL(dscale_kernel, dim3(batch), dim3(256), 0, st, n, Gpart, sGt, nsplit, sGs, dscale);
+    hipLaunchKernelGGL(init_kernel, grid, dim3(256), 0, st, n, np, Gpart, sGt, nsplit, sGs, W, U, dscale);
+
+    // relative block permutation between two rounds (circle method on the slots a_k = 2k, b_k = 2k + 1; a_0 stays):
+    // new a_1 <- b_0, new a_k <- a_{k-1} (k >= 2), new b_k <- b_{k+1} (k <= m - 2), new b_{m-1} <- a_{m-1}
+    std::vector<int> src(nb), hidx(np), lg(np), lg2(np);
+    for (int s = 0; s < nb; ++s) src[s] = s;
+    if (m > 1) {
+        src[2] = 1;
+        for (int k = 2; k < m; ++k) src[2 * k] = 2 * (k - 1);
+        for (int k = 0; k + 1 < m; ++k) src[2 * k + 1] = 2 * (k + 1) + 1;
+        src[2 * (m - 1) + 1] = 2 * (m - 1);
     }
-    if (own_w) (void)hipFreeAsync(W, st);
-    if (T) (void)hipFreeAsync(T, st);
-    if (own_d) (void)hipFreeAsync(D, st);
-    (void)hipFreeAsync(E, st);
-    (void)hipFreeAsync(info, st);
-    (void)hipFreeAsync(amax, st);
+    for (int i = 0; i < np; ++i) { hidx[i] = src[i / BS] * BS + i % BS; lg[i] = i; }
+    JSTSP_TRY(upload(ctx, idx, hidx.data(), np * sizeof(int)));
+
+    const int max_sweeps = getenv("JSTSP_BJ_SWEEPS") ? atoi(getenv("JSTSP_BJ_SWEEPS")) : 12;
+    const long long sPanel = (long long)sub * np, sSub = (long long)sub * sub;
+    double prev = -1.0;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        for (int r = 0; r < std::max(1, nb - 1); ++r) {
+            const float2 *Wc = W, *Uc = U;
+            if (m > 1) {                            // partners of this round side by side
+                hipLaunchKernelGGL(permute_kernel, grid, dim3(256), 0, st, np, idx, W, Wp, U, Up);
+                for (int i = 0; i < np; ++i) lg2[i] = lg[hidx[i]];
+                lg.swap(lg2);
+                Wc = Wp; Uc = Up;
+            }
+            hipLaunchKernelGGL(gather_diag_kernel, dim3((unsigned)cnt), dim3(256), 0, st, np, m, Wc, S);
+            JSTSP_HIP(hipGetLastError());
+            // every pair's 128 x 128 sub-problem, exactly (eig.hip: eigenvectors J, columns)
+            JSTSP_TRY(launch_eig(ctx, EIG_VECS, sub, (int)cnt, S, sSub, 1, 0, nullptr, nullptr, J, lamJ, Vg));
+            const Mat Jm{J, sSub, sub};
+            float2 *X = (m > 1) ? W : Wp;           // (the buffer that does not hold Wc)
+            float2 *Xh = (m > 1) ? Wp : W;
+            JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Wc, sPanel, np}, Jm, X, sPanel, np));          // X = W J
+            hipLaunchKernelGGL(conj_transpose_kernel, dim3(np / 32, np / 32, batch), dim3(32, 8), 0, st, np, X, Xh);
+            JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Xh, sPanel, np}, Jm, X, sPanel, np));          // W' = X^H J
+            if (vecs) {
+                float2 *Un = (m > 1) ? U : Up;
+                JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Uc, sPanel, np}, Jm, Un, sPanel, np));      // U' = U J
+                if (m == 1) std::swap(U, Up);
+            }
+            if (m == 1) std::swap(W, Wp);           // (results always end in W / U)
+        }
+        // stop when the off-diagonal mass is at the fp32 level of the matrix, or no longer shrinking
+        JSTSP_HIP(hipMemsetAsync(stat, 0, 2 * (size_t)batch * sizeof(double), st));
+        hipLaunchKernelGGL(offnorm_kernel, grid, dim3(256), 0, st, np, W, stat);
+        std::vector<double> hs(2 * (size_t)batch);
+        JSTSP_HIP(hipMemcpyAsync(hs.data(), stat, hs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        JSTSP_HIP(hipStreamSynchronize(st));
+        double worst = 0.0;
+        for (int t = 0; t < batch; ++t) worst = std::max(worst, hs[2 * t + 1] > 0 ? std::sqrt(hs[2 * t] / hs[2 * t + 1]) : 0.0);
+        if (getenv("JSTSP_BJ_TRACE")) fprintf(stderr, "block Jacobi order %d (%d blocks): sweep %d off/diag %.3e\n", n, nb, sweep, worst);
+        if (worst < 1e-7 * std::sqrt((double)np) || (prev >= 0 && worst > 0.5 * prev && worst < 1e-5)) break;
+        prev = worst;
+    }
+    JSTSP_TRY(upload(ctx, lgd, lg.data(), np * sizeof(int)));
+    float2 *Uout = nullptr;
+    if (mode == EIG_VECS) Uout = Q;
+    else if (mode == EIG_SVT_Q) { Uout = tmp.get<float2>((size_t)batch * n * n); JSTSP_REQUIRE(Uout, JSTSP_E_NOMEM, "eig: out of device memory"); }
+    float *lout = (mode == EIG_VECS) ? lam_out : lam;
+    const dim3 gx((unsigned)std::min<size_t>(((size_t)n * np + 255) / 256, 4096), (unsigned)batch);
+    hipLaunchKernelGGL(extract_kernel, gx, dim3(256), 0, st, n, np, lgd, W, U, Uout, lout);
+    int rcode = 0;
+    if (mode == EIG_LMAX) {
+        hipLaunchKernelGGL(lmax_of_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, n, batch, lam, lam_out);
+    } else if (mode == EIG_SVT_Q) {
+        float2 *T = tmp.get<float2>((size_t)batch * n * n);
+        JSTSP_REQUIRE(T, JSTSP_E_NOMEM, "eig: out of device memory");
+        const dim3 g2((unsigned)std::min<size_t>(((size_t)n * n + 255) / 256, 2048), (unsigned)batch);
+        hipLaunchKernelGGL(scale_cols_kernel, g2, dim3(256), 0, st, n, Uout, lam, prm, tau, T);
+        rcode = gemm(ctx, 'N', 'C', n, n, n, batch, Mat{T, (long long)n * n, n}, Mat{Uout, (long long)n * n, n}, Q, (long long)n * n, n);
+    }
     JSTSP_TRY(rcode);
     JSTSP_HIP(hipGetLastError());
     return 0;

@@ -155,7 +155,7 @@ def _hip_baselines(inp, numOfnz, metric="nmse", noise_var=1.0, tssr=None, vamp_m
         rcond, ns_res = ctx.last_conditioning()
         ls_ok = rcond * rcond >= 1e-6 and ns_res < 1e-2
     out = {"ls": _score(S_ls, zb, metric, noise_var) if ls_ok else nan()}
-    if G2 <= vamp_max_order and inp["A_hbf"].shape[0] <= 128:       # (orders above 128: one rocSOLVER decomposition per trial)
+    if G2 <= vamp_max_order and inp["A_hbf"].shape[0] <= 128:       # (orders above 128: one block-Jacobi decomposition of that order per trial)
         Gb = _times_h(Bh, Bh)                                                            # (B*B')  :79
         Ym = _times_h(inp["Y_hbf"], Bh)                                                  # Y_hbf*B' :80
         out["vamp"] = _score(J.vamp_kron(Ym, inp["A_hbf"], Gb, 1.0, numOfnz), zb, metric, noise_var)   # :100
@@ -239,7 +239,7 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
     ``solve_fn(inputs, Imax) -> (nmse, nmse_angles)`` (two tensors of per-trial NMSE) defaults to the HIP path.
     ``baselines=True`` adds the LS and VAMP columns of plot_errorVSsnr.m:83-105 (HIP path only; VAMP is NaN
     where the delay factor's order L*Gt exceeds ``vamp_max_order`` - 128 by default: above that every trial costs one
-    rocSOLVER eigen-decomposition of that order).  ``dist``: ``torch.distributed`` (initialised) or None.
+    block-Jacobi eigen-decomposition of that order, csrc/eig_large.hip).  ``dist``: ``torch.distributed`` (initialised) or None.
     ``builder``: "hip" — inputs from the library's own kernels (``jstsp_build_trials_c32``; the default with
     the HIP solvers) or "torch" — the tensor-op builder (the default with a custom ``solve_fn``, runs on CPU too).
     The two use different generators, so their curves agree statistically, not sample by sample.

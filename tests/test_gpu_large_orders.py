@@ -1,6 +1,7 @@
 """Orders above 128 (csrc/eig_large.hip: the LDS-resident Jacobi kernels stop at 128; above that the Hermitian
-eigen-decomposition is rocSOLVER's cheevd, loaded on first use): svt / mc_svt of inputs whose BOTH dimensions exceed 128, and
-VAMP on the Kronecker dictionary with G2 = L*Gt > 128 (towards BASELINE configs[4]).  Checked against the float64 oracle."""
+eigen-decomposition is the library's two-sided block Jacobi - 128 x 128 sub-problems on the existing kernel, their
+unitaries applied by batched GEMMs): svt / mc_svt of inputs whose BOTH dimensions exceed 128, and VAMP on the Kronecker
+dictionary with G2 = L*Gt > 128 (towards BASELINE configs[4]).  Checked against the float64 oracle."""
 import numpy as np
 import pytest
 
@@ -16,7 +17,7 @@ def _lowrank(rng, batch, R, C, r, noise):
     return H + noise * (rng.standard_normal((batch, R, C)) + 1j * rng.standard_normal((batch, R, C)))
 
 
-@pytest.mark.parametrize("shape", [(160, 192), (200, 136)])
+@pytest.mark.parametrize("shape", [(160, 192), (200, 136), (130, 131), (320, 400), (512, 640), (700, 520)])
 def test_svt_both_dimensions_above_128(shape):
     from oracle import solvers as O
     rng = np.random.default_rng(3)
@@ -67,7 +68,8 @@ def test_vamp_kron_with_a_large_delay_factor():
 
 
 def test_svt_of_an_input_with_an_exactly_diagonal_gram():
-    """cheevd returns NaN eigenvectors for exactly diagonal matrices: those are decomposed in place (csrc/eig_large.hip)."""
+    """An exactly diagonal Gram: nothing to rotate, the decomposition is the input (rounds 1-2: rocSOLVER's cheevd returned NaN
+    eigenvectors here)."""
     from oracle import solvers as O
     n, C = 136, 200
     Y = np.zeros((n, C), complex)
@@ -99,6 +101,36 @@ def test_proposed_algorithm_and_sparse_admm_above_128():
     Ss, ces = J.sparse_admm(H, OH, F, F, 6)
     Sso, ceso = O.sparse_admm(H, OH, F, F, 6)
     assert rel_err(Ss, Sso) < 3e-4
+
+
+def test_library_has_no_vendor_lapack_dependency():
+    """No rocSOLVER / rocBLAS behind the C ABI any more: neither linked nor dlopen'ed (the order > 128 path is csrc/eig_large.hip)."""
+    import os
+    import subprocess
+    out = subprocess.run(["ldd", J.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rocsolver" not in out and "rocblas" not in out
+    src = os.path.join(os.path.dirname(J.LIB_PATH))
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")):
+            assert "dlopen" not in open(os.path.join(src, f)).read(), f
+
+
+def test_eigen_decomposition_of_order_1024_through_the_kronecker_vamp():
+    """A delay factor of order 1024 (16 blocks of 64): first VAMP iterations against the float64 oracle - they use the
+    eigenvectors and eigenvalues of Gb directly (U^H (.) U, d = la x lb^2)."""
+    from oracle import vamp as V
+    rng = np.random.default_rng(16)
+    Na, Gr, G2, T = 16, 16, 1024, 1400
+    Af = (rng.standard_normal((Na, Gr)) + 1j * rng.standard_normal((Na, Gr))) / np.sqrt(2 * Na)
+    Bh = (rng.standard_normal((G2, T)) + 1j * rng.standard_normal((G2, T))) / np.sqrt(2 * T)
+    Gb = Bh @ Bh.conj().T
+    X0 = np.zeros((Gr, G2), complex)
+    X0.flat[rng.choice(Gr * G2, 30, replace=False)] = 3 * (rng.standard_normal(30) + 1j * rng.standard_normal(30))
+    Y = Af @ X0 @ Gb + 0.05 * (rng.standard_normal((Na, G2)) + 1j * rng.standard_normal((Na, G2)))
+    for nit, tol in ((2, 1e-4), (4, 1e-3)):
+        out = np.asarray(J.vamp_kron(Y, Af, Gb, 1.0, 30, nit=nit))
+        ref = V.vamp_kron(Y, Af, Gb, 1.0, 30, nit=nit)
+        assert rel_err(out, ref) < tol, (nit, rel_err(out, ref))
 
 
 def test_nmse_spectral_above_128():
