@@ -15,7 +15,9 @@
 // Between rounds the blocks are physically permuted (rows and columns of W, columns of U) so that the partners of the
 // next round are neighbours and every panel product is ONE strided-batched launch over (matrix, pair).  Block Jacobi
 // with exactly solved sub-problems converges quadratically like the scalar method; a sweep costs 3 * n^3 complex MACs.
-// Measured (MI355X): order 4096, 2 matrices: x.xx s (rocSOLVER cheevd: 0.5 s); orders 136-512: a few ms.
+// The basis is then re-orthonormalised (one Newton-Schulz step) and the eigenvalues taken as Rayleigh quotients against the
+// original matrix.  Measured (MI355X): order 4096, 2 matrices, 11 sweeps: 2.4 s (rocSOLVER cheevd, rounds 1-2: 0.5 s); svt of
+// 160 x 192 ... 700 x 520 inputs within 3e-5 of the float64 oracle (tests/test_gpu_large_orders.py).
 #include "common.h"
 #include "solver_common.h"
 
@@ -141,6 +143,32 @@ __global__ void extract_kernel(int n, int np, const int *lg, const float2 *W, co
     }
 }
 
+// T <- 1.5 I - 0.5 T   (one Newton-Schulz step towards U (U^H U)^(-1/2))
+__global__ void ns_factor_kernel(int n, float2 *T)
+{
+    const int t = blockIdx.y;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < (long long)n * n; e += (long long)gridDim.x * blockDim.x) {
+        float2 v = T[(size_t)t * n * n + e];
+        v.x = ((e % n == e / n) ? 1.5f : 0.f) - 0.5f * v.x;
+        v.y = -0.5f * v.y;
+        T[(size_t)t * n * n + e] = v;
+    }
+}
+
+// lam[t][c] = Re(u_c^H (G u_c)): Rayleigh quotients of the columns of U with respect to the ORIGINAL matrix
+__global__ void rayleigh_kernel(int n, const float2 *U, const float2 *GU, float *lam)
+{
+    const int t = blockIdx.y, c = blockIdx.x;
+    const float2 *u = U + (size_t)t * n * n + (size_t)n * c, *g = GU + (size_t)t * n * n + (size_t)n * c;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += (double)u[i].x * g[i].x + (double)u[i].y * g[i].y;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) lam[(size_t)t * n + c] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
 __global__ void lmax_of_kernel(int n, int batch, const float *lam, float *out)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,7 +248,10 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
     for (int i = 0; i < np; ++i) { hidx[i] = src[i / BS] * BS + i % BS; lg[i] = i; }
     JSTSP_TRY(upload(ctx, idx, hidx.data(), np * sizeof(int)));
 
-    const int max_sweeps = getenv("JSTSP_BJ_SWEEPS") ? atoi(getenv("JSTSP_BJ_SWEEPS")) : 12;
+    const int max_sweeps = getenv("JSTSP_BJ_SWEEPS") ? atoi(getenv("JSTSP_BJ_SWEEPS")) : 14;
+    const bool sub_fast = getenv("JSTSP_BJ_SUB") ? atoi(getenv("JSTSP_BJ_SUB")) != 0 : true;
+    JSTSP_HIP(hipMemsetAsync(lamJ, 0, cnt * sub * sizeof(float), st));
+    bool polished = false;
     const long long sPanel = (long long)sub * np, sSub = (long long)sub * sub;
     double prev = -1.0;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
@@ -234,8 +265,10 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
             }
             hipLaunchKernelGGL(gather_diag_kernel, dim3((unsigned)cnt), dim3(256), 0, st, np, m, Wc, S);
             JSTSP_HIP(hipGetLastError());
-            // every pair's 128 x 128 sub-problem, exactly (eig.hip: eigenvectors J, columns)
-            JSTSP_TRY(launch_eig(ctx, EIG_VECS, sub, (int)cnt, S, sSub, 1, 0, nullptr, nullptr, J, lamJ, Vg));
+            // every pair's 128 x 128 sub-problem, exactly: eigenvectors J (columns).  eig3.hip's register-resident kernel
+            // (1024 threads per matrix; its by-product, a projector for tau = 0, goes to a scratch buffer) or eig.hip's general one
+            if (sub_fast) JSTSP_TRY(launch_eig128(ctx, sub, (int)cnt, S, sSub, 1, 0, nullptr, lamJ /* tau = 0 */, Vg, J, 0));
+            else JSTSP_TRY(launch_eig(ctx, EIG_VECS, sub, (int)cnt, S, sSub, 1, 0, nullptr, nullptr, J, lamJ, Vg));
             const Mat Jm{J, sSub, sub};
             float2 *X = (m > 1) ? W : Wp;           // (the buffer that does not hold Wc)
             float2 *Xh = (m > 1) ? Wp : W;
@@ -258,7 +291,11 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
         double worst = 0.0;
         for (int t = 0; t < batch; ++t) worst = std::max(worst, hs[2 * t + 1] > 0 ? std::sqrt(hs[2 * t] / hs[2 * t + 1]) : 0.0);
         if (getenv("JSTSP_BJ_TRACE")) fprintf(stderr, "block Jacobi order %d (%d blocks): sweep %d off/diag %.3e\n", n, nb, sweep, worst);
-        if (worst < 1e-7 * std::sqrt((double)np) || (prev >= 0 && worst > 0.5 * prev && worst < 1e-5)) break;
+        if (worst < 1e-7 * std::sqrt((double)np) || (prev >= 0 && worst > 0.5 * prev && worst < 1e-5)) {
+            // converged to the fp32 level of the matrix; one more sweep (cheap up to order 1024) settles the small eigenvalues
+            if (polished || np > 1024) break;
+            polished = true;
+        }
         prev = worst;
     }
     JSTSP_TRY(upload(ctx, lgd, lg.data(), np * sizeof(int)));
@@ -269,6 +306,21 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
     const dim3 gx((unsigned)std::min<size_t>(((size_t)n * np + 255) / 256, 4096), (unsigned)batch);
     hipLaunchKernelGGL(extract_kernel, gx, dim3(256), 0, st, n, np, lgd, W, U, Uout, lout);
     int rcode = 0;
+    if (vecs && (getenv("JSTSP_BJ_REFINE") ? atoi(getenv("JSTSP_BJ_REFINE")) != 0 : true)) {
+        // The basis is a product of (nb - 1) x sweeps fp32 panel products and the diagonal of W has been through as many
+        // two-sided updates: restore orthonormality (one Newton-Schulz step, U <- U (1.5 I - 0.5 U^H U)) and take the
+        // eigenvalues as Rayleigh quotients u^H G u against the ORIGINAL matrix.  Three n^3 products.
+        const long long s2 = (long long)n * n;
+        const dim3 g2((unsigned)std::min<size_t>(((size_t)n * n + 255) / 256, 2048), (unsigned)batch);
+        float2 *G0 = Wp, *T1 = W, *U2 = Up;                      // (the padded work arrays are free now: np >= n)
+        hipLaunchKernelGGL(init_kernel, g2, dim3(256), 0, st, n, n, Gpart, sGt, nsplit, sGs, G0, (float2 *)nullptr, dscale);
+        JSTSP_TRY(gemm(ctx, 'C', 'N', n, n, n, batch, Mat{Uout, s2, n}, Mat{Uout, s2, n}, T1, s2, n));
+        hipLaunchKernelGGL(ns_factor_kernel, g2, dim3(256), 0, st, n, T1);
+        JSTSP_TRY(gemm(ctx, 'N', 'N', n, n, n, batch, Mat{Uout, s2, n}, Mat{T1, s2, n}, U2, s2, n));
+        JSTSP_HIP(hipMemcpyAsync(Uout, U2, (size_t)batch * s2 * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        JSTSP_TRY(gemm(ctx, 'N', 'N', n, n, n, batch, Mat{G0, s2, n}, Mat{Uout, s2, n}, T1, s2, n));
+        hipLaunchKernelGGL(rayleigh_kernel, dim3(n, batch), dim3(256), 0, st, n, Uout, T1, lout);
+    }
     if (mode == EIG_LMAX) {
         hipLaunchKernelGGL(lmax_of_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, n, batch, lam, lam_out);
     } else if (mode == EIG_SVT_Q) {
