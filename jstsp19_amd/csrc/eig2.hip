@@ -507,6 +507,7 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *G = reinterpret_cast<float2 *>(smem_raw);       // [NE][LD], zero padded (staging only)
     float2 *part = G + NE * LD;                             // [2][4 waves][NE] partial products
+    int *sflag = reinterpret_cast<int *>(part + 2 * 4 * NE);   // [2]: wave 0's "Krylov space exhausted" of step j, slot j & 1
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     for (int e = tid; e < NE * NE; e += 256) {
@@ -597,6 +598,10 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
         for (int r = 0; r < R; ++r)
             pw[wave * NE + lane + 64 * r] = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
         __syncthreads();
+        // The ONLY data-dependent exit: wave 0's verdict on the previous step, read by every wave from one LDS word behind
+        // the barrier above - the number of barriers each wave executes cannot differ, whatever the four waves' redundant
+        // arithmetic does (round 2 relied on it being bitwise identical; the step computed in between is discarded).
+        if (j > 0 && sflag[(j - 1) & 1]) break;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = lane + 64 * r;
@@ -622,7 +627,8 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
         for (int r = 0; r < R; ++r)
             if (lane + 64 * r == j) { dl[r] = alpha; el[r] = last ? 0.f : bb; }
         m = j + 1;
-        if (last) break;                    // identical in every wave: no barrier is skipped by a subset
+        if (wave == 0 && lane == 0) sflag[j & 1] = last ? 1 : 0;
+        if (j == n - 1) break;              // (uniform: n is a kernel argument)
         const float ib = 1.f / bnew;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -634,13 +640,26 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
 
     // ---- Gershgorin bounds of T_m, then 256-way multisection for its largest eigenvalue: every wave takes 64 of
     //      the candidates (all four hold identical copies of d / e^2), the waves' results meet in LDS
+    // d / e^2 and the step count to LDS: WAVE 0's copies are the ones every wave works with from here on (uniform-address
+    // reads broadcast and run ahead of the serial Sturm recurrence).  The staging copy of G is dead since the first step's
+    // barrier; `part` may still be read by slower waves.
+    float *sd = reinterpret_cast<float *>(G);               // [NE] d, [NE] e2, then [2][4] firsts, then m
+    float *se = sd + NE;
+    int *sfirst = reinterpret_cast<int *>(se + NE);
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { sd[lane + 64 * r] = dl[r]; se[lane + 64 * r] = (lane + 64 * r == m - 1) ? 0.f : el[r]; }
+        if (lane == 0) sfirst[8] = m;
+    }
+    __syncthreads();
+    m = sfirst[8];
     float lo, hi;
     {
         float emax = 0.f, dmin = 3.0e38f, dmax = -3.0e38f;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = lane + 64 * r;
-            if (i < m) { emax = fmaxf(emax, sqrtf(el[r])); dmin = fminf(dmin, dl[r]); dmax = fmaxf(dmax, dl[r]); }
+            if (i < m) { emax = fmaxf(emax, sqrtf(se[i])); dmin = fminf(dmin, sd[i]); dmax = fmaxf(dmax, sd[i]); }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -651,16 +670,6 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
         lo = dmin - 2.f * emax;             // every Gershgorin disc lies inside [dmin - 2 emax, dmax + 2 emax]
         hi = dmax + 2.f * emax;
     }
-    // d / e^2 to LDS (uniform-address reads broadcast and run ahead of the serial Sturm recurrence).  The staging copy
-    // of G is dead since the first step's barrier; `part` may still be read by slower waves.
-    float *sd = reinterpret_cast<float *>(G);               // [NE] d, [NE] e2, then [2][4] firsts
-    float *se = sd + NE;
-    int *sfirst = reinterpret_cast<int *>(se + NE);
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { sd[lane + 64 * r] = dl[r]; se[lane + 64 * r] = el[r]; }
-    }
-    __syncthreads();
     const float span0 = fmaxf(hi - lo, 1e-30f);
     hi += 1e-6f * span0 + 1e-30f;
     for (int round = 0; round < 4; ++round) {
@@ -764,7 +773,7 @@ template <int NE>
 static int launch_lanczos_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
                             long long sGs, float *lam_out)
 {
-    const size_t sh = ((size_t)NE * (NE + 1) + 2 * 4 * NE) * sizeof(float2);
+    const size_t sh = ((size_t)NE * (NE + 1) + 2 * 4 * NE) * sizeof(float2) + 16;      // (+ the two exit flags)
     JSTSP_HIP(hipFuncSetAttribute((const void *)lanczos_lmax_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh));
     hipLaunchKernelGGL((lanczos_lmax_kernel<NE>), dim3(batch), dim3(256), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs,
