@@ -36,3 +36,24 @@ def test_graft_entry_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_bench_host_path_and_sweep_mode_small_shape():
+    """The line carries the drop-in (JSTSP_HOST) rate next to the device-resident value, and `--sweep` (BASELINE configs[3]
+    at the reference-native shape here) prints one line with the per-point mean NMSE of both solvers."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--steps", "1", "--warmup", "0",
+                        "--batch", "8", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    hp = j["host_path"]
+    assert hp["value"] > 0 and hp["bit_identical_to_device_call"] is True and hp["h2d_gib"] > 0
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--small", "--sweep", "--sweep-trials", "16", "--batch",
+                        "16"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["scaling"] == "strong" and "configs[3]" in j["config"]["workload"]
+    assert len(j["snr_db"]) == 11 == len(j["mean_nmse_proposed"]) == len(j["mean_nmse_angles"])
+    assert all(0 < a <= b <= 1 for a, b in zip(j["mean_nmse_angles"], j["mean_nmse_proposed"]))     # the genie support helps
+    assert abs(j["value"] - 2 * 11 * 16 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
