@@ -750,6 +750,11 @@ int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gp
     if (n <= 32)
         return launch_jacobi2_t<32, 256>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
                                          skip_amax);
+    // JSTSP_JACOBI_NT=512: half the threads per matrix, two 2 x 2 blocks each (a lighter resident: 8 instead of 16 waves per CU)
+    static const int nt64 = getenv("JSTSP_JACOBI_NT") ? atoi(getenv("JSTSP_JACOBI_NT")) : 1024;
+    if (nt64 == 512)
+    return launch_jacobi2_t<64, 512>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
+                                      skip_amax);
     return launch_jacobi2_t<64, 1024>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
                                       skip_amax);
 }

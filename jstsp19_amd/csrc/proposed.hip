@@ -362,6 +362,9 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // With that, the Gram partials of the three norms are double-buffered by iteration parity (gn / gn2) and ALL three
     // lambda_max of an iteration are ONE launch (3 x batch matrices fill the chip once) instead of two half-empty ones.
     const int ce_gate = getenv("JSTSP_CE_GATE") ? atoi(getenv("JSTSP_CE_GATE")) : 1;
+    const int svt_order_env = getenv("JSTSP_SVT_ORDER") ? atoi(getenv("JSTSP_SVT_ORDER")) : 0;
+    const int svt_gatepos = getenv("JSTSP_SVT_GATEPOS") ? atoi(getenv("JSTSP_SVT_GATEPOS")) : 0;
+    hipEvent_t ev_q1 = ctx->ev[7];
     const bool dbuf = ce_gate && fusedp && zfly && want_ce;
     auto gn_of = [&](int i) -> GramWS & { return (dbuf && (i & 1)) ? w.gn2 : w.gn; };
     int ce_pending = -1;
@@ -421,11 +424,14 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(launch_update_x(ctx, snm, batch, w.X, w.V1, w.V2, w.C, w.Xs, w.Y, subY, w.invD, w.prm, w.ZK));
         }
         JSTSP_HIP(hipEventRecord(ev_x, sm));
-        if (it + 1 < Imax) {        // s1: next iteration's Z, Gram, eigen-decomposition
-            JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
+        // s1: next iteration's Z, Gram, eigen-decomposition.  stage 0: all of it; 1: up to the Gram pass; 2: from the
+        // eigen-decomposition on (JSTSP_SVT_ORDER: where in the window the two halves are issued, see below)
+        auto issue_s1 = [&](int stage) -> int {
+            if (stage != 2) JSTSP_HIP(hipStreamWaitEvent(s1, ev_x, 0));
             StreamScope sc(ctx, s1);
-            if (!fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
+            if (stage != 2 && !fz) JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, Zn));   // fused: written by the epilogue
             if (zfly) {
+              if (stage != 2) {
                 // (the spectral norms of X, V1 of the previous iteration read the G_x, G_v1 partials this pass overwrites)
                 // (double-buffered: the buffer of this parity was last read by the lambda_max launch of iteration it - 2)
                 if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, dbuf ? ev_ce : ev_lxv, 0));
@@ -447,6 +453,8 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
                     JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 0, 2 * batch, w.lam, true));
                     JSTSP_HIP(hipEventRecord(ev_lxv, s2));
                 }
+              }
+              if (stage == 1) return 0;
                 JSTSP_TRY(svt_prepare(ctx, w.gz, w.X, w.prm, nullptr, true, w.zmax, svt_skip, nullptr, true));
                 if (fusedy) {       // the pass at the end of this iteration forms Y = (I - Q) Z itself: fragments of I - Q
                     JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
@@ -464,6 +472,16 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
                 if (fusedy) JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
             }
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
+            return 0;
+        };
+        // JSTSP_SVT_ORDER (fused pass with convergence_error only): 0 - the whole side chain starts with the window; 1 - it
+        // starts when the gradient step's bandwidth-heavy head (partial sums ... (G_A Res) G_B) is through; 2 - the Gram pass
+        // starts with the window, the eigen-decomposition behind that head (a resident Jacobi workgroup leaves the G_B apply
+        // no room on its CU: profiles/r03_fused_iteration_timeline.txt)
+        const int svt_order = (passed && fusedp && zfly && it + 1 < Imax) ? svt_order_env : 0;
+        if (it + 1 < Imax) {
+            if (svt_order == 0) JSTSP_TRY(issue_s1(0));
+            else if (svt_order == 2) JSTSP_TRY(issue_s1(1));
         }
         if (want_ce && !(zfly && it + 1 < Imax)) {              // s2: Gram of [X | V1]
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_x, 0));
@@ -512,7 +530,17 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
                            -1.f));
             //    R*res for alpha = res'*res / (res'*R*res)                                    (:48)
+            if (svt_order && svt_gatepos == 1) {       // (gate behind the first product of the step only)
+                JSTSP_HIP(hipEventRecord(ev_q1, sm));
+                JSTSP_HIP(hipStreamWaitEvent(s1, ev_q1, 0));
+                JSTSP_TRY(issue_s1(svt_order == 1 ? 0 : 2));
+            }
             JSTSP_TRY(apply_R(w.Res, w.RRes));
+            if (svt_order && svt_gatepos == 0) {
+                JSTSP_HIP(hipEventRecord(ev_q1, sm));
+                JSTSP_HIP(hipStreamWaitEvent(s1, ev_q1, 0));
+                JSTSP_TRY(issue_s1(svt_order == 1 ? 0 : 2));
+            }
             //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
                                     Imax, it, rv_refresh > 1 ? w.RV : nullptr));
