@@ -310,8 +310,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // With the fused pass the work between two passes is three short independent chains (Gram + eigen-decomposition of
     // the next Z | partial sums -> gradient step -> A S | spectral norms): there the side streams are on by default
     // (4.35 -> 4.21 ms per iteration at configs[1]).
-    const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0
-                                                 : (want_fused && !(getenv("JSTSP_SVT_SKIP") && atoi(getenv("JSTSP_SVT_SKIP")) != 0));
+    const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0 : want_fused;
     uint32_t *const kmax0 = w.kmax;
     JSTSP_TRY(ensure_side_streams(ctx));
     hipStream_t sm = ctx->stream, s1 = overlap ? ctx->side[0] : sm, s2 = overlap ? ctx->side[1] : sm;
@@ -341,7 +340,9 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // Y = (I - Q) Z formed inside the pass (JSTSP_FUSED_Y=0: by a GEMM before it, from X and V1)
     const bool fy_env = getenv("JSTSP_FUSED_Y") ? atoi(getenv("JSTSP_FUSED_Y")) != 0 : true;
     // with convergence_error: G_z comes from the three-Gram pass over X, V1 (zfly); without: from the Z the pass stores
-    const bool fusedp = want_fused && hmax && !svt_skip && (want_ce ? zfly : fy_env);
+    // (round 3: the opt-in short-cut JSTSP_SVT_SKIP=1 no longer switches the pass off - a skipped trial's Q = 0 becomes
+    //  I - Q = I in the pass's fragments)
+    const bool fusedp = want_fused && hmax && (want_ce ? zfly : fy_env);
     const bool fusedy = fusedp && fy_env;
     FusedWS fw;
     if (fusedp) {
