@@ -343,7 +343,7 @@ def main():
         except (OSError, ValueError):
             pass
         nthr = a.cpu_threads or (min(phys, quota) if quota else phys)
-        nt = min(a.batch, a.cpu_trials if a.cpu_trials > 0 else 3 * nthr)     # about 15-20 s of host work
+        nt = min(a.batch, a.cpu_trials if a.cpu_trials > 0 else min(3 * nthr, 64))     # about 15-20 s of host work
         try:                                                       # tuned for the host it is timed on
             lib = bp.load(bp.build(native=True, out=os.path.join(tempfile.mkdtemp(prefix="jstsp_cpu_"), "libjstsp_cpu_port.so")))
             tuned = "-march=native"
