@@ -57,3 +57,17 @@ def test_bench_host_path_and_sweep_mode_small_shape():
     assert len(j["snr_db"]) == 11 == len(j["mean_nmse_proposed"]) == len(j["mean_nmse_angles"])
     assert all(0 < a <= b <= 1 for a, b in zip(j["mean_nmse_angles"], j["mean_nmse_proposed"]))     # the genie support helps
     assert abs(j["value"] - 2 * 11 * 16 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+
+
+def test_bench_under_the_launcher_with_one_rank_uses_rccl():
+    """The multi-GPU code path with the one GPU a test box has: torch.distributed.run starts ONE rank, bench.py initialises
+    the RCCL process group (WORLD_SIZE is set), barriers, all-reduces the timing MAX and the NMSE sum, and prints the line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in (["--steps", "1", "--warmup", "0", "--batch", "8", "--no-cpu-baseline", "--no-host-path"],
+                  ["--sweep", "--sweep-trials", "8", "--batch", "8"]):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                            "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--small"] + extra,
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1 and json.loads(lines[0])["value"] > 0
