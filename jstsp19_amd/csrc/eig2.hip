@@ -497,33 +497,25 @@ __global__ __launch_bounds__(256) void lmax_kernel(int n, const float2 *Gpart, l
 // convergence_error ratios of proposed_algorithm.m:67,69 take this path (three matrices per trial and iteration);
 // the Householder + Sturm kernel above (1e-7) stays for jstsp_nmse_spectral_c32.  Largest eigenvalue of the
 // tridiagonal matrix by 64-way multisection on the Sturm count, d / e^2 held one entry per lane.
-template <int NE>
-__global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
+// NW waves per matrix (4: lowest latency - the default of rounds 1-2; 1: no exchange, no barrier, no redundant reductions -
+// a quarter of the instructions per matrix at four times the latency)
+template <int NE, int NW>
+__global__ __launch_bounds__(64 * NW) void lanczos_lmax_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
                                                            long long sGs, float *lam_out)
 {
     constexpr int R = NE / 64;              // components per lane
-    constexpr int KW = NE / 4;              // columns of G per wave
-    constexpr int LD = NE + 1;
+    constexpr int KW = NE / NW;             // columns of G per wave
+    constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float2 *G = reinterpret_cast<float2 *>(smem_raw);       // [NE][LD], zero padded (staging only)
-    float2 *part = G + NE * LD;                             // [2][4 waves][NE] partial products
-    int *sflag = reinterpret_cast<int *>(part + 2 * 4 * NE);   // [2]: wave 0's "Krylov space exhausted" of step j, slot j & 1
+    // LDS: only the exchange of the partial products and the tridiagonal matrix (round 3: the matrix itself is no longer
+    // staged here - 33 KiB per workgroup for the kernel's whole life kept eigen-decomposition workgroups, 101 KiB, off the CU)
+    float2 *part = reinterpret_cast<float2 *>(smem_raw);       // [2][NW waves][NE] partial products
+    int *sflag = reinterpret_cast<int *>(part + 2 * NW * NE);   // [2]: wave 0's "Krylov space exhausted" of step j, slot j & 1
+    float *sd = reinterpret_cast<float *>(sflag + 4);          // [NE] d, [NE] e2, then [2][4] firsts, then m
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int e = tid; e < NE * NE; e += 256) {
-        const int i = e % NE, j = e / NE;
-        float2 g = make_float2(0.f, 0.f);
-        if (i < n && j < n) {
-            const float2 *src = Gpart + (long long)t * sGt + i + (long long)n * j;
-            for (int s = 0; s < nsplit; ++s) {
-                const float2 x = src[(long long)s * sGs];
-                g.x += x.x; g.y += x.y;
-            }
-        }
-        G[i + LD * j] = g;
-    }
-    __syncthreads();
-    // this wave's columns, Hermitian part (the Gram is Hermitian only up to rounding): g(i,k) = (G(i,k) + conj(G(k,i)))/2
+    // this wave's columns straight from memory: lane i owns row i (coalesced), the split-K partials summed on the way.
+    // (The Gram is Hermitian up to the rounding of its MFMA sums, 1e-7 relative: its stored entries are used as they are.)
     float2 grow[KW * R];
     const int kbase = wave * KW;
 #pragma unroll
@@ -531,8 +523,16 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = lane + 64 * r, k = kbase + kk;
-            const float2 a = G[i + LD * k], b = G[k + LD * i];
-            grow[kk * R + r] = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            float2 g = make_float2(0.f, 0.f);
+            if (i < n && k < n) {
+                const float2 *src = Gpart + (long long)t * sGt + i + (long long)n * k;
+                for (int s = 0; s < nsplit; ++s) {
+                    const float2 x = src[(long long)s * sGs];
+                    g.x += x.x; g.y += x.y;
+                }
+                if (i == k) g.y = 0.f;
+            }
+            grow[kk * R + r] = g;
         }
 
     auto bcast = [](float x, int k) {       // k is wave-uniform
@@ -593,11 +593,13 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
                 py[r][kk & 1] = fmaf(g.y, vx, py[r][kk & 1]);
             }
         }
-        float2 *pw = part + (j & 1) * 4 * NE;
+        float2 *pw = part + (j & 1) * NW * NE;
+        if constexpr (NW > 1) {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-            pw[wave * NE + lane + 64 * r] = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
-        __syncthreads();
+            for (int r = 0; r < R; ++r)
+                pw[wave * NE + lane + 64 * r] = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
+            __syncthreads();
+        }
         // The ONLY data-dependent exit: wave 0's verdict on the previous step, read by every wave from one LDS word behind
         // the barrier above - the number of barriers each wave executes cannot differ, whatever the four waves' redundant
         // arithmetic does (round 2 relied on it being bitwise identical; the step computed in between is discarded).
@@ -605,9 +607,17 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = lane + 64 * r;
-            const float2 p0 = pw[i], p1 = pw[NE + i], p2 = pw[2 * NE + i], p3 = pw[3 * NE + i];
-            u[r] = make_float2(((p0.x + p1.x) + (p2.x + p3.x)) - beta * vp[r].x,
-                               ((p0.y + p1.y) + (p2.y + p3.y)) - beta * vp[r].y);
+            float2 ps;
+            if constexpr (NW == 4) {
+                const float2 p0 = pw[i], p1 = pw[NE + i], p2 = pw[2 * NE + i], p3 = pw[3 * NE + i];
+                ps = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+            } else if constexpr (NW == 2) {
+                const float2 p0 = pw[i], p1 = pw[NE + i];
+                ps = make_float2(p0.x + p1.x, p0.y + p1.y);
+            } else {
+                ps = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
+            }
+            u[r] = make_float2(ps.x - beta * vp[r].x, ps.y - beta * vp[r].y);
         }
         float a = 0.f;
 #pragma unroll
@@ -641,9 +651,7 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
     // ---- Gershgorin bounds of T_m, then 256-way multisection for its largest eigenvalue: every wave takes 64 of
     //      the candidates (all four hold identical copies of d / e^2), the waves' results meet in LDS
     // d / e^2 and the step count to LDS: WAVE 0's copies are the ones every wave works with from here on (uniform-address
-    // reads broadcast and run ahead of the serial Sturm recurrence).  The staging copy of G is dead since the first step's
-    // barrier; `part` may still be read by slower waves.
-    float *sd = reinterpret_cast<float *>(G);               // [NE] d, [NE] e2, then [2][4] firsts, then m
+    // reads broadcast and run ahead of the serial Sturm recurrence).
     float *se = sd + NE;
     int *sfirst = reinterpret_cast<int *>(se + NE);
     if (wave == 0) {
@@ -672,10 +680,11 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
     }
     const float span0 = fmaxf(hi - lo, 1e-30f);
     hi += 1e-6f * span0 + 1e-30f;
-    for (int round = 0; round < 4; ++round) {
+    constexpr int NROUND = NW == 4 ? 4 : (NW == 2 ? 5 : 6);         // (64 NW + 1)^NROUND >= 3e10 sub-intervals
+    for (int round = 0; round < NROUND; ++round) {
         // candidates x_c = lo + (c+1) (hi-lo)/257, c = 64 wave + lane; count(x) = #eigenvalues < x;
         // lambda_max in (x_first-1, x_first]
-        const float step = (hi - lo) / 257.f;
+        const float step = (hi - lo) / (float)(NT + 1);
         const float x = lo + (64 * wave + lane + 1) * step;
         float q = 1.f, eprev = 0.f;
         int c = 0;
@@ -686,12 +695,14 @@ __global__ __launch_bounds__(256) void lanczos_lmax_kernel(int n, const float2 *
             eprev = se[i];
         }
         const unsigned long long full = __ballot(c >= m);            // candidates above every eigenvalue
-        if (lane == 0) sfirst[(round & 1) * 4 + wave] = full ? 64 * wave + (int)__ffsll((long long)full) - 1 : 256;
+        if (lane == 0) sfirst[(round & 1) * 4 + wave] = full ? 64 * wave + (int)__ffsll((long long)full) - 1 : NT;
         __syncthreads();
         const int *sf = sfirst + (round & 1) * 4;
-        const int first = min(min(sf[0], sf[1]), min(sf[2], sf[3]));
+        int first = sf[0];
+#pragma unroll
+        for (int wv = 1; wv < NW; ++wv) first = min(first, sf[wv]);
         const float nlo = lo + first * step;
-        const float nhi = (first < 256) ? lo + (first + 1) * step : hi;
+        const float nhi = (first < NT) ? lo + (first + 1) * step : hi;
         lo = nlo; hi = nhi;
     }
     if (wave != 0) return;
@@ -774,14 +785,14 @@ static int launch_lmax_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, 
     return 0;
 }
 
-template <int NE>
+template <int NE, int NW>
 static int launch_lanczos_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
                             long long sGs, float *lam_out)
 {
-    const size_t sh = ((size_t)NE * (NE + 1) + 2 * 4 * NE) * sizeof(float2) + 16;      // (+ the two exit flags)
-    JSTSP_HIP(hipFuncSetAttribute((const void *)lanczos_lmax_kernel<NE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t sh = (size_t)2 * NW * NE * sizeof(float2) + 16 + (size_t)(2 * NE + 16) * sizeof(float);   // exchange, flags, T
+    JSTSP_HIP(hipFuncSetAttribute((const void *)lanczos_lmax_kernel<NE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh));
-    hipLaunchKernelGGL((lanczos_lmax_kernel<NE>), dim3(batch), dim3(256), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs,
+    hipLaunchKernelGGL((lanczos_lmax_kernel<NE, NW>), dim3(batch), dim3(64 * NW), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs,
                        lam_out);
     JSTSP_HIP(hipGetLastError());
     return 0;
@@ -796,8 +807,12 @@ int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long
     JSTSP_REQUIRE(n >= 1, JSTSP_E_UNSUPPORTED, "launch_lmax: n = %d", n);
     const bool lz = lanczos && (getenv("JSTSP_LANCZOS") ? atoi(getenv("JSTSP_LANCZOS")) != 0 : true);
     if (lz) {
-        if (n <= 64) return launch_lanczos_t<64>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
-        return launch_lanczos_t<128>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+        // waves per matrix at order <= 64 (JSTSP_LANCZOS_NW = 1 / 2 / 4)
+        const int nw = getenv("JSTSP_LANCZOS_NW") ? atoi(getenv("JSTSP_LANCZOS_NW")) : 4;
+        if (n <= 64 && nw == 1) return launch_lanczos_t<64, 1>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+        if (n <= 64 && nw == 2) return launch_lanczos_t<64, 2>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+        if (n <= 64) return launch_lanczos_t<64, 4>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+        return launch_lanczos_t<128, 4>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
     }
     if (n <= 32) return launch_lmax_t<32>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
     if (n <= 64) return launch_lmax_t<64>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
