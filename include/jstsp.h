@@ -132,6 +132,14 @@ int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
  * that is a measurement of the reference's system model. */
 int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count);
 
+/* Structure the last jstsp_proposed_algorithm_c32/_c64 call on this context found in its dictionary B (G2 x M).  The
+ * dictionaries of the reference's drivers stack L delayed copies of one pilot frame under the transmit steering vectors
+ * (errorVSsnr.m:36-47), which makes them block-Toeplitz: B(ld*Gt + g, m) == B(g, m - ld) for m >= ld, G2 = L*Gt.  The
+ * library PROBES that (exact comparison of every entry, once per call) and, where it holds, streams only the first block
+ * in each iteration; results are bit-identical to the unstructured path.  *gt = the block height used, 0 = none found
+ * (any B is accepted; an unstructured one just costs the full read).  JSTSP_TOEPLITZ=0 in the environment skips the probe. */
+int jstsp_last_dictionary_block(jstsp_ctx *ctx, int *gt);
+
 /* S_ls = pinv(A)*Y*pinv(B)   — the LS baseline of the drivers (plot_errorVSsnr.m:83).
  * Factors that fit the in-LDS float64 pinv kernel (see jstsp_pinv_c32; every shape the reference's drivers use)
  * get MATLAB's SVD-based pinv, any rank, any aspect ratio.  Larger factors take the fp32 Gram-inverse route

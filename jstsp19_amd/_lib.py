@@ -58,6 +58,7 @@ SIGNATURES = {
     "jstsp_pinv_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
     "jstsp_last_conditioning": (c_int, [c_void_p, c_dp, c_dp]),
     "jstsp_last_fused_fallbacks": (c_int, [c_void_p, c_ip]),
+    "jstsp_last_dictionary_block": (c_int, [c_void_p, c_ip]),
     "jstsp_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_dp, c_void_p, c_int]),
     "jstsp_omp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p,
                               c_void_p, c_void_p, c_int]),
@@ -179,6 +180,12 @@ class Context:
         """Trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass."""
         n = C.c_int(0)
         check(self._lib.jstsp_last_fused_fallbacks(self.handle, C.byref(n)), "jstsp_last_fused_fallbacks")
+        return int(n.value)
+
+    def last_dictionary_block(self):
+        """Block height of the block-Toeplitz structure the last proposed_algorithm call found in its dictionary (0: none)."""
+        n = C.c_int(0)
+        check(self._lib.jstsp_last_dictionary_block(self.handle, C.byref(n)), "jstsp_last_dictionary_block")
         return int(n.value)
 
     def last_conditioning(self):

@@ -112,6 +112,7 @@ struct jstsp_ctx {
     // float bits of [0] the smallest sigma_min/sigma_max met by the float64 pinv kernel, [1] the largest Newton-Schulz
     // residual max|I - G X|, [2] the smallest lambda_min/lambda_max of an eigen-inverted factor Gram
     uint32_t *diag = nullptr;
+    int last_dict_block = 0;     // block height of the block-Toeplitz structure the last fused solve found in its dictionary (0: none)
     int fused_fallbacks = 0;     // trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

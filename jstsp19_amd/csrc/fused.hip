@@ -26,7 +26,9 @@
 // Shapes: N = 64, G2 = 128, 256, 384 or 512 (GB = G2 / 128 blocks of 16 rows g per wave), M a multiple of 32 * parts.
 // Everything else keeps the three-kernel path.
 #include "solver_common.h"
+#include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 
 namespace jstsp {
 namespace {
@@ -118,12 +120,143 @@ __global__ __launch_bounds__(256) void pack_bf_kernel(const float2 *B, long long
     for (int p = 0; p < 4; ++p) o[(((long long)(blk * 4 + p) * 8 + mq) * 2 + g8i) * 4 + r] = *reinterpret_cast<uint4 *>(&pl[p]);
 }
 
+// ---- Block-Toeplitz dictionaries.  The dictionaries the reference's drivers build (B = the pilot frame delayed by ld samples
+//      under every transmit steering vector: system_model.m / errorVSsnr.m:36-47) satisfy, bit for bit,
+//          B(ld Gt + g, m) == B(g, m - ld)     for m >= ld,   ld = 0 .. L - 1,  G2 = L Gt:
+//      block ld is block 0 shifted right by ld columns; only the ld leading columns of block ld differ.  The property is
+//      a fact about the DATA, so it is probed (exact comparison of every entry, all candidate block heights in one pass)
+//      and never assumed.  When it holds, the tile image shrinks L-fold: one 16-byte chunk (8 rows g of one column m, one
+//      plane) of block ld is the chunk of block 0 at column m - ld, so the pass's refill reads the COMPACT image
+//          E[p 4][g8' Gt/8][halo | columns 0 .. M-1]
+//      at shifted columns; the L re-reads of a chunk by the L waves of a workgroup hit in L2 / L1 instead of HBM, and the
+//      LDS tile - hence every product and every result bit - is the same as with the full image.  The columns m < ld of
+//      block ld live in the halo: chunk (ld, c = m - ld < 0) at index c - ld (ld - 1) / 2 relative to column 0.
+__global__ __launch_bounds__(256) void toeplitz_probe_kernel(const float2 *B, long long sBt, int G2, int M, uint32_t cand, uint32_t *mism)
+{
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;   // (G2 M < 2^31)
+    uint32_t bad = 0;
+    if (idx < (uint32_t)G2 * (uint32_t)M) {
+        const int m = (int)(idx / (uint32_t)G2), g = (int)(idx - (uint32_t)m * (uint32_t)G2);
+        const uint2 *b = reinterpret_cast<const uint2 *>(B) + (long long)blockIdx.y * sBt;
+        const uint2 x = b[idx];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {                       // candidate block heights 16 .. 256
+            const int gt = 16 << c, ld = g >> (4 + c);
+            if (!((cand >> c) & 1u) || ld == 0 || m < ld) continue;
+            const uint2 y = b[idx - (uint32_t)gt - (uint32_t)G2];
+            if (x.x != y.x || x.y != y.y) bad |= 1u << c;
+        }
+    }
+    // (the wrong candidates fail almost everywhere: one atomic per wave, and only for bits that are not raised yet)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && (bad & ~__atomic_load_n(mism, __ATOMIC_RELAXED))) atomicOr(mism, bad);
+}
+
+__global__ __launch_bounds__(256) void pack_e_kernel(const float2 *B, long long sBt, int G2, int M, int gt, int ecols, int ehalo,
+                                                     const uint32_t *bmax, int sbmax, uint4 *out, long long sOut)
+{
+    const int t = blockIdx.y;
+    const int G8t = gt >> 3, L = G2 / gt;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)G8t * ecols) return;
+    const int g8 = (int)(idx % G8t), j = (int)(idx / G8t);  // g fastest: coalesced reads of B
+    int row0 = 8 * g8, m = j - ehalo;
+    bool live = true;
+    if (m < 0) {                                            // halo: chunk (ld, c) at -(ld (ld - 1) / 2) + c, c in [-ld, -1]
+        const int jh = -m;
+        int ld = 1;
+        while (ld * (ld + 1) / 2 < jh) ++ld;
+        live = ld < L;
+        const int c = -(jh - ld * (ld - 1) / 2);
+        m = c + ld; row0 += ld * gt;
+    }
+    const float s = ldexpf(1.f, fscale_exp(bmax[(long long)t * sbmax]));
+    half8 pl[4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float2 x = live ? B[(long long)t * sBt + (row0 + c) + (long long)G2 * m] : make_float2(0.f, 0.f);
+        _Float16 h, l;
+        fsplit(x.x * s, h, l); pl[0][c] = h; pl[1][c] = l;
+        fsplit(x.y * s, h, l); pl[2][c] = h; pl[3][c] = l;
+    }
+    uint4 *o = out + (long long)t * sOut;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o[(long long)(p * G8t + g8) * ecols + j] = *reinterpret_cast<uint4 *>(&pl[p]);
+}
+
+// ---- v2 (block height 64, fused_pass64_kernel): the image IS the LDS layout of the window.  Plane p is an array of columns
+//      cc = m + 7 (7 zero columns in front, one behind: the window of tile T is columns 32 T .. 32 T + 39, one contiguous
+//      5-KiB piece per plane), a column is 8 octets of 16 bytes (8 rows g each), octet o stored at o ^ swz(cc):
+//      swz(x) = 2 ((x >> 1) & 3) | ((x >> 3) & 1) makes both the phase-A reads (16 consecutive columns, one octet) and the
+//      phase-B transposing reads (8 consecutive columns, an octet pair) conflict-free at ANY column offset - the shift by
+//      the delay ld moves the window of each wave.  The columns m < ld of block ld are NOT in this image (zeros instead): they
+//      are applied in fp32 outside the products (xs_delta below, reduce_parts_delta_kernel).
+__host__ __device__ inline int eswz(int x) { return (((x >> 1) & 3) << 1) | ((x >> 3) & 1); }
+
+__global__ __launch_bounds__(256) void pack_e2_kernel(const float2 *B, long long sBt, int G2, int M, const uint32_t *bmax, int sbmax,
+                                                      uint4 *out, long long sOut, float2 *Bdl)
+{
+    const int t = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < G2 * 8)                                       // the leading columns, row-major: Bdl[t][g][m < 8]
+        Bdl[(long long)t * G2 * 8 + idx] = B[(long long)t * sBt + (idx >> 3) + (long long)G2 * (idx & 7)];
+    if (idx >= (M + 8) * 8) return;
+    const int o = idx & 7, cc = idx >> 3, m = cc - 7;
+    const bool live = m >= 0 && m < M;
+    const float s = ldexpf(1.f, fscale_exp(bmax[(long long)t * sbmax]));
+    half8 pl[4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float2 x = live ? B[(long long)t * sBt + (8 * o + c) + (long long)G2 * m] : make_float2(0.f, 0.f);
+        _Float16 h, l;
+        fsplit(x.x * s, h, l); pl[0][c] = h; pl[1][c] = l;
+        fsplit(x.y * s, h, l); pl[2][c] = h; pl[3][c] = l;
+    }
+    uint4 *dst = out + (long long)t * sOut;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dst[((long long)p * (M + 8) + cc) * 8 + (o ^ eswz(cc))] = *reinterpret_cast<uint4 *>(&pl[p]);
+}
+
+// XsD[t][n + 64 m] = sum over ld > m, g < 64 of W[n, 64 ld + g] B[64 ld + g, m]   (m < L - 1: what the leading columns of the
+// delayed blocks add to Xs = (A S) B; fp32).  One block of 256 threads per (problem, column): lane = n, the four waves split
+// the rows g; Bdl = the leading columns row-major (uniform, consecutive loads).
+__device__ __forceinline__ void xs_delta(const float2 *W, const float2 *Bdl, int G2, int m, float2 *out)
+{
+    __shared__ float2 part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int g0 = 64 * (m + 1), cnt = G2 - g0;             // rows of the blocks ld > m
+    float2 a = make_float2(0.f, 0.f), a2 = a;
+    const int per = (cnt + 3) / 4, lo = g0 + wv * per, hi = min(lo + per, G2);
+    int g = lo;
+    for (; g + 1 < hi; g += 2) {
+        const float2 w0 = W[lane + 64ll * g], w1 = W[lane + 64ll * (g + 1)];
+        const float2 b0 = Bdl[g * 8 + m], b1 = Bdl[(g + 1) * 8 + m];
+        a.x = fmaf(w0.x, b0.x, fmaf(-w0.y, b0.y, a.x)); a.y = fmaf(w0.x, b0.y, fmaf(w0.y, b0.x, a.y));
+        a2.x = fmaf(w1.x, b1.x, fmaf(-w1.y, b1.y, a2.x)); a2.y = fmaf(w1.x, b1.y, fmaf(w1.y, b1.x, a2.y));
+    }
+    if (g < hi) {
+        const float2 w0 = W[lane + 64ll * g], b0 = Bdl[g * 8 + m];
+        a.x = fmaf(w0.x, b0.x, fmaf(-w0.y, b0.y, a.x)); a.y = fmaf(w0.x, b0.y, fmaf(w0.y, b0.x, a.y));
+    }
+    part[wv][lane] = make_float2(a.x + a2.x, a.y + a2.y);
+    __syncthreads();
+    if (wv == 0) {
+        const float2 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+        out[lane + 64 * m] = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+    }
+}
+
 // ---- W = A S (N x G2, column-major) -> B-operand fragments of (A S)^T: out[t][ks G2/32][nb 4][plane 4][lane 64],
 //      lane l: n = 16 nb + (l & 15), g = 32 ks + 8 (l >> 4) + 0..7
 __global__ __launch_bounds__(256) void pack_as_kernel(const float2 *W, long long sWt, int G2, const uint32_t *wmax, uint4 *out,
-                                                      long long sOut)
+                                                      long long sOut, const float2 *Bd, long long sBd, float2 *XsD)
 {
     const int t = blockIdx.y;
+    if ((int)blockIdx.x >= G2 / 32) {            // (v2 only: one more block per leading column of the problem)
+        xs_delta(W + (long long)t * sWt, Bd + (long long)t * sBd, G2, (int)blockIdx.x - G2 / 32, XsD + (long long)t * 512);
+        return;
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= (G2 / 32) * 256) return;
     const int lane = idx & 63, nb = (idx >> 6) & 3, ks = idx >> 8;
@@ -180,10 +313,34 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float4 *P, int 
     out[(long long)t * n4 + i] = a;
 }
 
+// the same with the leading columns of a block-Toeplitz dictionary (v2): Tc[n, g] += sum over m < ld(g) of k[n, m] conj(B[g, m])
+__global__ __launch_bounds__(256) void reduce_parts_delta_kernel(const float4 *P, int parts, long long n4, float4 *out, const float2 *Kf,
+                                                                 const float2 *B, long long sBt, int G2)
+{
+    const int t = blockIdx.y;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 *p = P + (long long)t * parts * n4 + i;
+    float4 a = p[0];
+    for (int s = 1; s < parts; ++s) {
+        const float4 b = p[(long long)s * n4];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int n = (int)((2 * i) & 63), g = (int)((2 * i) >> 6), ld = g >> 6;
+    const float2 *kf = Kf + (long long)t * 512, *b = B + (long long)t * sBt + g * 8;     // (the leading columns row-major)
+    for (int m = 0; m < ld; ++m) {
+        const float2 k0 = kf[n + 64 * m], k1 = kf[n + 1 + 64 * m], c = b[m];
+        a.x = fmaf(k0.x, c.x, fmaf(k0.y, c.y, a.x)); a.y = fmaf(k0.y, c.x, fmaf(-k0.x, c.y, a.y));
+        a.z = fmaf(k1.x, c.x, fmaf(k1.y, c.y, a.z)); a.w = fmaf(k1.y, c.x, fmaf(-k1.x, c.y, a.w));
+    }
+    out[(long long)t * n4 + i] = a;
+}
+
 // DBG != 0 (timing experiments only, results are wrong; not instantiated by default): 1 skips the phase-A products,
 // 2 the element-wise loads / stores, 4 the phase-B products, 8 the tile refill
 // YIN: Y = (I - Q) Z of the next iteration is formed here (Z from d.Zin, fragments of I - Q from d.Wqp) instead of read
-template <int GB, int DBG, bool YIN>
+// TOEP: the tile comes from the compact image of a block-Toeplitz dictionary (above) instead of the full tile image
+template <int GB, int DBG, bool YIN, bool TOEP>
 __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 {
     constexpr int G2 = 128 * GB;
@@ -216,9 +373,26 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     const float rho = prm.rho, ir = prm.irho, omc = 1.f - prm.c_coef, omr = 1.f - rho, omir = 1.f - ir;
 
     // refill of the tile: wave w owns the rows g of its phase-B range, block gb of them = 256 chunks, 4 per lane (plane p = c)
-    const u32x4 *const bt = reinterpret_cast<const u32x4 *>(d.Bf) + (long long)t * d.sBf + (long long)tile0 * (16ll * G2);
-    const uint32_t boff = 16u * ((uint32_t)(w * GB) * 256u + l);          // bytes
-    constexpr uint32_t tile_b = 256u * G2;                                // bytes per tile
+    // compact image: chunk (block gb, plane c) of lane l = E[(c G8t + g8'(gb) + g8i) ecols + ehalo + m - ld(gb)], m = 4 mq + r:
+    // a lane part (g8i, mq, r), a part that is uniform in the wave (ug[gb] + c ps) and 512 bytes per tile
+    const u32x4 *const bt = TOEP ? reinterpret_cast<const u32x4 *>(d.Ec) + (long long)t * d.sEc + 32ll * tile0
+                                 : reinterpret_cast<const u32x4 *>(d.Bf) + (long long)t * d.sBf + (long long)tile0 * (16ll * G2);
+    const uint32_t boff = TOEP ? 16u * ((uint32_t)((l >> 2) & 1) * (uint32_t)d.ecols + 4u * ((l >> 3) & 7) + (l & 3))
+                               : 16u * ((uint32_t)(w * GB) * 256u + l);   // bytes
+    const uint32_t tile_b = TOEP ? 512u : 256u * G2;                      // bytes per tile
+    uint32_t ug[GB], eld[GB];
+    const uint32_t ps = TOEP ? 16u * ((uint32_t)d.ecols << (d.gsh - 3)) : 1024u;
+    {
+        const int ws = __builtin_amdgcn_readfirstlane(w);
+#pragma unroll
+        for (int gb = 0; gb < GB; ++gb) {
+            const int blk = GB * ws + gb;
+            eld[gb] = TOEP ? (uint32_t)((16 * blk) >> d.gsh) : 0u;
+            ug[gb] = TOEP ? 16u * ((uint32_t)((2 * blk) & ((1 << (d.gsh - 3)) - 1)) * (uint32_t)d.ecols + (uint32_t)d.ehalo - eld[gb])
+                          : (uint32_t)gb * 4096u;
+        }
+    }
+#define FUSED_BLD(off_, gb_, c_) (TOEP ? ldg<u32x4>(bt, (off_) + ug[gb_] + (c_) * ps) : ldg_nt<u32x4>(bt, (off_) + (gb_) * 4096 + (c_) * 1024))
     unsigned char *rdst = tile + ((l >> 3) & 7) * ROWB + (2 * GB * w + ((l >> 2) & 1)) * 64 + (l & 3) * 16;   // + p 8 ROWB + gb 128
 
     f32x4 pr[GB][4], pi[GB][4];
@@ -244,10 +418,13 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 
     {
 #pragma unroll
-        for (int gb = 0; gb < GB; ++gb)
+        for (int gb = 0; gb < GB; ++gb) {
+            // (the columns m < ld of block ld - first tile of the dictionary only - come from the halo)
+            const int cc = 4 * ((l >> 3) & 7) + (l & 3) - (int)eld[gb];
+            const uint32_t fo = boff - ((TOEP && tile0 == 0 && cc < 0) ? 8u * eld[gb] * (eld[gb] - 1u) : 0u);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = ldg_nt<u32x4>(bt, boff + gb * 4096 + c * 1024);
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = FUSED_BLD(fo, gb, c);
+        }
     }
     __syncthreads();
 
@@ -413,7 +590,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
         u32x4 rf[2][4];
         if (!(DBG & 8)) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { rf[0][c] = ldg_nt<u32x4>(bt, noff + c * 1024); if (GB > 1) rf[1][c] = ldg_nt<u32x4>(bt, noff + 4096 + c * 1024); }
+            for (int c = 0; c < 4; ++c) { rf[0][c] = FUSED_BLD(noff, 0, c); if (GB > 1) rf[1][c] = FUSED_BLD(noff, (GB > 1 ? 1 : 0), c); }
         }
         // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
         // A operand: lane = g, registers = 8 of the 32 columns m - two transposing reads (ds_read_b64_tr_b16) of the
@@ -463,7 +640,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         *reinterpret_cast<u32x4 *>(rdst + c * 8 * ROWB + gb * 128) = rf[gb & 1][c];
-                        if (gb + 2 < GB) rf[gb & 1][c] = ldg_nt<u32x4>(bt, noff + (gb + 2) * 4096 + c * 1024);
+                        if (gb + 2 < GB) rf[gb & 1][c] = FUSED_BLD(noff, (gb + 2 < GB ? gb + 2 : 0), c);
                     }
                 }
             }
@@ -475,6 +652,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 
 #undef FUSED_ZLOAD
 #undef FUSED_YCOMP
+#undef FUSED_BLD
     // ---- partial sums of this column range: Ppart[t][part][n + 64 g]
     float2 *po = d.Ppart + ((long long)t * d.parts + part) * (64ll * G2);
 #pragma unroll
@@ -502,6 +680,422 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     }
 }
 
+
+// ================================================================================================================
+// v2: the pass for a block-Toeplitz dictionary of block height 64 (G2 = 64 L, L = 2 GB delays).
+//
+// Block ld of the dictionary is block 0 shifted right by ld columns, so the LDS tile of 32 columns is not G2 x 32 entries
+// (128 KiB) but the 64 x 39 window of block 0 they all come from (20 KiB): a fragment of block ld, column m, is read at
+// window column m - ld.  Both products are the ones of fused_pass_kernel - same fragments, same order, same bits when the
+// leading columns m < ld of the delayed blocks are zero - only the LDS addresses differ.  What the 108 KiB buy:
+//   * the element-wise operands of the NEXT tile (X, V1, V2, subY, 1/D: 72 KiB per tile) are fetched into an LDS staging
+//     area while phase B runs (through the 32 registers the 128-KiB refill of fused_pass_kernel needed), each wave for its
+//     own block; in fused_pass_kernel those loads sit between the two product phases with nothing to hide them (1.30 ms
+//     of products + 0.69 ms of exposed element-wise traffic = 1.98 ms per pass, measured by switching parts off:
+//     tools/pass_breakdown.py);
+//   * the svt argument Z = X - V1 / rho of Y = (I - Q) Z is formed from the staged X and V1 of the four waves of a column
+//     half instead of being written by one pass and read by the next (- 1.07 GB per pass with convergence_error; without
+//     it the Gram of the stored Z still needs the write);
+//   * the window of the next tile arrives the same way into a second buffer.
+// (LDS-direct loads - global_load_lds_dwordx4, no registers at all - were tried first and are slower here: every one of
+//  the 12 per wave and tile holds its wave for 250-300 cycles at issue, 3000 cycles per tile, wherever in the tile they are
+//  issued: tools/probe/lds_dma_probe.hip checks their addressing, profiles/r03_pass64_sections.txt has the timings.)
+// The leading columns (m < ld of block ld: 28 of the 4096 x 8 column-blocks) are outside the Toeplitz part.  They enter
+// as fp32 corrections: XsD = (A S) Delta is added to Xs in the first tile (xs_delta, formed with the (A S) fragments), the
+// first L - 1 columns of k are stored, and the sum of the partial sums adds k(:, m) conj(B(g, m)) (reduce_parts_delta_kernel).
+template <int GB, int DBG>
+__global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
+{
+    constexpr int G2 = 128 * GB;
+    constexpr int KSH = G2 / 64;               // 32-wide k-steps per g-half
+    constexpr int EPL = 40 * 128;              // bytes of one plane of the window: 40 columns x 8 octets x 16 B
+    constexpr int EBUF = 4 * EPL;              // 20 KiB
+    // staged element-wise operands of one wave (its 16 rows n x 16 columns m of the tile): X, V1, V2, subY as [column][n]
+    // with 144 bytes per column (the 16 lanes of a Z-fragment read - 16 columns, one 16-byte piece - cover all banks),
+    // then 1/D with 80 bytes per column
+    constexpr int SCOL = 144, SFLD = 16 * SCOL, SINV = 4 * SFLD, ICOL = 80, STW = SINV + 16 * ICOL;
+    constexpr int STG0 = 2 * EBUF + 24576;
+    extern __shared__ __align__(16) unsigned char lds[];
+    unsigned char *xch = lds + 2 * EBUF;       // 24 KiB: phase-A partial sums (16), then the k fragments (6 planes)
+
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int t = (slot / d.parts) * 8 + xcd;  // the column ranges of one problem run on ONE XCD: (A S) stays in its L2
+    if (t >= d.batch) return;
+    const int part = slot % d.parts;
+    const int tpw = (d.M / 32) / d.parts;
+    const int tile0 = part * tpw;
+
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, q = l >> 4, c16 = l & 15;
+    const int nb = w & 3, kh = w >> 2;
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    unsigned char *stag = lds + STG0 + ws * STW;
+
+    const TrialParams prm = d.prm[t];
+    const int eb = fscale_exp(d.bmax[(long long)t * d.sbmax]), ew = fscale_exp(d.wmax[t]);
+    const int ek = fscale_exp(d.kmax_prev[t]) - d.kback;       // (see fused_pass_kernel)
+    const float sxs = ldexpf(1.f, -(eb + ew)), sk = ldexpf(1.f, ek), sp = ldexpf(1.f, -(eb + ek));
+    const float rho = prm.rho, ir = prm.irho, omc = 1.f - prm.c_coef, omr = 1.f - rho, omir = 1.f - ir;
+
+    f32x4 pr[GB][4], pi[GB][4];
+#pragma unroll
+    for (int gb = 0; gb < GB; ++gb)
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) { pr[gb][n2] = f32x4{0.f, 0.f, 0.f, 0.f}; pi[gb][n2] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float kmx = 0.f, xmx = 0.f, v1mx = 0.f, zmx = 0.f, v2mx = 0.f;
+
+    float2 *const Xt = d.X + (long long)t * d.snm, *const V1t = d.V1 + (long long)t * d.snm, *const V2t = d.V2 + (long long)t * d.snm;
+    const float2 *const sYt = d.subY + (long long)t * d.snm;
+    const float *const iDt = d.invD + (long long)t * d.snm;
+    float2 *const Zot = d.Zout ? d.Zout + (long long)t * d.snm : nullptr;
+    float2 *const Yot = d.Yout ? d.Yout + (long long)t * d.snm : nullptr;
+    const u32x4 *const wqt = reinterpret_cast<const u32x4 *>(d.Wqp) + (long long)t * 2048;
+    const uint32_t wqoff = 16u * (nb * 256 + l);                                                              // bytes
+    const float sy = ldexpf(1.f, -(fscale_exp(d.zmax_in[t]) + 13)), sz = ldexpf(1.f, fscale_exp(d.zmax_in[t]));
+    const uint32_t ebase = 8u * (16 * nb + c16 + 64 * (16 * kh + 4 * q));     // bytes; + 512 (m0 + s)
+    const u32x4 *const ast = reinterpret_cast<const u32x4 *>(d.ASp) + (long long)t * d.sAS;
+    const uint32_t aoff = 16u * ((uint32_t)(kh * KSH) * 1024u + nb * 256 + l);      // bytes
+    const uint4 *const Et = d.Ec + (long long)t * d.sEc;
+    const float2 *const XsDt = d.XsD + (long long)t * 512;
+    float2 *const Kft = d.Kf + (long long)t * 512;
+    const uint32_t epl = 128u * (uint32_t)d.ecols;                            // bytes per plane of the image
+
+    // ---- the 12 pieces of 1 KiB (16 bytes per lane) a wave moves per tile, through registers:
+    //   0..2   window of the tile: per plane the 5 KiB at column 32 T of the image, 20 pieces, wave w takes w, w + 8, w + 16
+    //   3..10  X, V1, V2, subY of this wave's block: lane -> rows n = 2 (l & 7), + 1 of column (l >> 3) + 8 j
+    //   11     1/D: lane -> rows 4 (l & 3) .. + 3 of column l >> 2
+    const uint32_t so = 128u * nb + 16u * (l & 7) + 512u * (16 * kh + (l >> 3));
+    const uint32_t io = 64u * nb + 16u * (l & 3) + 256u * (16 * kh + (l >> 2));
+    unsigned char *const sdst = stag + (l >> 3) * SCOL + (l & 7) * 16;       // + field SFLD + j 8 SCOL
+    unsigned char *const idst = stag + SINV + (l >> 2) * ICOL + (l & 3) * 16;
+#define F64_LOAD(pc_, T_, dst_)                                                                                              \
+    {                                                                                                                        \
+        if ((pc_) < 3) {                                                                                                     \
+            const int e_ = ws + 8 * (pc_) - ((pc_) == 2 && ws >= 4 ? 8 : 0);    /* (waves 4-7 have two pieces: the second again) */ \
+            if (!(DBG & 8)) {                                                                                                \
+                const int p_ = e_ / 5, j_ = e_ - 5 * p_;                                                                     \
+                dst_ = ldg_nt<u32x4>(Et, (uint32_t)p_ * epl + 4096u * (uint32_t)(T_) + 1024u * j_ + 16u * l);               \
+            }                                                                                                                \
+        } else if (!(DBG & 2)) {                                                                                             \
+            const uint32_t o_ = so + 16384u * (uint32_t)(T_) + 4096u * (((pc_) - 3) & 1);                                   \
+            if ((pc_) == 3 || (pc_) == 4) dst_ = ldg_nt<u32x4>(Xt, o_);                                                      \
+            if ((pc_) == 5 || (pc_) == 6) dst_ = ldg_nt<u32x4>(V1t, o_);                                                     \
+            if ((pc_) == 7 || (pc_) == 8) dst_ = ldg_nt<u32x4>(V2t, o_);                                                     \
+            if ((pc_) == 9 || (pc_) == 10) dst_ = ldg_nt<u32x4>(sYt, o_);                                                    \
+            if ((pc_) == 11) dst_ = ldg_nt<u32x4>(iDt, io + 8192u * (uint32_t)(T_));                                         \
+        }                                                                                                                    \
+    }
+#define F64_STORE(pc_, buf_, src_)                                                                                           \
+    {                                                                                                                        \
+        if ((pc_) < 3) {                                                                                                     \
+            const int e_ = ws + 8 * (pc_) - ((pc_) == 2 && ws >= 4 ? 8 : 0);                                                 \
+            if (!(DBG & 8)) {                                                                                                \
+                const int p_ = e_ / 5, j_ = e_ - 5 * p_;                                                                     \
+                *reinterpret_cast<u32x4 *>(lds + (buf_) * EBUF + p_ * EPL + j_ * 1024 + 16 * l) = src_;                      \
+            }                                                                                                                \
+        } else if (!(DBG & 2)) {                                                                                             \
+            if ((pc_) == 11) *reinterpret_cast<u32x4 *>(idst) = src_;                                                        \
+            else *reinterpret_cast<u32x4 *>(sdst + (((pc_) - 3) >> 1) * SFLD + (((pc_) - 3) & 1) * 8 * SCOL) = src_;         \
+        }                                                                                                                    \
+    }
+    u32x4 rf[2][4];
+    {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) F64_LOAD(4 * r + c, tile0, rf[0][c])
+#pragma unroll
+            for (int c = 0; c < 4; ++c) F64_STORE(4 * r + c, 0, rf[0][c])
+        }
+    }
+    __syncthreads();
+
+    // phase-A window column of this lane before the delay: block ld = kh GB + (ks >> 1) sits ld columns to the left
+    const int cA = c16 + 7 - kh * GB;
+    const int cB0 = 4 * q + (c16 >> 2) + 7;    // phase B: window column of this lane's row 4 q + (c16 >> 2), before the delay
+    // Z fragments of Y = (I - Q) Z: columns m = 16 kh + c16 of the tile, rows n' = 32 ks + 8 q .. + 7, from the staged X and V1
+    // of wave (2 ks + (q >> 1), kh)
+    const unsigned char *const zsrc = lds + STG0 + ((q >> 1) + 4 * kh) * STW + c16 * SCOL + (q & 1) * 64;      // + 2 ks STW
+
+    // the fragments of (I - Q)^T (the same for every tile; no registers to keep them): requested behind the last products of a
+    // tile, so that they arrive while the wave waits at the barrier
+    u32x4 wq[2][4];
+#define F64_WQLOAD()                                                                                                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                        \
+    {                                                                                                                        \
+        uint32_t wo_ = wqoff + ks * 16384;          /* (opaque: else a 64-bit address per plane is built and spilled) */     \
+        asm volatile("" : "+v"(wo_));                                                                                        \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) wq[ks][p] = ldg<u32x4>(wqt, wo_ + p * 1024);                           \
+    }
+    F64_WQLOAD()
+    long long t_wait = 0, t_bar = 0, t_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const long long t_start = (DBG & 16) ? (long long)__builtin_readcyclecounter() : 0;
+    for (int i = 0; i < tpw; ++i) {
+        const int m0 = (tile0 + i) * 32;
+        const unsigned char *ebuf = lds + (i & 1) * EBUF;
+        long long tp = (DBG & 16) ? (long long)__builtin_readcyclecounter() : 0;
+        // ================= Y^T(block) = Z^T Wq^T for this wave's element-wise block: A operand = Z^T (lane = column m, 8
+        // consecutive rows n' per k-step), Z = X - V1 / rho formed from the staged operands of the four waves of this
+        // column half - the svt argument is neither read from memory nor (with convergence_error) written to it;
+        // B operand = the fragments of Wq^T = (I - Q)^T; two k-steps of 32 rows
+        float2 ey[4];
+        {
+            f32x4 yr = f32x4{0.f, 0.f, 0.f, 0.f}, yi = yr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 zp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float4 xv = make_float4(1.f, 1.f, 1.f, 1.f), vv = xv;
+                    if (!(DBG & 2)) {
+                        xv = *reinterpret_cast<const float4 *>(zsrc + 2 * ks * STW + 16 * j);
+                        vv = *reinterpret_cast<const float4 *>(zsrc + 2 * ks * STW + SFLD + 16 * j);
+                    }
+                    const float4 z = make_float4(xv.x - ir * vv.x, xv.y - ir * vv.y, xv.z - ir * vv.z, xv.w - ir * vv.w);
+                    _Float16 h, lo;
+                    fsplit(z.x * sz, h, lo); zp[0][2 * j] = h; zp[1][2 * j] = lo;
+                    fsplit(z.y * sz, h, lo); zp[2][2 * j] = h; zp[3][2 * j] = lo;
+                    fsplit(z.z * sz, h, lo); zp[0][2 * j + 1] = h; zp[1][2 * j + 1] = lo;
+                    fsplit(z.w * sz, h, lo); zp[2][2 * j + 1] = h; zp[3][2 * j + 1] = lo;
+                }
+                u32x4 zf[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) zf[p] = __builtin_bit_cast(u32x4, zp[p]);
+                const u32x4 nwi_h = negu(wq[ks][2]), nwi_l = negu(wq[ks][3]);
+                yr = mma(zf[0], wq[ks][0], yr); yi = mma(zf[0], wq[ks][2], yi);
+                yr = mma(zf[0], wq[ks][1], yr); yi = mma(zf[0], wq[ks][3], yi);
+                yr = mma(zf[1], wq[ks][0], yr); yi = mma(zf[1], wq[ks][2], yi);
+                yr = mma(zf[2], nwi_h, yr); yi = mma(zf[2], wq[ks][0], yi);
+                yr = mma(zf[2], nwi_l, yr); yi = mma(zf[2], wq[ks][1], yi);
+                yr = mma(zf[3], nwi_h, yr); yi = mma(zf[3], wq[ks][0], yi);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ey[s] = make_float2(yr[s] * sy, yi[s] * sy);
+        }
+        __builtin_amdgcn_sched_barrier(0);      // (else the first (A S) fragments of phase A are requested above these products: spills)
+        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[3] += tq - tp; tp = tq; }
+        // ================= phase A: Xs^T(tile) = B^T (A S)^T, this wave: n-block nb, g-half kh, both m-blocks
+        f32x4 ar[2], ai[2];
+        ar[0] = ar[1] = ai[0] = ai[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(DBG & 1)) {
+            u32x4 wr[2][4], bfb[4];
+            uint32_t ao = aoff;
+            asm volatile("" : "+v"(ao));
+            int cK = cA;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) wr[0][p] = ldg<u32x4>(ast, ao + p * 1024);
+#pragma unroll
+            for (int st = 0; st < 2 * KSH; ++st) {
+                const int ks = st >> 1, mb = st & 1;
+                if (mb == 0 && ks + 1 < KSH) {
+                    ao += 16384;
+                    asm volatile("" : "+v"(ao));
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) wr[(ks + 1) & 1][p] = ldg<u32x4>(ast, ao + p * 1024);
+                }
+                {
+                    // (the column is advanced opaquely per delay block: computed up front, the addresses of all (block, octet)
+                    //  pairs are loop invariants of the tile loop and the compiler keeps - and spills - them)
+                    if (mb == 0 && (ks & 1) == 0) {
+                        if (ks > 0) cK -= 1;
+                        asm volatile("" : "+v"(cK));
+                    }
+                    const unsigned char *arow = ebuf + cK * 128 + 16 * ((4 * (ks & 1) + q) ^ eswz(cK)) + mb * 2048;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) bfb[p] = *reinterpret_cast<const u32x4 *>(arow + p * EPL);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 *wf = wr[ks & 1];
+                const u32x4 nwi_h = negu(wf[2]), nwi_l = negu(wf[3]);
+                // re += Br Wr - Bi Wi ; im += Br Wi + Bi Wr   (h h + h l + l h each)
+                ar[mb] = mma(bfb[0], wf[0], ar[mb]); ai[mb] = mma(bfb[0], wf[2], ai[mb]);
+                ar[mb] = mma(bfb[0], wf[1], ar[mb]); ai[mb] = mma(bfb[0], wf[3], ai[mb]);
+                ar[mb] = mma(bfb[1], wf[0], ar[mb]); ai[mb] = mma(bfb[1], wf[2], ai[mb]);
+                ar[mb] = mma(bfb[2], nwi_h, ar[mb]); ai[mb] = mma(bfb[2], wf[0], ai[mb]);
+                ar[mb] = mma(bfb[2], nwi_l, ar[mb]); ai[mb] = mma(bfb[2], wf[1], ai[mb]);
+                ar[mb] = mma(bfb[3], nwi_h, ar[mb]); ai[mb] = mma(bfb[3], wf[0], ai[mb]);
+            }
+        }
+        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[0] += tq - tp; tp = tq; }
+        // the two g-halves meet: wave (nb, kh) keeps m-block kh and hands m-block 1 - kh to wave (nb, 1 - kh)
+        {
+            const f32x4 sr = kh ? ar[0] : ar[1], si = kh ? ai[0] : ai[1];
+            f32x4 *x4 = reinterpret_cast<f32x4 *>(xch);
+            const int dw = nb + 4 * (1 - kh);
+            x4[(dw * 2 + 0) * 64 + l] = sr;
+            x4[(dw * 2 + 1) * 64 + l] = si;
+        }
+        // the element-wise operands of this wave's block (n = 16 nb + c16, m = m0 + 16 kh + 4 q + s), staged by this wave
+        float2 ex[4], ev1[4], ev2[4], esy[4];
+        float eid[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (DBG & 2) { ex[s] = ev1[s] = ev2[s] = esy[s] = make_float2(1.f, 1.f); eid[s] = 1.f; continue; }
+            const unsigned char *sp_ = stag + (4 * q + s) * SCOL + c16 * 8;
+            ex[s] = *reinterpret_cast<const float2 *>(sp_);              ev1[s] = *reinterpret_cast<const float2 *>(sp_ + SFLD);
+            ev2[s] = *reinterpret_cast<const float2 *>(sp_ + 2 * SFLD);  esy[s] = *reinterpret_cast<const float2 *>(sp_ + 3 * SFLD);
+            eid[s] = *reinterpret_cast<const float *>(stag + SINV + (4 * q + s) * ICOL + c16 * 4);
+        }
+        __syncthreads();
+        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[4] += tq - tp; tp = tq; }
+        f32x4 xr = kh ? ar[1] : ar[0], xi = kh ? ai[1] : ai[0];
+        {
+            const f32x4 *x4 = reinterpret_cast<const f32x4 *>(xch);
+            const f32x4 orr = x4[(w * 2 + 0) * 64 + l], oi = x4[(w * 2 + 1) * 64 + l];
+            xr += orr; xi += oi;
+        }
+        half4 kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t ix = ebase + 512u * (uint32_t)(m0 + s);
+            float2 xs = make_float2(xr[s] * sxs, xi[s] * sxs);
+            const bool lead = m0 == 0 && kh == 0 && 4 * q + s < 2 * GB - 1;      // a leading column: + (A S) Delta
+            if (lead) {                          // (m0 = 0, kh = 0: ix is 8 (n + 64 m))
+                const float2 dx = ldg<float2>(XsDt, ix);
+                xs.x += dx.x; xs.y += dx.y;
+            }
+            // V2 <- (1 - cc)(V2 - rho (X - Xs))                       (:61 + :65, C == -V2)
+            const float2 v2 = make_float2(omc * (ev2[s].x - rho * (ex[s].x - xs.x)), omc * (ev2[s].y - rho * (ex[s].y - xs.y)));
+            // X <- iK1 (V1 + rho Y + subY + V2 + rho C + rho Xs)      (:38-40)
+            const float2 x = make_float2((ev1[s].x + rho * ey[s].x + esy[s].x + omr * v2.x + rho * xs.x) * eid[s],
+                                         (ev1[s].y + rho * ey[s].y + esy[s].y + omr * v2.y + rho * xs.y) * eid[s]);
+            const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);                  // (:43)
+            const float2 v1 = make_float2(ev1[s].x + rho * (ey[s].x - x.x), ev1[s].y + rho * (ey[s].y - x.y));   // (:64)
+            if (!(DBG & 2)) { stg_nt2(V2t, ix, v2); stg_nt2(Xt, ix, x); stg_nt2(V1t, ix, v1); }
+            const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+            if (Zot) stg_nt2(Zot, ix, zn);
+            if (Yot) stg(Yot, ix, ey[s]);
+            if (lead) stg(Kft, ix, kk);
+            v2mx = fmaxf(v2mx, fmaxf(fabsf(v2.x), fabsf(v2.y)));
+            xmx = fmaxf(xmx, fmaxf(fabsf(x.x), fabsf(x.y)));
+            v1mx = fmaxf(v1mx, fmaxf(fabsf(v1.x), fabsf(v1.y)));
+            zmx = fmaxf(zmx, fmaxf(fabsf(zn.x), fabsf(zn.y)));
+            kmx = fmaxf(kmx, fmaxf(fabsf(kk.x), fabsf(kk.y)));
+            _Float16 h, lo;
+            fsplit(kk.x * sk, h, lo); kf[0][s] = h; kf[1][s] = lo;
+            fsplit(kk.y * sk, h, lo); kf[2][s] = h; kf[3][s] = lo;
+        }
+        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[5] += tq - tp; tp = tq; }
+        __syncthreads();                        // every wave has read its partial sums: the exchange area is free
+        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[6] += tq - tp; tp = tq; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<half4 *>(xch + ((nb * 6 + p) * 64 + l) * 16 + kh * 8) = kf[p];
+        // planes 4, 5: -k_re (the imaginary part of conj(B) k needs it; negating per product costs registers)
+        *reinterpret_cast<half4 *>(xch + ((nb * 6 + 4) * 64 + l) * 16 + kh * 8) = -kf[0];
+        *reinterpret_cast<half4 *>(xch + ((nb * 6 + 5) * 64 + l) * 16 + kh * 8) = -kf[1];
+        __syncthreads();
+        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[7] += tq - tp; tp = tq; }
+        // the next tile (the last one is fetched again: unconditional loads): its window goes into the other buffer, its
+        // element-wise operands into this wave's staging area (every wave has read what it needs of it: Y above, the operands
+        // before the first barrier).  Pieces 0-7 are requested now, written behind the products of blocks 1 and 2, pieces 8-11
+        // requested then and written behind the last block.
+        const int tn = tile0 + min(i + 1, tpw - 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) F64_LOAD(c, tn, rf[0][c])
+#pragma unroll
+        for (int c = 0; c < 4; ++c) F64_LOAD(4 + c, tn, rf[1][c])
+        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[1] += tq - tp; tp = tq; }
+        // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
+        if (!(DBG & 4)) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+            auto *lbase = (__attribute__((address_space(3))) unsigned char *)lds;
+#pragma unroll
+            for (int gb = 0; gb < GB; ++gb) {
+                // rows 16 (GB w + gb) ..: delay ld, octet pair jp of block 0; lane: window column of row 4 q + (c16 >> 2)
+                const int blk = GB * ws + gb, ld = blk >> 2, jp = 2 * (blk & 3);
+                int cB = cB0 - ld;
+                asm volatile("" : "+v"(cB));                 // (as in phase A: no address per block kept across the tile loop)
+                const uint32_t tr0 = (uint32_t)((i & 1) * EBUF) + cB * 128 + 16 * ((jp + ((c16 >> 1) & 1)) ^ eswz(cB)) + (c16 & 1) * 8;
+                u32x4 bf[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t o_ = tr0 + p * EPL;
+                    const u32x2 lo_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o_)));
+                    const u32x2 hi_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o_ + 2048)));
+                    bf[p] = u32x4{lo_.x, lo_.y, hi_.x, hi_.y};
+                }
+#pragma unroll
+                for (int n2 = 0; n2 < 4; ++n2) {
+                    const unsigned char *kp = xch + (n2 * 6 * 64 + l) * 16;
+                    u32x4 k0 = *reinterpret_cast<const u32x4 *>(kp), k1 = *reinterpret_cast<const u32x4 *>(kp + 1024);
+                    const u32x4 k2 = *reinterpret_cast<const u32x4 *>(kp + 2048), k3 = *reinterpret_cast<const u32x4 *>(kp + 3072);
+                    // re += Br kr + Bi ki ; im += Br ki - Bi kr
+                    pr[gb][n2] = mma(bf[0], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k2, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[0], k1, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k3, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[1], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[1], k2, pi[gb][n2]);
+                    k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
+                    pr[gb][n2] = mma(bf[2], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k0, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[2], k3, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k1, pi[gb][n2]);
+                    pr[gb][n2] = mma(bf[3], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[3], k0, pi[gb][n2]);
+                    __builtin_amdgcn_sched_barrier(0);      // (else the fragment reads of all four n-blocks are hoisted: spills)
+                }
+                if (GB == 4 && gb == 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { F64_STORE(c, (i + 1) & 1, rf[0][c]) F64_LOAD(8 + c, tn, rf[0][c]) }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (GB == 4 && gb == 2) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) F64_STORE(4 + c, (i + 1) & 1, rf[1][c])
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (GB == 4 && !(DBG & 4)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) F64_STORE(8 + c, (i + 1) & 1, rf[0][c])
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) F64_STORE(c, (i + 1) & 1, rf[0][c])
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { F64_STORE(4 + c, (i + 1) & 1, rf[1][c]) F64_LOAD(8 + c, tn, rf[0][c]) }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) F64_STORE(8 + c, (i + 1) & 1, rf[0][c])
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        F64_WQLOAD()
+        long long tw0 = 0;
+        if (DBG & 16) { tw0 = __builtin_readcyclecounter(); t_ph[2] += tw0 - tp; }
+        __syncthreads();                        // window and operands of the next tile in place for every wave; k fragments dead
+        if (DBG & 16) t_bar += __builtin_readcyclecounter() - tw0;
+    }
+    if ((DBG & 16) && l == 0) {                 // (timing experiment: cycles per section, summed over the waves of the trial)
+        unsigned long long *cnt = reinterpret_cast<unsigned long long *>(d.Kf + (long long)t * 512 + 448);
+        atomicAdd(cnt, (unsigned long long)t_wait); atomicAdd(cnt + 1, (unsigned long long)t_bar);
+        atomicAdd(cnt + 2, (unsigned long long)(__builtin_readcyclecounter() - t_start));
+        for (int z = 0; z < 9; ++z) atomicAdd(cnt + 3 + z, (unsigned long long)t_ph[z]);
+    }
+#undef F64_LOAD
+#undef F64_STORE
+#undef F64_WQLOAD
+    // ---- partial sums of this column range: Ppart[t][part][n + 64 g]
+    float2 *po = d.Ppart + ((long long)t * d.parts + part) * (64ll * G2);
+#pragma unroll
+    for (int gb = 0; gb < GB; ++gb)
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int g = 16 * GB * w + 16 * gb + 4 * q + s;
+                po[64ll * g + 16 * n2 + c16] = make_float2(pr[gb][n2][s] * sp, pi[gb][n2][s] * sp);
+            }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        kmx = fmaxf(kmx, __shfl_xor(kmx, o)); xmx = fmaxf(xmx, __shfl_xor(xmx, o)); v1mx = fmaxf(v1mx, __shfl_xor(v1mx, o));
+        zmx = fmaxf(zmx, __shfl_xor(zmx, o)); v2mx = fmaxf(v2mx, __shfl_xor(v2mx, o));
+    }
+    if (l == 0) {
+        if (d.kmax_out) atomicMax(&d.kmax_out[t], __float_as_uint(kmx));
+        if (d.xmax) atomicMax(&d.xmax[t], __float_as_uint(xmx));
+        if (d.v1max) atomicMax(&d.v1max[t], __float_as_uint(v1mx));
+        if (d.zmax) atomicMax(&d.zmax[t], __float_as_uint(zmx));
+        if (d.v2max) atomicMax(&d.v2max[t], __float_as_uint(v2mx));
+        if (d.ovf && !(kmx * sk < 60000.f)) atomicOr(&d.ovf[t], 1u);      // per trial: the caller re-solves exactly those
+    }
+}
+
 }  // namespace
 
 bool fused_shape_ok(int N, int M, int G2, int parts)
@@ -509,28 +1103,101 @@ bool fused_shape_ok(int N, int M, int G2, int parts)
     return N == 64 && G2 >= 128 && G2 <= 512 && G2 % 128 == 0 && parts > 0 && M % (32 * parts) == 0;
 }
 
-size_t fused_bytes(int M, int G2, int nB, int batch, int parts)
+static void compact_dims(int M, int G2, int gt, int *ecols, int *ehalo)
 {
-    return rnd256((size_t)nB * (M / 32) * 16 * G2 * sizeof(uint4)) + rnd256((size_t)batch * (G2 / 32) * 1024 * sizeof(uint4)) +
-           rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256((size_t)batch * sizeof(uint32_t)) + rnd256((size_t)batch * 2048 * sizeof(uint4));
+    const int L = G2 / gt;
+    *ehalo = ((L * (L - 1) / 2 + 3) / 4) * 4;               // column 0 stays 64-byte aligned
+    *ecols = *ehalo + M;
 }
 
-int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts)
+size_t fused_bytes(int M, int G2, int nB, int batch, int parts)
+{
+    int ec, eh;
+    compact_dims(M, G2, 16, &ec, &eh);                      // (the probe decides between the two images after this is sized)
+    return rnd256((size_t)nB * (M / 32) * 16 * G2 * sizeof(uint4)) + rnd256((size_t)batch * (G2 / 32) * 1024 * sizeof(uint4)) +
+           rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256((size_t)batch * sizeof(uint32_t)) + rnd256((size_t)batch * 2048 * sizeof(uint4)) +
+           rnd256((size_t)nB * 4 * (G2 / 16) * ec * sizeof(uint4)) + 2 * rnd256((size_t)batch * 512 * sizeof(float2)) +
+           rnd256((size_t)nB * G2 * 8 * sizeof(float2)) + 512;
+}
+
+// Exact probe of the block-Toeplitz property over all nB dictionaries; *gt = the smallest block height (16 .. 256, a power
+// of two, G2 / gt >= 2) for which EVERY entry outside the leading columns repeats, 0 if none.  One pass over B and one
+// 4-byte read-back: the caller chooses the image (and the kernel instance) from it, so the stream is synchronised here.
+int fused_probe_toeplitz(jstsp_ctx *ctx, Arena &ar, const float2 *B, long long sBt, int G2, int M, int nB, int *gt)
+{
+    *gt = 0;
+    uint32_t *flag = ar.get<uint32_t>(1);
+    JSTSP_REQUIRE(flag, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
+    JSTSP_REQUIRE((long long)G2 * M < (1ll << 31), JSTSP_E_UNSUPPORTED, "fused pass: dictionary too large");
+    uint32_t cand = 0;
+    for (int c = 0; c < 5; ++c)
+        if (G2 % (16 << c) == 0 && 2 * (16 << c) <= G2) cand |= 1u << c;
+    const unsigned nblk = (unsigned)(((long long)G2 * M + 255) / 256);
+    // every candidate on the first dictionary, then the smallest surviving one on all of them (a wrong candidate fails on
+    // nearly every entry: testing all five on the whole batch is five times the traffic for nothing)
+    for (int step = 0; step < (nB > 1 ? 2 : 1) && cand; ++step) {
+        JSTSP_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(toeplitz_probe_kernel, dim3(nblk, step ? nB : 1), dim3(256), 0, ctx->stream, B, sBt, G2, M, cand, flag);
+        JSTSP_HIP(hipGetLastError());
+        uint32_t bad = ~0u;
+        JSTSP_HIP(hipMemcpyAsync(&bad, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+        cand &= ~bad;
+        cand &= cand ? (~cand + 1u) : 0u;                   // the lowest surviving bit
+    }
+    if (cand) *gt = 16 << (31 - __builtin_clz(cand));
+    return 0;
+}
+
+int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts, int gt, int v2)
 {
     f.parts = parts;
     f.sBf = (long long)(M / 32) * 16 * G2;
     f.sAS = (long long)(G2 / 32) * 1024;
-    f.Bf = ar.get<uint4>((size_t)nB * f.sBf);
+    f.gt = gt;
+    f.v2 = (gt == 64 && v2) ? 1 : 0;
+    if (f.v2) {                                             // the window image: 4 planes x (M + 8) columns x 8 octets
+        f.ecols = M + 8; f.ehalo = 7;
+        f.sEc = 4ll * f.ecols * 8;
+        f.Ec = ar.get<uint4>((size_t)nB * f.sEc);
+        f.XsD = ar.get<float2>((size_t)batch * 512);
+        f.Kf = ar.get<float2>((size_t)batch * 512);
+        f.Bdl = ar.get<float2>((size_t)nB * G2 * 8);
+        JSTSP_REQUIRE(f.XsD && f.Kf && f.Bdl, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
+    } else if (gt) {
+        compact_dims(M, G2, gt, &f.ecols, &f.ehalo);
+        f.sEc = 4ll * (gt / 8) * f.ecols;
+        f.Ec = ar.get<uint4>((size_t)nB * f.sEc);
+    } else
+        f.Bf = ar.get<uint4>((size_t)nB * f.sBf);
     f.ASp = ar.get<uint4>((size_t)batch * f.sAS);
     f.Ppart = ar.get<float2>((size_t)batch * parts * 64 * G2);
     f.ovf = ar.get<uint32_t>(batch);
     f.Wqp = ar.get<uint4>((size_t)batch * 2048);
-    JSTSP_REQUIRE(f.Bf && f.ASp && f.Ppart && f.ovf && f.Wqp, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
+    JSTSP_REQUIRE((f.Bf || f.Ec) && f.ASp && f.Ppart && f.ovf && f.Wqp, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
     return 0;
 }
 
-int fused_pack_b(jstsp_ctx *ctx, const FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax)
+int fused_pack_b(jstsp_ctx *ctx, FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax)
 {
+    f.Bsrc = B; f.sBsrc = sBt;
+    if (f.v2) {
+        hipLaunchKernelGGL(pack_e2_kernel, dim3((unsigned)((std::max(M + 8, G2) * 8 + 255) / 256), nB), dim3(256), 0, ctx->stream, B, sBt, G2, M,
+                           bmax, 1, f.Ec, f.sEc, f.Bdl);
+        JSTSP_HIP(hipGetLastError());
+        f.sBdl = sBt ? (long long)G2 * 8 : 0;
+#ifdef JSTSP_FUSED_DBG_BUILD
+        JSTSP_HIP(hipMemsetAsync(f.Kf, 0, 4096, ctx->stream));     // (cycle counters of the timing experiment, trial 0)
+#endif
+        return 0;
+    }
+    if (f.gt) {
+        const long long n = (long long)(f.gt / 8) * f.ecols;
+        hipLaunchKernelGGL(pack_e_kernel, dim3((unsigned)((n + 255) / 256), nB), dim3(256), 0, ctx->stream, B, sBt, G2, M, f.gt,
+                           f.ecols, f.ehalo, bmax, 1, f.Ec, f.sEc);
+        JSTSP_HIP(hipGetLastError());
+        return 0;
+    }
     const long long n = (long long)(M / 32) * 16 * (G2 / 4);
     hipLaunchKernelGGL(pack_bf_kernel, dim3((unsigned)((n + 255) / 256), nB), dim3(256), 0, ctx->stream, B, sBt, G2, M, bmax, 1,
                        f.Bf, f.sBf);
@@ -538,42 +1205,111 @@ int fused_pack_b(jstsp_ctx *ctx, const FusedWS &f, const float2 *B, long long sB
     return 0;
 }
 
-int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int batch, const uint32_t *wmax)
+int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int M, int batch, const uint32_t *wmax)
 {
-    hipLaunchKernelGGL(pack_as_kernel, dim3((G2 / 32), batch), dim3(256), 0, ctx->stream, W, sWt, G2, wmax, f.ASp, f.sAS);
+    // (v2: two more blocks per problem form (A S) Delta, the leading columns' share of Xs)
+    hipLaunchKernelGGL(pack_as_kernel, dim3((G2 / 32) + (f.v2 ? G2 / 64 - 1 : 0), batch), dim3(256), 0, ctx->stream, W, sWt, G2, wmax,
+                       f.ASp, f.sAS, f.Bdl, f.sBdl, f.XsD);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }
 
-template <int GB, bool YIN> static int launch_fused_gb(jstsp_ctx *ctx, const FusedDesc &d)
+template <int GB> static int launch_fused64(jstsp_ctx *ctx, const FusedDesc &d)
+{
+    const size_t sh = 2 * 20480 + 24576 + 8 * (4 * 16 * 144 + 16 * 80);
+    const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
+#ifdef JSTSP_FUSED_DBG_BUILD
+    if (GB == 4 && getenv("JSTSP_FUSED_DBG") && atoi(getenv("JSTSP_FUSED_DBG"))) {
+#define DBG_CASE(k_)                                                                                                          \
+    case k_:                                                                                                                  \
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<4, k_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)); \
+        hipLaunchKernelGGL((fused_pass64_kernel<4, k_>), dim3(grid), dim3(512), sh, ctx->stream, d);                          \
+        return 0;
+        const int dbg = atoi(getenv("JSTSP_FUSED_DBG"));
+        if (dbg & 16) {
+            static int calls = 0;
+            if (dbg == 16) {
+                JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                hipLaunchKernelGGL((fused_pass64_kernel<4, 16>), dim3(grid), dim3(512), sh, ctx->stream, d);
+            } else {
+                JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<4, 26>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+                hipLaunchKernelGGL((fused_pass64_kernel<4, 26>), dim3(grid), dim3(512), sh, ctx->stream, d);
+            }
+            if (++calls == 7) {
+                unsigned long long c[12];
+                JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+                JSTSP_HIP(hipMemcpy(c, d.Kf + 448, sizeof(c), hipMemcpyDeviceToHost));
+                const double n = 8.0 * d.parts * calls * ((d.M / 32) / d.parts);     // (waves x tiles) of trial 0 so far
+                fprintf(stderr, "pass64 timing dbg=%d (trial 0, cycles per wave and tile): phase A %.0f, [exchange+stage reads+barrier %.0f, update+stores %.0f, barrier %.0f, k fragments+barrier %.0f, "
+                        "issue %.0f], phase B %.0f, Y %.0f, load wait %.0f, barrier %.0f; loop %.0f\n", dbg, c[3] / n, c[7] / n, c[8] / n, c[9] / n,
+                        c[10] / n, c[4] / n, c[5] / n, c[6] / n, c[0] / n, c[1] / n, c[2] / n);
+                calls = 0;
+            }
+            return 0;
+        }
+        switch (atoi(getenv("JSTSP_FUSED_DBG"))) {
+            DBG_CASE(1) DBG_CASE(2) DBG_CASE(4) DBG_CASE(8) DBG_CASE(5) DBG_CASE(7) DBG_CASE(13) DBG_CASE(15) DBG_CASE(10)
+        default: break;
+        }
+#undef DBG_CASE
+    }
+#endif
+    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL((fused_pass64_kernel<GB, 0>), dim3(grid), dim3(512), sh, ctx->stream, d);
+    return 0;
+}
+
+template <int GB, bool YIN, bool TOEP> static int launch_fused_gb(jstsp_ctx *ctx, const FusedDesc &d)
 {
     const size_t sh = (size_t)32 * (128 * GB * 8 + FPAD) + 24576;
     const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
-    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB, 0, YIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL((fused_pass_kernel<GB, 0, YIN>), dim3(grid), dim3(512), sh, ctx->stream, d);
+#ifdef JSTSP_FUSED_DBG_BUILD        // timing experiments (tools/pass_breakdown.py): parts of the kernel switched off, results wrong
+    if (GB == 4 && YIN && getenv("JSTSP_FUSED_DBG") && atoi(getenv("JSTSP_FUSED_DBG"))) {
+#define DBG_CASE(k_)                                                                                                          \
+    case k_:                                                                                                                  \
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<4, k_, true, TOEP>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));                                  \
+        hipLaunchKernelGGL((fused_pass_kernel<4, k_, true, TOEP>), dim3(grid), dim3(512), sh, ctx->stream, d);                \
+        return 0;
+        switch (atoi(getenv("JSTSP_FUSED_DBG"))) {
+            DBG_CASE(1) DBG_CASE(2) DBG_CASE(4) DBG_CASE(8) DBG_CASE(5) DBG_CASE(7) DBG_CASE(13) DBG_CASE(15) DBG_CASE(10)
+        default: break;
+        }
+#undef DBG_CASE
+    }
+#endif
+    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass_kernel<GB, 0, YIN, TOEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL((fused_pass_kernel<GB, 0, YIN, TOEP>), dim3(grid), dim3(512), sh, ctx->stream, d);
     return 0;
+}
+
+template <bool YIN, bool TOEP> static int launch_fused_y(jstsp_ctx *ctx, const FusedDesc &d)
+{
+    switch (d.G2 / 128) {
+    case 1: return launch_fused_gb<1, YIN, TOEP>(ctx, d);
+    case 2: return launch_fused_gb<2, YIN, TOEP>(ctx, d);
+    case 3: return launch_fused_gb<3, YIN, TOEP>(ctx, d);
+    default: return launch_fused_gb<4, YIN, TOEP>(ctx, d);
+    }
 }
 
 int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d)
 {
     JSTSP_REQUIRE(fused_shape_ok(64, d.M, d.G2, d.parts), JSTSP_E_UNSUPPORTED, "fused pass: shape");
+    JSTSP_REQUIRE(d.Ec ? (d.gsh >= 4 && d.gsh <= 8) : d.Bf != nullptr, JSTSP_E_UNSUPPORTED, "fused pass: dictionary image");
     prof_begin(ctx, "fused_pass");
     int rc = 0;
-    if (d.Wqp) {
+    if (d.v2) {
+        JSTSP_REQUIRE(d.Wqp && d.Ec && d.XsD && d.Kf && d.gsh == 6, JSTSP_E_UNSUPPORTED, "fused pass: window image");
         switch (d.G2 / 128) {
-        case 1: rc = launch_fused_gb<1, true>(ctx, d); break;
-        case 2: rc = launch_fused_gb<2, true>(ctx, d); break;
-        case 3: rc = launch_fused_gb<3, true>(ctx, d); break;
-        default: rc = launch_fused_gb<4, true>(ctx, d); break;
+        case 1: rc = launch_fused64<1>(ctx, d); break;
+        case 2: rc = launch_fused64<2>(ctx, d); break;
+        case 3: rc = launch_fused64<3>(ctx, d); break;
+        default: rc = launch_fused64<4>(ctx, d); break;
         }
-    } else {        // Y read from memory (JSTSP_FUSED_Y=0)
-        switch (d.G2 / 128) {
-        case 1: rc = launch_fused_gb<1, false>(ctx, d); break;
-        case 2: rc = launch_fused_gb<2, false>(ctx, d); break;
-        case 3: rc = launch_fused_gb<3, false>(ctx, d); break;
-        default: rc = launch_fused_gb<4, false>(ctx, d); break;
-        }
-    }
+    } else
+    if (d.Wqp) rc = d.Ec ? launch_fused_y<true, true>(ctx, d) : launch_fused_y<true, false>(ctx, d);
+    else       rc = d.Ec ? launch_fused_y<false, true>(ctx, d) : launch_fused_y<false, false>(ctx, d);   // Y read from memory (JSTSP_FUSED_Y=0)
     prof_end(ctx, "fused_pass");
     JSTSP_TRY(rc);
     JSTSP_HIP(hipGetLastError());
@@ -587,11 +1323,16 @@ int fused_pack_wq(jstsp_ctx *ctx, const FusedWS &f, const float2 *Q, int batch)
     return 0;
 }
 
-int fused_reduce(jstsp_ctx *ctx, const FusedWS &f, int G2, int batch, float2 *Tc)
+int fused_reduce(jstsp_ctx *ctx, const FusedWS &f, int G2, int M, int batch, float2 *Tc)
 {
     const long long n4 = 64ll * G2 / 2;
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n4 + 255) / 256), batch), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const float4 *>(f.Ppart), f.parts, n4, reinterpret_cast<float4 *>(Tc));
+    if (f.v2)
+        hipLaunchKernelGGL(reduce_parts_delta_kernel, dim3((unsigned)((n4 + 255) / 256), batch), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float4 *>(f.Ppart), f.parts, n4, reinterpret_cast<float4 *>(Tc), f.Kf, f.Bdl,
+                           f.sBdl, G2);
+    else
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n4 + 255) / 256), batch), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float4 *>(f.Ppart), f.parts, n4, reinterpret_cast<float4 *>(Tc));
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

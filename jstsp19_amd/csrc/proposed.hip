@@ -346,7 +346,16 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const bool fusedy = fusedp && fy_env;
     FusedWS fw;
     if (fusedp) {
-        JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts));
+        // a block-Toeplitz dictionary (what the reference's drivers build) is kept as its first block only: probed exactly,
+        // results bit-identical either way (fused.hip); JSTSP_TOEPLITZ=0: always the full tile image
+        // JSTSP_TOEPLITZ=2 (default): block height 64 with Y formed in the pass takes the window kernel (fused_pass64_kernel:
+        // 20-KiB LDS tile, element-wise operands prefetched into LDS; the leading columns as fp32 corrections - not
+        // bit-identical, fp32-equivalent); 1: the compact HBM image only (bit-identical to 0)
+        const int toep_env = getenv("JSTSP_TOEPLITZ") ? atoi(getenv("JSTSP_TOEPLITZ")) : 2;
+        int toep_gt = 0;
+        if (toep_env != 0) JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
+        ctx->last_dict_block = toep_gt;
+        JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts, toep_gt, toep_env >= 2 && fusedy));
         JSTSP_TRY(fused_pack_b(ctx, fw, B, strideB, G2, M, nB, w.Bs.bmax));
         JSTSP_HIP(hipMemsetAsync(fw.ovf, 0, (size_t)batch * sizeof(uint32_t), sm));
     }
@@ -497,7 +506,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         //  and VALU products lose against the MFMA GEMM even at k = 64;  2. the last column range of a problem adding the
         //  partial sums inside the pass: the device-scope fence it needs writes the L2 back, 3.95 -> 4.36 ms)
         if (passed) {
-            JSTSP_TRY(fused_reduce(ctx, fw, G2, batch, w.Tc));
+            JSTSP_TRY(fused_reduce(ctx, fw, G2, M, batch, w.Tc));
         } else if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
             JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, M, batch, Mat{w.ZK, snm, N}, Mat{PB, strideB ? (long long)M * G2 : 0, M},
                            w.Tc, sng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
@@ -571,14 +580,17 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             // the pass writes the operand maxima of iteration it + 1 (k, X, V1, next Z): zero that block now
             uint32_t *nx = kmax0 + (size_t)((it + 1) & 1) * 8 * (size_t)batch;
             JSTSP_HIP(hipMemsetAsync(nx, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
-            JSTSP_TRY(fused_pack_as(ctx, fw, w.W, sng, G2, batch, w.wmax));
+            JSTSP_TRY(fused_pack_as(ctx, fw, w.W, sng, G2, M, batch, w.wmax));
             JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));          // Y of the next iteration (side stream s1)
             FusedDesc fd{fw.Bf, strideB ? fw.sBf : 0, w.Bs.bmax, strideB ? 1 : 0, fw.ASp, fw.sAS, w.wmax, w.kmax,
                          w.X, w.V1, w.V2, subY, w.Y, w.invD, snm, w.prm, fw.Ppart,
                          nx, nx + batch, nx + 2 * (size_t)batch, nx + 4 * (size_t)batch, w.nmax + 2 * (size_t)batch, fw.ovf,
                          M, G2, batch, fparts,
-                         fusedy ? fw.Wqp : nullptr, Zbuf[(it + 1) & 1], w.zmax, Zbuf[it & 1],
-                         (fusedy && it + 2 == Imax) ? w.Y : nullptr, fused_kback};
+                         fusedy ? fw.Wqp : nullptr, Zbuf[(it + 1) & 1], w.zmax,
+                         (fw.v2 && zfly) ? nullptr : Zbuf[it & 1],      // (window kernel: Z comes from the staged X, V1)
+                         (fusedy && it + 2 == Imax) ? w.Y : nullptr, fused_kback,
+                         fw.Ec, strideB ? fw.sEc : 0, fw.gt ? 31 - __builtin_clz((unsigned)fw.gt) : 0, fw.ecols, fw.ehalo,
+                         fw.v2, fw.XsD, fw.Kf};
             JSTSP_TRY(launch_fused_pass(ctx, fd));
             passed = true;
         } else
@@ -653,7 +665,7 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
                                             double *ce_out, int memspace)
 {
     std::vector<int> ovf;
-    if (ctx) ctx->fused_fallbacks = 0;
+    if (ctx) { ctx->fused_fallbacks = 0; ctx->last_dict_block = 0; }
     JSTSP_TRY(proposed_impl(ctx, N, M, Gr, G2, batch, subY, Omega, A, strideA, B, strideB, Imax, tau_Y, tau_S, rho, type,
                             indx_S, S_out, Y_out, ce_out, memspace, true, &ovf));
     // Recovery: runs of consecutive flagged trials are solved again by the three-kernel iteration (every operand scale
@@ -680,5 +692,13 @@ extern "C" int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count)
 {
     JSTSP_REQUIRE(ctx && count, JSTSP_E_NULL, "last_fused_fallbacks: NULL argument");
     *count = ctx->fused_fallbacks;
+    return 0;
+}
+/* Block height Gt of the block-Toeplitz structure the last jstsp_proposed_algorithm_* call found in its dictionary
+ * (B(ld Gt + g, m) == B(g, m - ld) bit for bit; the pass then streams the first block only), 0 if it found none. */
+extern "C" int jstsp_last_dictionary_block(jstsp_ctx *ctx, int *gt)
+{
+    JSTSP_REQUIRE(ctx && gt, JSTSP_E_NULL, "last_dictionary_block: NULL argument");
+    *gt = ctx->last_dict_block;
     return 0;
 }

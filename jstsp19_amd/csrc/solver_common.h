@@ -113,6 +113,16 @@ struct FusedWS {
     uint32_t *ovf = nullptr;                      // [batch]: raised for a trial when a k entry left the f16 range of its scale
     uint4 *Wqp = nullptr;                         // B-operand fragments of (I - Q)^T, 2048 uint4 per problem
     int parts = 0;
+    // block-Toeplitz dictionary (fused.hip, "compact image"): B(ld Gt + g, m) == B(g, m - ld) bit for bit for m >= ld.
+    // Then only block 0 (+ the ld leading columns of block ld) is stored, and the pass's refill reads it at shifted columns.
+    uint4 *Ec = nullptr; long long sEc = 0;       // compact image, uint4 per problem; Bf stays NULL then
+    int gt = 0, ecols = 0, ehalo = 0;             // block height (0: unstructured), chunks per image row, halo chunks before column 0
+    // v2 (block height 64, fused_pass64_kernel): the LDS tile is the 39-column window of block 0 itself; the leading columns
+    // m < ld of block ld (outside the Toeplitz part) are applied as fp32 corrections around the pass
+    int v2 = 0;
+    const float2 *Bsrc = nullptr; long long sBsrc = 0;    // the caller's dictionary
+    float2 *Bdl = nullptr; long long sBdl = 0;            // its leading columns, row-major: [nB][G2][8]
+    float2 *XsD = nullptr, *Kf = nullptr;                 // [batch][64 x 8]: (A S) Delta of this iteration; k(:, 0..6) of the pass
 };
 struct FusedDesc {
     const uint4 *Bf; long long sBf;               // 0: one dictionary for the batch
@@ -131,14 +141,17 @@ struct FusedDesc {
     // maximum, where to put the Z after that; Yout != NULL: also store Y (the last pass: Y is an output of the solver)
     const uint4 *Wqp; const float2 *Zin; const uint32_t *zmax_in; float2 *Zout, *Yout;
     int kback;                                    // headroom of the predicted k scale in bits (KBACK; JSTSP_FUSED_KBACK: tests)
+    const uint4 *Ec; long long sEc; int gsh, ecols, ehalo;   // compact image of a block-Toeplitz dictionary (gsh = log2 Gt; 0: none)
+    int v2; const float2 *XsD; float2 *Kf;                   // fused_pass64_kernel (see FusedWS)
 };
 bool fused_shape_ok(int N, int M, int G2, int parts);
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts);
-int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts);
-int fused_pack_b(jstsp_ctx *ctx, const FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax);
-int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int batch, const uint32_t *wmax);
+int fused_probe_toeplitz(jstsp_ctx *ctx, Arena &ar, const float2 *B, long long sBt, int G2, int M, int nB, int *gt);   // syncs
+int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts, int gt, int v2);
+int fused_pack_b(jstsp_ctx *ctx, FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax);
+int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int M, int batch, const uint32_t *wmax);
 int launch_fused_pass(jstsp_ctx *ctx, const FusedDesc &d);
-int fused_reduce(jstsp_ctx *ctx, const FusedWS &f, int G2, int batch, float2 *Tc);
+int fused_reduce(jstsp_ctx *ctx, const FusedWS &f, int G2, int M, int batch, float2 *Tc);
 int fused_pack_wq(jstsp_ctx *ctx, const FusedWS &f, const float2 *Q, int batch);      // from the raw Q of svt_prepare
 
 }  // namespace jstsp
