@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0              # same guide: HBM3E peak (6.3 TB/s measured achievable)
+MFMA_F16_PEAK_TFLOPS = 2500.0      # same guide: dense BF16/FP16 MFMA peak (2495 TF measured with 32x32x16)
 IMAX = 100
 
 
@@ -267,7 +268,7 @@ def main():
     # FETCH_SIZE doubled as the microarch guide prescribes for gfx950); only valid for the profiled shape
     pm, pm_src = {}, None
     if not a.small and a.batch == 256:
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):      # the newest committed measurement
+        for name in ("r03b_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):      # the newest committed measurement
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pm = json.load(f)
@@ -279,25 +280,67 @@ def main():
     traffic_of = lambda key: pm.get(key, {}).get("hbm_bytes_per_launch")
     roofline = None
     if n_f:
-        # Dominant kernel: fused_pass_kernel (csrc/fused.hip) - per iteration ONE read of the dictionary: Xs = (A S) B (:58), the
-        # V2 / X / V1 / k updates (:61-65, :38-43 of the next iteration, Y = (I - Q) Z formed in the kernel) and the first factor
-        # K B^H of the next :47.  HBM-bound by construction; algorithmic bytes per launch =
-        #   dictionary tiles (4 f16 planes = 8 B per complex entry of B, read once)                       G2*M*8 * nB
-        # + state: read X, V1, V2, subY (8 B each), invD (4 B), Z (8 B); write X, V1, V2, Z (8 B each)    76 * N*M * batch
-        # + (A S) fragments read once per column range, partial sums of K B^H written                     2 * parts * N*G2*8 * batch
-        # (per trial at configs[1]: 16.0 MiB + 19.0 MiB + 2.0 MiB).
         parts = int(os.environ.get("JSTSP_FUSED_PARTS", "4"))
-        bytes_pass = 8.0 * G2 * M * nB + 76.0 * N * M * a.batch + 2.0 * parts * 8.0 * N * G2 * a.batch
         avg_f = ms_f / n_f
-        ach = bytes_pass / (avg_f * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "fused_pass_kernel ((A S) B, element-wise ADMM updates incl. Y = (I - Q) Z, K B^H: one read of "
-                                              "the dictionary per iteration; split-f16 MFMA, tile in LDS)",
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic_of("fused_pass"), "avg_launch_ms": round(avg_f, 4), "launches": n_f,
-                    "bytes_per_launch": bytes_pass,
-                    "algorithmic_tflops": round(2 * flops_per_launch / (avg_f * 1e-3) / 1e12, 1),
-                    "note": "the three kernels this pass replaces (JSTSP_FUSED=0) run at 0.66-0.68 of the HBM peak each but move "
-                            "16.5 GB per iteration instead of 9.9 GB"}
+        gt = ctx.last_dictionary_block()                           # block height of the block-Toeplitz structure found in B (0: none)
+        toep = int(os.environ.get("JSTSP_TOEPLITZ", "2"))
+        window = gt == 64 and toep >= 2
+        # executed MFMA work of the pass: both contractions (8 N G2 M real flops each) as three f16 products (h h + h l + l h)
+        # + Y = (I - Q) Z (8 N N M, three products)
+        mfma_flop = 3.0 * (2 * flops_per_launch + 8.0 * N * N * M * a.batch)
+        mfma = {"executed_tflops": round(mfma_flop / (avg_f * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS,
+                "frac": round(mfma_flop / (avg_f * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                "note": "v_mfma_f32_16x16x32_f16, split-f16 (three products per fp32-equivalent one); dense f16 peak of "
+                        "MI355X_MICROARCH.md"}
+        # what the reference's algorithm moves per iteration in this formulation: the whole dictionary once (8 B per complex
+        # entry as four f16 planes), the state (X, V1, V2, subY, Z, 1/D read; X, V1, V2, Z written: 76 B per entry of N x M),
+        # (A S) fragments and partial sums of K B^H - fused_pass_kernel's bytes, the figure of rounds 2 and 3
+        bytes_full = 8.0 * G2 * M * nB + 76.0 * N * M * a.batch + 2.0 * parts * 8.0 * N * G2 * a.batch
+        if window:
+            # Dominant kernel: fused_pass64_kernel (csrc/fused.hip).  The dictionary of this workload is block-Toeplitz (probed, exact):
+            # only block 0 is streamed (8 B per complex entry of Gt x M), Z is formed from X and V1 in the kernel (neither read
+            # nor, with convergence_error, written).  Algorithmic bytes per launch =
+            #   window image   8 * Gt*M * nB
+            # + state: read X, V1, V2, subY (8 B each), 1/D (4 B); write X, V1, V2 (8 B each) [+ Z without convergence_error]
+            # + (A S) fragments read once per column range, partial sums of K B^H written     2 * parts * N*G2*8 * batch
+            st = 60.0 if not a.no_ce else 68.0
+            bytes_pass = 8.0 * gt * M * nB + st * N * M * a.batch + 2.0 * parts * 8.0 * N * G2 * a.batch
+            ach = bytes_pass / (avg_f * 1e-3) / 1e9
+            hbm = {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                   "bytes_per_launch": bytes_pass}
+            full = bytes_full / (avg_f * 1e-3) / 1e9
+            kname = ("fused_pass64_kernel ((A S) B, element-wise ADMM updates incl. Y = (I - Q) Z, K B^H in one pass; block-Toeplitz "
+                     "dictionary: 20-KiB window of block 0 in LDS, operands of the next tile prefetched into LDS; split-f16 MFMA)")
+            # the kernel sits between its two roofs (both within a factor 3): report the nearer one as `bound`, the other beside it
+            if mfma["frac"] >= hbm["frac"]:
+                roofline = {"bound": "mfma", "kernel": kname, "achieved": mfma["executed_tflops"], "peak": MFMA_F16_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": mfma["frac"], "hbm": hbm}
+            else:
+                roofline = {"bound": "hbm", "kernel": kname, **hbm, "mfma": mfma}
+            roofline.update({"traffic": traffic_of("fused_pass64"), "avg_launch_ms": round(avg_f, 4), "launches": n_f,
+                             "bytes_per_launch": bytes_pass, "dictionary_block": gt,
+                             "algorithmic_tflops": round(2 * flops_per_launch / (avg_f * 1e-3) / 1e12, 1),
+                             "full_dictionary_equivalent": {"bytes_per_launch": bytes_full, "achieved": round(full, 1), "unit": "GB/s",
+                                                            "frac": round(full / HBM_PEAK_GBS, 4),
+                                                            "note": "the bytes an unstructured dictionary needs (fused_pass_kernel, the figure "
+                                                                    "of rounds 2-3) over this kernel's duration - a speed comparison, "
+                                                                    "not traffic"},
+                             "note": "section timings (tools/pass_breakdown.py, profiles/r03_pass64_sections.txt): the two product phases run "
+                                     "at the MFMA issue rate and take 53 % of a tile, the element-wise section 22 %, Y 11 %, barriers 8 %"})
+        else:
+            # Dominant kernel: fused_pass_kernel (csrc/fused.hip) - per iteration ONE read of the dictionary: Xs = (A S) B (:58), the
+            # V2 / X / V1 / k updates (:61-65, :38-43 of the next iteration, Y = (I - Q) Z formed in the kernel) and the first factor
+            # K B^H of the next :47.  HBM-bound by construction (per trial at configs[1]: 16.0 MiB + 19.0 MiB + 2.0 MiB).
+            bytes_pass = bytes_full - (8.0 * (G2 - gt) * M * nB if gt else 0.0)
+            ach = bytes_pass / (avg_f * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "fused_pass_kernel ((A S) B, element-wise ADMM updates incl. Y = (I - Q) Z, K B^H: one read of "
+                                                  "the dictionary per iteration; split-f16 MFMA, tile in LDS)",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "traffic": traffic_of("fused_pass"), "avg_launch_ms": round(avg_f, 4), "launches": n_f,
+                        "bytes_per_launch": bytes_pass, "dictionary_block": gt, "mfma": mfma,
+                        "algorithmic_tflops": round(2 * flops_per_launch / (avg_f * 1e-3) / 1e12, 1),
+                        "note": "the three kernels this pass replaces (JSTSP_FUSED=0) run at 0.66-0.68 of the HBM peak each but move "
+                                "16.5 GB per iteration instead of 9.9 GB"}
         roofline["traffic_source"] = pm_src if roofline["traffic"] else None
         if roofline["traffic"]:     # measured bytes (PMC) over the same duration: what the memory system actually delivers
             roofline["traffic_rate"] = round(roofline["traffic"] / (avg_f * 1e-3) / 1e9, 1)

@@ -716,7 +716,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
     constexpr int SCOL = 144, SFLD = 16 * SCOL, SINV = 4 * SFLD, ICOL = 80, STW = SINV + 16 * ICOL;
     constexpr int STG0 = 2 * EBUF + 24576;
     extern __shared__ __align__(16) unsigned char lds[];
-    unsigned char *xch = lds + 2 * EBUF;       // 24 KiB: phase-A partial sums (16), then the k fragments (6 planes)
+    unsigned char *xch = lds + 2 * EBUF;       // 24 KiB: the k fragments (6 planes)
 
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
@@ -917,10 +917,13 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
             }
         }
         if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[0] += tq - tp; tp = tq; }
-        // the two g-halves meet: wave (nb, kh) keeps m-block kh and hands m-block 1 - kh to wave (nb, 1 - kh)
+        // the two g-halves meet: wave (nb, kh) keeps m-block kh and hands m-block 1 - kh to wave (nb, 1 - kh) - through the
+        // window buffer that is not in use (the next window arrives there during phase B), so that the k fragments below
+        // need not wait for these reads
+        unsigned char *const pex = lds + ((i + 1) & 1) * EBUF;
         {
             const f32x4 sr = kh ? ar[0] : ar[1], si = kh ? ai[0] : ai[1];
-            f32x4 *x4 = reinterpret_cast<f32x4 *>(xch);
+            f32x4 *x4 = reinterpret_cast<f32x4 *>(pex);
             const int dw = nb + 4 * (1 - kh);
             x4[(dw * 2 + 0) * 64 + l] = sr;
             x4[(dw * 2 + 1) * 64 + l] = si;
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
         if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[4] += tq - tp; tp = tq; }
         f32x4 xr = kh ? ar[1] : ar[0], xi = kh ? ai[1] : ai[0];
         {
-            const f32x4 *x4 = reinterpret_cast<const f32x4 *>(xch);
+            const f32x4 *x4 = reinterpret_cast<const f32x4 *>(pex);
             const f32x4 orr = x4[(w * 2 + 0) * 64 + l], oi = x4[(w * 2 + 1) * 64 + l];
             xr += orr; xi += oi;
         }
@@ -976,8 +979,6 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
             fsplit(kk.y * sk, h, lo); kf[2][s] = h; kf[3][s] = lo;
         }
         if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[5] += tq - tp; tp = tq; }
-        __syncthreads();                        // every wave has read its partial sums: the exchange area is free
-        if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[6] += tq - tp; tp = tq; }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             *reinterpret_cast<half4 *>(xch + ((nb * 6 + p) * 64 + l) * 16 + kh * 8) = kf[p];
@@ -988,13 +989,10 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
         if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[7] += tq - tp; tp = tq; }
         // the next tile (the last one is fetched again: unconditional loads): its window goes into the other buffer, its
         // element-wise operands into this wave's staging area (every wave has read what it needs of it: Y above, the operands
-        // before the first barrier).  Pieces 0-7 are requested now, written behind the products of blocks 1 and 2, pieces 8-11
-        // requested then and written behind the last block.
+        // before the first barrier).  One piece is requested behind each product group of phase B and written to LDS six
+        // groups later (eight register slots): requested together, the 8 KiB per wave of all eight waves queue up at the CU's
+        // 64-byte-per-clock load path and every wave waits 1200 cycles before its first product (tools/pass_breakdown.py).
         const int tn = tile0 + min(i + 1, tpw - 1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) F64_LOAD(c, tn, rf[0][c])
-#pragma unroll
-        for (int c = 0; c < 4; ++c) F64_LOAD(4 + c, tn, rf[1][c])
         if (DBG & 16) { const long long tq = __builtin_readcyclecounter(); t_ph[1] += tq - tp; tp = tq; }
         // ================= phase B: P^T += conj(B)(g, tile) k^T(tile, :), this wave: g in [16 GB w, 16 GB (w + 1))
         if (!(DBG & 4)) {
@@ -1029,30 +1027,22 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                     pr[gb][n2] = mma(bf[2], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k0, pi[gb][n2]);
                     pr[gb][n2] = mma(bf[2], k3, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k1, pi[gb][n2]);
                     pr[gb][n2] = mma(bf[3], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[3], k0, pi[gb][n2]);
+                    {
+                        const int grp = 4 * gb + n2;
+                        if (grp >= 6 && grp - 6 < 12) F64_STORE(grp - 6, (i + 1) & 1, rf[((grp - 6) >> 2) & 1][(grp - 6) & 3])
+                        if (grp < 12) F64_LOAD(grp, tn, rf[(grp >> 2) & 1][grp & 3])
+                    }
                     __builtin_amdgcn_sched_barrier(0);      // (else the fragment reads of all four n-blocks are hoisted: spills)
-                }
-                if (GB == 4 && gb == 1) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) { F64_STORE(c, (i + 1) & 1, rf[0][c]) F64_LOAD(8 + c, tn, rf[0][c]) }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (GB == 4 && gb == 2) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) F64_STORE(4 + c, (i + 1) & 1, rf[1][c])
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        if (GB == 4 && !(DBG & 4)) {
+        {
+            constexpr int NG = (DBG & 4) ? 0 : 4 * GB;      // product groups that ran; what is left of the 12 pieces:
 #pragma unroll
-            for (int c = 0; c < 4; ++c) F64_STORE(8 + c, (i + 1) & 1, rf[0][c])
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) F64_STORE(c, (i + 1) & 1, rf[0][c])
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { F64_STORE(4 + c, (i + 1) & 1, rf[1][c]) F64_LOAD(8 + c, tn, rf[0][c]) }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) F64_STORE(8 + c, (i + 1) & 1, rf[0][c])
+            for (int pc = (NG > 6 ? NG - 6 : 0); pc < 12; ++pc) {
+                if (pc >= NG) F64_LOAD(pc, tn, rf[(pc >> 2) & 1][pc & 3])
+                F64_STORE(pc, (i + 1) & 1, rf[(pc >> 2) & 1][pc & 3])
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         F64_WQLOAD()

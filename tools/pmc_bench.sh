@@ -23,29 +23,37 @@ done
 python3 - "$R" "$tag" <<'PY'
 import csv, json, subprocess, sys
 R, tag = sys.argv[1], sys.argv[2]
-out = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    tot, disp, dur = 0.0, set(), 0.0
-    for r in csv.DictReader(open("%s/gpurun_out/%s_pmc_%s.csv" % (R, tag, c))):
-        if "fused_pass" in r["Kernel_Name"] and r["Counter_Name"] == c:
-            tot += float(r["Counter_Value"])
-            if r["Dispatch_Id"] not in disp:
-                disp.add(r["Dispatch_Id"]); dur += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-    out[c] = (tot / max(len(disp), 1), len(disp), dur / max(len(disp), 1) / 1e3)
-fetch_kib, n, us = out["FETCH_SIZE"]
-write_kib = out["WRITE_SIZE"][0]
+def collect(match):
+    out = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        tot, disp, dur = 0.0, set(), 0.0
+        for r in csv.DictReader(open("%s/gpurun_out/%s_pmc_%s.csv" % (R, tag, c))):
+            if match in r["Kernel_Name"] and r["Counter_Name"] == c:
+                tot += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in disp:
+                    disp.add(r["Dispatch_Id"]); dur += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        out[c] = (tot / max(len(disp), 1), len(disp), dur / max(len(disp), 1) / 1e3)
+    fetch_kib, n, us = out["FETCH_SIZE"]
+    write_kib = out["WRITE_SIZE"][0]
+    if not n:
+        return None
+    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md); both counters are in KiB
+    return {"FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "dispatches": n, "avg_us_under_pmc": us,
+            "hbm_read_bytes_per_launch": 2 * 1024 * fetch_kib, "hbm_write_bytes_per_launch": 1024 * write_kib,
+            "hbm_bytes_per_launch": 2 * 1024 * fetch_kib + 1024 * write_kib}
 try:
     build = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "snapshot"
 except OSError:
     build = "snapshot"
-# gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> doubled (MI355X_MICROARCH.md); both counters are in KiB
 doc = {"_how": "tools/pmc_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE, then in a separate pass --pmc WRITE_SIZE, of "
-               "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path` on MI355X; averages per dispatch of "
-               "fused_pass_kernel; FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
-       "build": build,
-       "fused_pass": {"FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "dispatches": n, "avg_us_under_pmc": us,
-                      "hbm_read_bytes_per_launch": 2 * 1024 * fetch_kib, "hbm_write_bytes_per_launch": 1024 * write_kib,
-                      "hbm_bytes_per_launch": 2 * 1024 * fetch_kib + 1024 * write_kib}}
+               "`python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-host-path` on MI355X; averages per dispatch of the "
+               "named kernel; FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)",
+       "build": build}
+for key, match in (("fused_pass64", "fused_pass64_kernel"), ("fused_pass", "fused_pass_kernel"), ("hgram3", "hgram3_kernel"),
+                   ("hgram", "hgram_kernel"), ("hgemm", "hgemm_kernel"), ("jacobi2", "jacobi2_kernel")):
+    v = collect(match)
+    if v:
+        doc[key] = v
 json.dump(doc, open("%s/gpurun_out/%s_pmc_traffic.json" % (R, tag), "w"), indent=1)
-print(json.dumps(doc["fused_pass"]))
+print(json.dumps({k: v for k, v in doc.items() if k.startswith("fused_pass")}))
 PY
