@@ -710,11 +710,13 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
     constexpr int KSH = G2 / 64;               // 32-wide k-steps per g-half
     constexpr int EPL = 40 * 128;              // bytes of one plane of the window: 40 columns x 8 octets x 16 B
     constexpr int EBUF = 4 * EPL;              // 20 KiB
-    // staged element-wise operands of one wave (its 16 rows n x 16 columns m of the tile): X, V1, V2, subY as [column][n]
-    // with 144 bytes per column (the 16 lanes of a Z-fragment read - 16 columns, one 16-byte piece - cover all banks),
-    // then 1/D with 80 bytes per column
-    constexpr int SCOL = 144, SFLD = 16 * SCOL, SINV = 4 * SFLD, ICOL = 80, STW = SINV + 16 * ICOL;
+    // staged element-wise operands of one wave (its 16 rows n x 16 columns m of the tile): X, V1, V2, subY as [column][n],
+    // 128 bytes per column, then 1/D with 80 bytes per column
+    constexpr int SCOL = 128, SFLD = 16 * SCOL, SINV = 4 * SFLD, ICOL = 80, STW = SINV + 16 * ICOL;
     constexpr int STG0 = 2 * EBUF + 24576;
+    // the svt argument Z = X - V1 / rho of the tile as A-operand fragments of Y = (I - Q) Z (16 KiB): [column half kh][k-step ks]
+    // [plane][q][column c16] 16-byte chunks (8 consecutive rows n' = 32 ks + 8 q .. of one column, one f16 plane)
+    constexpr int ZF0 = STG0 + 8 * STW;
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned char *xch = lds + 2 * EBUF;       // 24 KiB: the k fragments (6 planes)
 
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
     float2 *const Yot = d.Yout ? d.Yout + (long long)t * d.snm : nullptr;
     const u32x4 *const wqt = reinterpret_cast<const u32x4 *>(d.Wqp) + (long long)t * 2048;
     const uint32_t wqoff = 16u * (nb * 256 + l);                                                              // bytes
-    const float sy = ldexpf(1.f, -(fscale_exp(d.zmax_in[t]) + 13)), sz = ldexpf(1.f, fscale_exp(d.zmax_in[t]));
+    const float sy = ldexpf(1.f, -(fscale_exp(d.zmax_in[t]) + 13));
     const uint32_t ebase = 8u * (16 * nb + c16 + 64 * (16 * kh + 4 * q));     // bytes; + 512 (m0 + s)
     const u32x4 *const ast = reinterpret_cast<const u32x4 *>(d.ASp) + (long long)t * d.sAS;
     const uint32_t aoff = 16u * ((uint32_t)(kh * KSH) * 1024u + nb * 256 + l);      // bytes
@@ -762,12 +764,18 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
 
     // ---- the 12 pieces of 1 KiB (16 bytes per lane) a wave moves per tile, through registers:
     //   0..2   window of the tile: per plane the 5 KiB at column 32 T of the image, 20 pieces, wave w takes w, w + 8, w + 16
-    //   3..10  X, V1, V2, subY of this wave's block: lane -> rows n = 2 (l & 7), + 1 of column (l >> 3) + 8 j
+    //   3..10  X, V1 (3: X j = 0, 4: V1 j = 0, 5: X j = 1, 6: V1 j = 1), V2 (7, 8), subY (9, 10) of this wave's block:
+    //          lane -> rows n = 2 (l & 7), + 1 of column (l >> 3) + 8 j
     //   11     1/D: lane -> rows 4 (l & 3) .. + 3 of column l >> 2
+    // When the V1 piece of a column half goes to LDS, the X piece of the same half is still in its register slot: the wave
+    // forms Z = X - V1 / rho of its block there and writes it as split-f16 fragments - the four waves of a column half
+    // read fragments (8 reads per tile and lane) instead of every one of them reading and converting X and V1 (32 reads)
     const uint32_t so = 128u * nb + 16u * (l & 7) + 512u * (16 * kh + (l >> 3));
-    const uint32_t io = 64u * nb + 16u * (l & 3) + 256u * (16 * kh + (l >> 2));
     unsigned char *const sdst = stag + (l >> 3) * SCOL + (l & 7) * 16;       // + field SFLD + j 8 SCOL
-    unsigned char *const idst = stag + SINV + (l >> 2) * ICOL + (l & 3) * 16;
+    // rows n' = 16 nb + 2 (l & 7), + 1: k-step nb >> 1, q = 2 (nb & 1) + ((l & 7) >> 2), halves 2 (l & 3), + 1 of the chunk
+    const float sz = ldexpf(1.f, fscale_exp(d.zmax_in[t]));
+#define F64_FLD(pc_) ((pc_) < 7 ? ((pc_) - 3) & 1 : 2 + (((pc_) - 7) >> 1))
+#define F64_J(pc_) ((pc_) < 7 ? ((pc_) - 3) >> 1 : ((pc_) - 7) & 1)
 #define F64_LOAD(pc_, T_, dst_)                                                                                              \
     {                                                                                                                        \
         if ((pc_) < 3) {                                                                                                     \
@@ -777,14 +785,19 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                 dst_ = ldg_nt<u32x4>(Et, (uint32_t)p_ * epl + 4096u * (uint32_t)(T_) + 1024u * j_ + 16u * l);               \
             }                                                                                                                \
         } else if (!(DBG & 2)) {                                                                                             \
-            const uint32_t o_ = so + 16384u * (uint32_t)(T_) + 4096u * (((pc_) - 3) & 1);                                   \
-            if ((pc_) == 3 || (pc_) == 4) dst_ = ldg_nt<u32x4>(Xt, o_);                                                      \
-            if ((pc_) == 5 || (pc_) == 6) dst_ = ldg_nt<u32x4>(V1t, o_);                                                     \
-            if ((pc_) == 7 || (pc_) == 8) dst_ = ldg_nt<u32x4>(V2t, o_);                                                     \
-            if ((pc_) == 9 || (pc_) == 10) dst_ = ldg_nt<u32x4>(sYt, o_);                                                    \
-            if ((pc_) == 11) dst_ = ldg_nt<u32x4>(iDt, io + 8192u * (uint32_t)(T_));                                         \
+            const uint32_t o_ = so + 16384u * (uint32_t)(T_) + 4096u * F64_J(pc_);                                           \
+            if ((pc_) < 11 && F64_FLD(pc_) == 0) dst_ = ldg_nt<u32x4>(Xt, o_);                                               \
+            if ((pc_) < 11 && F64_FLD(pc_) == 1) dst_ = ldg_nt<u32x4>(V1t, o_);                                              \
+            if ((pc_) < 11 && F64_FLD(pc_) == 2) dst_ = ldg_nt<u32x4>(V2t, o_);                                              \
+            if ((pc_) < 11 && F64_FLD(pc_) == 3) dst_ = ldg_nt<u32x4>(sYt, o_);                                              \
+            if ((pc_) == 11) {      /* (lane offsets of the one 1/D piece are formed here, not kept in registers across the tile) */ \
+                int lo_ = l;                                                                                                 \
+                asm volatile("" : "+v"(lo_));                                                                                \
+                dst_ = ldg_nt<u32x4>(iDt, 64u * nb + 16u * (lo_ & 3) + 256u * (16 * kh + (lo_ >> 2)) + 8192u * (uint32_t)(T_)); \
+            }                                                                                                                \
         }                                                                                                                    \
     }
+    // (slot of piece pc: rf[(pc >> 2) & 1][pc & 3]; the X piece of V1 piece pc is pc - 1)
 #define F64_STORE(pc_, buf_, src_)                                                                                           \
     {                                                                                                                        \
         if ((pc_) < 3) {                                                                                                     \
@@ -794,29 +807,46 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                 *reinterpret_cast<u32x4 *>(lds + (buf_) * EBUF + p_ * EPL + j_ * 1024 + 16 * l) = src_;                      \
             }                                                                                                                \
         } else if (!(DBG & 2)) {                                                                                             \
-            if ((pc_) == 11) *reinterpret_cast<u32x4 *>(idst) = src_;                                                        \
-            else *reinterpret_cast<u32x4 *>(sdst + (((pc_) - 3) >> 1) * SFLD + (((pc_) - 3) & 1) * 8 * SCOL) = src_;         \
+            if ((pc_) == 11) {                                                                                               \
+                int lo_ = l;                                                                                                 \
+                asm volatile("" : "+v"(lo_));                                                                                \
+                *reinterpret_cast<u32x4 *>(stag + SINV + (lo_ >> 2) * ICOL + (lo_ & 3) * 16) = src_;                         \
+            }                                                                                                                \
+            else *reinterpret_cast<u32x4 *>(sdst + F64_FLD(pc_) * SFLD + F64_J(pc_) * 8 * SCOL) = src_;                      \
+            if ((pc_) == 4 || (pc_) == 6) {                                                                                  \
+                const f32x4 xv_ = __builtin_bit_cast(f32x4, rf[(((pc_) - 1) >> 2) & 1][((pc_) - 1) & 3]);                    \
+                const f32x4 vv_ = __builtin_bit_cast(f32x4, src_);                                                           \
+                _Float16 h0_, l0_, h1_, l1_;                                                                                 \
+                fsplit((xv_[0] - ir * vv_[0]) * sz, h0_, l0_); fsplit((xv_[2] - ir * vv_[2]) * sz, h1_, l1_);                \
+                typedef _Float16 half2_ __attribute__((ext_vector_type(2)));                                                 \
+                int lz_ = l;                                                                                                 \
+                asm volatile("" : "+v"(lz_));                                                                                \
+                unsigned char *z_ = lds + ZF0 + ((kh * 2 + (nb >> 1)) * 16 + 2 * (nb & 1) + ((lz_ & 7) >> 2)) * 256 +       \
+                                    (lz_ >> 3) * 16 + 4 * (lz_ & 3) + F64_J(pc_) * 128;                                      \
+                *reinterpret_cast<half2_ *>(z_) = half2_{h0_, h1_}; *reinterpret_cast<half2_ *>(z_ + 1024) = half2_{l0_, l1_}; \
+                fsplit((xv_[1] - ir * vv_[1]) * sz, h0_, l0_); fsplit((xv_[3] - ir * vv_[3]) * sz, h1_, l1_);                \
+                *reinterpret_cast<half2_ *>(z_ + 2048) = half2_{h0_, h1_}; *reinterpret_cast<half2_ *>(z_ + 3072) = half2_{l0_, l1_}; \
+            }                                                                                                                \
         }                                                                                                                    \
     }
     u32x4 rf[2][4];
     {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int pc = 0; pc < 8; ++pc) F64_LOAD(pc, tile0, rf[pc >> 2][pc & 3])
 #pragma unroll
-            for (int c = 0; c < 4; ++c) F64_LOAD(4 * r + c, tile0, rf[0][c])
+        for (int pc = 0; pc < 8; ++pc) F64_STORE(pc, 0, rf[pc >> 2][pc & 3])
 #pragma unroll
-            for (int c = 0; c < 4; ++c) F64_STORE(4 * r + c, 0, rf[0][c])
-        }
+        for (int pc = 8; pc < 12; ++pc) F64_LOAD(pc, tile0, rf[0][pc & 3])
+#pragma unroll
+        for (int pc = 8; pc < 12; ++pc) F64_STORE(pc, 0, rf[0][pc & 3])
     }
     __syncthreads();
 
     // phase-A window column of this lane before the delay: block ld = kh GB + (ks >> 1) sits ld columns to the left
     const int cA = c16 + 7 - kh * GB;
     const int cB0 = 4 * q + (c16 >> 2) + 7;    // phase B: window column of this lane's row 4 q + (c16 >> 2), before the delay
-    // Z fragments of Y = (I - Q) Z: columns m = 16 kh + c16 of the tile, rows n' = 32 ks + 8 q .. + 7, from the staged X and V1
-    // of wave (2 ks + (q >> 1), kh)
-    const unsigned char *const zsrc = lds + STG0 + ((q >> 1) + 4 * kh) * STW + c16 * SCOL + (q & 1) * 64;      // + 2 ks STW
-
+    // Z fragments of Y = (I - Q) Z for this lane: column 16 kh + c16, rows n' = 32 ks + 8 q .. + 7
+    const unsigned char *const zsrc = lds + ZF0 + (kh * 2 * 16 + q) * 256 + c16 * 16;      // + ks 4096 + plane 1024
     // the fragments of (I - Q)^T (the same for every tile; no registers to keep them): requested behind the last products of a
     // tile, so that they arrive while the wave waits at the barrier
     u32x4 wq[2][4];
@@ -843,24 +873,11 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
             f32x4 yr = f32x4{0.f, 0.f, 0.f, 0.f}, yi = yr;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                half8 zp[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float4 xv = make_float4(1.f, 1.f, 1.f, 1.f), vv = xv;
-                    if (!(DBG & 2)) {
-                        xv = *reinterpret_cast<const float4 *>(zsrc + 2 * ks * STW + 16 * j);
-                        vv = *reinterpret_cast<const float4 *>(zsrc + 2 * ks * STW + SFLD + 16 * j);
-                    }
-                    const float4 z = make_float4(xv.x - ir * vv.x, xv.y - ir * vv.y, xv.z - ir * vv.z, xv.w - ir * vv.w);
-                    _Float16 h, lo;
-                    fsplit(z.x * sz, h, lo); zp[0][2 * j] = h; zp[1][2 * j] = lo;
-                    fsplit(z.y * sz, h, lo); zp[2][2 * j] = h; zp[3][2 * j] = lo;
-                    fsplit(z.z * sz, h, lo); zp[0][2 * j + 1] = h; zp[1][2 * j + 1] = lo;
-                    fsplit(z.w * sz, h, lo); zp[2][2 * j + 1] = h; zp[3][2 * j + 1] = lo;
-                }
                 u32x4 zf[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) zf[p] = __builtin_bit_cast(u32x4, zp[p]);
+                for (int p = 0; p < 4; ++p)
+                    zf[p] = (DBG & 2) ? u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}
+                                      : *reinterpret_cast<const u32x4 *>(zsrc + ks * 4096 + p * 1024);
                 const u32x4 nwi_h = negu(wq[ks][2]), nwi_l = negu(wq[ks][3]);
                 yr = mma(zf[0], wq[ks][0], yr); yi = mma(zf[0], wq[ks][2], yi);
                 yr = mma(zf[0], wq[ks][1], yr); yi = mma(zf[0], wq[ks][3], yi);
@@ -1059,6 +1076,8 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
     }
 #undef F64_LOAD
 #undef F64_STORE
+#undef F64_FLD
+#undef F64_J
 #undef F64_WQLOAD
     // ---- partial sums of this column range: Ppart[t][part][n + 64 g]
     float2 *po = d.Ppart + ((long long)t * d.parts + part) * (64ll * G2);
@@ -1206,7 +1225,7 @@ int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long s
 
 template <int GB> static int launch_fused64(jstsp_ctx *ctx, const FusedDesc &d)
 {
-    const size_t sh = 2 * 20480 + 24576 + 8 * (4 * 16 * 144 + 16 * 80);
+    const size_t sh = 2 * 20480 + 24576 + 8 * (4 * 16 * 128 + 16 * 80) + 16384;
     const int grid = ((d.batch + 7) / 8) * 8 * d.parts;
 #ifdef JSTSP_FUSED_DBG_BUILD
     if (GB == 4 && getenv("JSTSP_FUSED_DBG") && atoi(getenv("JSTSP_FUSED_DBG"))) {
