@@ -218,24 +218,31 @@ __global__ __launch_bounds__(256) void pack_e2_kernel(const float2 *B, long long
     for (int p = 0; p < 4; ++p) dst[((long long)p * (M + 8) + cc) * 8 + (o ^ eswz(cc))] = *reinterpret_cast<uint4 *>(&pl[p]);
 }
 
-// XsD[t][n + 64 m] = sum over ld > m, g < 64 of W[n, 64 ld + g] B[64 ld + g, m]   (m < L - 1: what the leading columns of the
-// delayed blocks add to Xs = (A S) B; fp32).  One block of 256 threads per (problem, column): lane = n, the four waves split
-// the rows g; Bdl = the leading columns row-major (uniform, consecutive loads).
-__device__ __forceinline__ void xs_delta(const float2 *W, const float2 *Bdl, int G2, int m, float2 *out)
+// XsD[t][r][n + 64 m], summed over r = 0..3: sum over ld > m, g < 64 of W[n, 64 ld + g] B[64 ld + g, m]   (m < L - 1: what the
+// leading columns of the delayed blocks add to Xs = (A S) B; fp32).  Four blocks of 256 threads per (problem, column): lane = n,
+// the sixteen waves split the rows g (the pass adds the four partial sums); Bdl = the leading columns row-major.
+__device__ __forceinline__ void xs_delta(const float2 *W, const float2 *Bdl, int G2, int m, int r, float2 *out)
 {
     __shared__ float2 part[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int g0 = 64 * (m + 1), cnt = G2 - g0;             // rows of the blocks ld > m
+    const int g0 = 64 * (m + 1), cnt = G2 - g0;             // rows of the blocks ld > m; this block: quarter r of them
     float2 a = make_float2(0.f, 0.f), a2 = a;
-    const int per = (cnt + 3) / 4, lo = g0 + wv * per, hi = min(lo + per, G2);
+    const int per = (cnt + 15) / 16, lo = min(g0 + (4 * r + wv) * per, G2), hi = min(lo + per, G2);
+    // (eight rows per trip: the loads of a trip are independent and in flight together - with two, the loop is a chain of
+    //  memory latencies, 75 us for 0.2 MFLOP per problem on the critical path of the iteration)
     int g = lo;
-    for (; g + 1 < hi; g += 2) {
-        const float2 w0 = W[lane + 64ll * g], w1 = W[lane + 64ll * (g + 1)];
-        const float2 b0 = Bdl[g * 8 + m], b1 = Bdl[(g + 1) * 8 + m];
-        a.x = fmaf(w0.x, b0.x, fmaf(-w0.y, b0.y, a.x)); a.y = fmaf(w0.x, b0.y, fmaf(w0.y, b0.x, a.y));
-        a2.x = fmaf(w1.x, b1.x, fmaf(-w1.y, b1.y, a2.x)); a2.y = fmaf(w1.x, b1.y, fmaf(w1.y, b1.x, a2.y));
+    for (; g + 8 <= hi; g += 8) {
+        float2 w[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { w[u] = W[lane + 64ll * (g + u)]; b[u] = Bdl[(g + u) * 8 + m]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            a.x = fmaf(w[u].x, b[u].x, fmaf(-w[u].y, b[u].y, a.x)); a.y = fmaf(w[u].x, b[u].y, fmaf(w[u].y, b[u].x, a.y));
+            a2.x = fmaf(w[u + 1].x, b[u + 1].x, fmaf(-w[u + 1].y, b[u + 1].y, a2.x));
+            a2.y = fmaf(w[u + 1].x, b[u + 1].y, fmaf(w[u + 1].y, b[u + 1].x, a2.y));
+        }
     }
-    if (g < hi) {
+    for (; g < hi; ++g) {
         const float2 w0 = W[lane + 64ll * g], b0 = Bdl[g * 8 + m];
         a.x = fmaf(w0.x, b0.x, fmaf(-w0.y, b0.y, a.x)); a.y = fmaf(w0.x, b0.y, fmaf(w0.y, b0.x, a.y));
     }
@@ -253,8 +260,9 @@ __global__ __launch_bounds__(256) void pack_as_kernel(const float2 *W, long long
                                                       long long sOut, const float2 *Bd, long long sBd, float2 *XsD)
 {
     const int t = blockIdx.y;
-    if ((int)blockIdx.x >= G2 / 32) {            // (v2 only: one more block per leading column of the problem)
-        xs_delta(W + (long long)t * sWt, Bd + (long long)t * sBd, G2, (int)blockIdx.x - G2 / 32, XsD + (long long)t * 512);
+    if ((int)blockIdx.x >= G2 / 32) {            // (v2 only: four more blocks per leading column of the problem)
+        const int e = (int)blockIdx.x - G2 / 32;
+        xs_delta(W + (long long)t * sWt, Bd + (long long)t * sBd, G2, e >> 2, e & 3, XsD + (long long)t * 2048 + (e & 3) * 512);
         return;
     }
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
     const u32x4 *const ast = reinterpret_cast<const u32x4 *>(d.ASp) + (long long)t * d.sAS;
     const uint32_t aoff = 16u * ((uint32_t)(kh * KSH) * 1024u + nb * 256 + l);      // bytes
     const uint4 *const Et = d.Ec + (long long)t * d.sEc;
-    const float2 *const XsDt = d.XsD + (long long)t * 512;
+    const float2 *const XsDt = d.XsD + (long long)t * 2048;
     float2 *const Kft = d.Kf + (long long)t * 512;
     const uint32_t epl = 128u * (uint32_t)d.ecols;                            // bytes per plane of the image
 
@@ -971,8 +979,9 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
             float2 xs = make_float2(xr[s] * sxs, xi[s] * sxs);
             const bool lead = m0 == 0 && kh == 0 && 4 * q + s < 2 * GB - 1;      // a leading column: + (A S) Delta
             if (lead) {                          // (m0 = 0, kh = 0: ix is 8 (n + 64 m))
-                const float2 dx = ldg<float2>(XsDt, ix);
-                xs.x += dx.x; xs.y += dx.y;
+                const float2 d0 = ldg<float2>(XsDt, ix), d1 = ldg<float2>(XsDt, ix + 4096), d2 = ldg<float2>(XsDt, ix + 8192),
+                             d3 = ldg<float2>(XsDt, ix + 12288);
+                xs.x += (d0.x + d1.x) + (d2.x + d3.x); xs.y += (d0.y + d1.y) + (d2.y + d3.y);
             }
             // V2 <- (1 - cc)(V2 - rho (X - Xs))                       (:61 + :65, C == -V2)
             const float2 v2 = make_float2(omc * (ev2[s].x - rho * (ex[s].x - xs.x)), omc * (ev2[s].y - rho * (ex[s].y - xs.y)));
@@ -1125,7 +1134,7 @@ size_t fused_bytes(int M, int G2, int nB, int batch, int parts)
     compact_dims(M, G2, 16, &ec, &eh);                      // (the probe decides between the two images after this is sized)
     return rnd256((size_t)nB * (M / 32) * 16 * G2 * sizeof(uint4)) + rnd256((size_t)batch * (G2 / 32) * 1024 * sizeof(uint4)) +
            rnd256((size_t)batch * parts * 64 * G2 * sizeof(float2)) + rnd256((size_t)batch * sizeof(uint32_t)) + rnd256((size_t)batch * 2048 * sizeof(uint4)) +
-           rnd256((size_t)nB * 4 * (G2 / 16) * ec * sizeof(uint4)) + 2 * rnd256((size_t)batch * 512 * sizeof(float2)) +
+           rnd256((size_t)nB * 4 * (G2 / 16) * ec * sizeof(uint4)) + 5 * rnd256((size_t)batch * 512 * sizeof(float2)) +
            rnd256((size_t)nB * G2 * 8 * sizeof(float2)) + 512;
 }
 
@@ -1169,7 +1178,7 @@ int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int par
         f.ecols = M + 8; f.ehalo = 7;
         f.sEc = 4ll * f.ecols * 8;
         f.Ec = ar.get<uint4>((size_t)nB * f.sEc);
-        f.XsD = ar.get<float2>((size_t)batch * 512);
+        f.XsD = ar.get<float2>((size_t)batch * 2048);
         f.Kf = ar.get<float2>((size_t)batch * 512);
         f.Bdl = ar.get<float2>((size_t)nB * G2 * 8);
         JSTSP_REQUIRE(f.XsD && f.Kf && f.Bdl, JSTSP_E_NOMEM, "fused pass: workspace exhausted");
@@ -1217,7 +1226,7 @@ int fused_pack_b(jstsp_ctx *ctx, FusedWS &f, const float2 *B, long long sBt, int
 int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int M, int batch, const uint32_t *wmax)
 {
     // (v2: two more blocks per problem form (A S) Delta, the leading columns' share of Xs)
-    hipLaunchKernelGGL(pack_as_kernel, dim3((G2 / 32) + (f.v2 ? G2 / 64 - 1 : 0), batch), dim3(256), 0, ctx->stream, W, sWt, G2, wmax,
+    hipLaunchKernelGGL(pack_as_kernel, dim3((G2 / 32) + (f.v2 ? 4 * (G2 / 64 - 1) : 0), batch), dim3(256), 0, ctx->stream, W, sWt, G2, wmax,
                        f.ASp, f.sAS, f.Bdl, f.sBdl, f.XsD);
     JSTSP_HIP(hipGetLastError());
     return 0;

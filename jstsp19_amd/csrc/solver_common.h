@@ -122,7 +122,7 @@ struct FusedWS {
     int v2 = 0;
     const float2 *Bsrc = nullptr; long long sBsrc = 0;    // the caller's dictionary
     float2 *Bdl = nullptr; long long sBdl = 0;            // its leading columns, row-major: [nB][G2][8]
-    float2 *XsD = nullptr, *Kf = nullptr;                 // [batch][64 x 8]: (A S) Delta of this iteration; k(:, 0..6) of the pass
+    float2 *XsD = nullptr, *Kf = nullptr;                 // [batch][4][64 x 8]: (A S) Delta of this iteration in four partial sums; [batch][64 x 8]: k(:, 0..6) of the pass
 };
 struct FusedDesc {
     const uint4 *Bf; long long sBf;               // 0: one dictionary for the batch
