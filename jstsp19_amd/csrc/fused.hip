@@ -25,6 +25,12 @@
 //
 // Shapes: N = 64, G2 = 128, 256, 384 or 512 (GB = G2 / 128 blocks of 16 rows g per wave), M a multiple of 32 * parts.
 // Everything else keeps the three-kernel path.
+//
+// Round 3: when the dictionary is block-Toeplitz in the delay index - B(ld Gt + g, m) == B(g, m - ld), what the reference's
+// drivers build; probed exactly, never assumed - the same pass runs on much less data: fused_pass_kernel<.., TOEP> refills
+// its tile from a compact image of the first block, and for block height 64 fused_pass64_kernel keeps only the 64 x 39
+// window of that block in LDS and uses the room for a prefetch of the next tile's element-wise operands (second half of
+// this file).
 #include "solver_common.h"
 #include <algorithm>
 #include <cstdlib>

@@ -54,6 +54,24 @@ def test_forced_overflow_of_every_trial_is_recovered():
     assert _rel(S1, S0) < 1e-5                                               # and the healthy fused solve agrees anyway
 
 
+def test_forced_overflow_in_the_window_kernel_is_recovered():
+    """The same with a block-Toeplitz dictionary of block height 64, i.e. through fused_pass64_kernel (csrc/fused.hip)."""
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    p = SweepParams(Nt=64, Nr=64, L=4, T=8, Mr=8, snr_db=5.0)
+    assert p.solver_shape == (64, 512, 64, 256)
+    inp = build_trials(p, 0, 5, seed=43)
+    (S0, Y0, c0), _ = _solve(inp, 12, {"JSTSP_FUSED": "0"})
+    (S1, Y1, c1), n1 = _solve(inp, 12)
+    assert n1 == 0 and J.default_context(0).last_dictionary_block() == 64
+    assert _rel(S1, S0) < 1e-5 and _rel(Y1, Y0) < 1e-5
+    (S2, Y2, c2), n2 = _solve(inp, 12, {"JSTSP_FUSED_KBACK": "-20"})
+    assert n2 == 5
+    assert _rel(S2, S0) < 1e-6 and _rel(Y2, Y0) < 1e-6                       # the same kernels as JSTSP_FUSED=0
+    fin = np.isfinite(c0)
+    assert np.array_equal(np.isfinite(c2), fin) and np.max(np.abs(c2[fin] - c0[fin]) / np.abs(c0[fin])) < 1e-4
+
+
 def test_one_trial_whose_k_jumps_is_re_solved_alone_and_matches_the_oracle():
     """A weight matrix Omega with entries just above -2*rho where nothing was sampled makes 1/(Omega + 2 rho) = 1e3 there
     (iK1 of proposed_algorithm.m:14-20 is defined for any Omega): X is zero at those entries after iteration 1 and
