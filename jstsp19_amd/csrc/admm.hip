@@ -305,7 +305,12 @@ int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const flo
                   float2 *S, const int32_t *rank, int cnt, const TrialParams *prm, double *ce3,
                   int Imax, int it, float2 *RV)
 {
-    if (g >= 8192)
+    // (JSTSP_STEPV_NT=512: eight waves per problem - a workgroup that fits on a CU beside a resident eigen-decomposition)
+    static const int nt_env = getenv("JSTSP_STEPV_NT") ? atoi(getenv("JSTSP_STEPV_NT")) : 1024;
+    if (g >= 8192 && nt_env == 512)
+        hipLaunchKernelGGL(step_v_kernel<512>, dim3(batch), dim3(512), 0, ctx->stream, g, Res, RRes, V, S, rank,
+                           cnt, prm, ce3, Imax, it, RV);
+    else if (g >= 8192)
         hipLaunchKernelGGL(step_v_kernel<1024>, dim3(batch), dim3(1024), 0, ctx->stream, g, Res, RRes, V, S, rank,
                            cnt, prm, ce3, Imax, it, RV);
     else
