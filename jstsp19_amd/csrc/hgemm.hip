@@ -606,6 +606,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
     }
 }
 
+// ---- A Gram Z Z^H is Hermitian: with Z = h + l (f16 planes), G = HH + T + T^H, T(i,j) = sum h_i conj(l_j), so the product
+//      stream with the low plane on the other operand is the conjugate transpose of the one already computed.  The Gram
+//      kernels below accumulate A = HH + 2 T (two f16 product streams instead of three) and finish with G = (A + A^H) / 2:
+//      block (wi, wj) of wave (wi, wj) meets the transposed block of wave (wj, wi) in LDS (32 x 32 complex per wave, element
+//      (p, q) at p * 32 + (q ^ p): the writes of a half-wave and the transposed reads both cover all banks).
+__device__ __forceinline__ void herm_symmetrize(f32x16 &re, f32x16 &im, float2 *scr, int wi, int wj, int lane)
+{
+    const int p = lane & 31;
+    float2 *mine = scr + (wi + 2 * wj) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        mine[p * 32 + (q ^ p)] = make_float2(re[r], im[r]);
+    }
+    __syncthreads();
+    const float2 *oth = scr + (wj + 2 * wi) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float2 o = oth[q * 32 + (p ^ q)];                 // element (q, p) of block (wj, wi) = A(j, i)
+        re[r] = 0.5f * (re[r] + o.x); im[r] = 0.5f * (im[r] - o.y);
+    }
+    __syncthreads();
+}
+
 // ---- Gram partials G_s = sum_{k in chunk s} z_k z_k^H of a rows x cols matrix (rows <= 64), same split-f16
 //      arithmetic: ONE panel (64 rows x 32 k, split on the fly) feeds both MFMA operands,
 //        re G(i,j) = sum ar_i ar_j + ai_i ai_j,   im G(i,j) = sum ai_i ar_j - ar_i ai_j.
@@ -683,8 +708,8 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
     auto fold = [&]() {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            Lre[r] += re_h[r] + re_l[r] * LO_INV;
-            Lim[r] += im_h[r] + im_l[r] * LO_INV;
+            Lre[r] += re_h[r] + re_l[r] * (2.f * LO_INV);
+            Lim[r] += im_h[r] + im_l[r] * (2.f * LO_INV);
             re_h[r] = 0.f; re_l[r] = 0.f; im_h[r] = 0.f; im_l[r] = 0.f;
         }
     };
@@ -693,22 +718,19 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
         for (int ks = 0; ks < 2; ++ks) {
             const uint4 *fi = buf + ((wi * 2 + ks) * 4) * 64 + lane;     // rows i: MFMA B operand (tile columns)
             const uint4 *fj = buf + ((wj * 2 + ks) * 4) * 64 + lane;     // rows j: MFMA A operand (tile rows)
-            const half8 ir_h = as_half8(fi[0]), ir_l = as_half8(fi[64]), ii_h = as_half8(fi[128]), ii_l = as_half8(fi[192]);
+            const half8 ir_h = as_half8(fi[0]), ii_h = as_half8(fi[128]);
             const uint4 ujr_h = fj[0], ujr_l = fj[64], uji_h = fj[128], uji_l = fj[192];
             const half8 jr_h = as_half8(ujr_h), jr_l = as_half8(ujr_l), ji_h = as_half8(uji_h), ji_l = as_half8(uji_l);
             const half8 nji_h = neg_half8(uji_h), nji_l = neg_half8(uji_l);
+            // (h h and l h; the h l stream is the conjugate transpose of l h: herm_symmetrize)
             re_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_h, re_h, 0, 0, 0);
             re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ir_h, re_l, 0, 0, 0);
             im_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_h, im_h, 0, 0, 0);
             im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ii_h, im_l, 0, 0, 0);
             re_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_h, re_h, 0, 0, 0);
-            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_l, re_l, 0, 0, 0);
             im_h = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_h, im_h, 0, 0, 0);
-            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_l, im_l, 0, 0, 0);
             re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_l, ii_h, re_l, 0, 0, 0);
             im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_l, ir_h, im_l, 0, 0, 0);
-            re_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_l, re_l, 0, 0, 0);
-            im_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_l, im_l, 0, 0, 0);
         }
     };
     auto stage = [&](int s, const uint4 *cur, uint4 *nxt, Stg &Rnear, Stg &Rfar) {
@@ -733,6 +755,7 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
         }
     }
     fold();
+    herm_symmetrize(Lre, Lim, reinterpret_cast<float2 *>(smem), wi, wj, lane);
     const float alpha = ldexpf(1.f, -2 * ea);
     const int gi = wi * 32 + (lane & 31);
     float2 *Gp = Gpart + ((long long)t * nsplit + split) * rows * rows;
@@ -801,8 +824,8 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             _Float16 h, l;
-            split2(val[u].x * sc, h, l); rh[u] = h; rl[u] = l;
-            split2(val[u].y * sc, h, l); ih[u] = h; il[u] = l;
+            split2(val[u].x * sc, h, l); rh[u] = h; rl[u] = l + l;      // (2 l: the low plane is read as ONE operand only,
+            split2(val[u].y * sc, h, l); ih[u] = h; il[u] = l + l;      //  see herm_symmetrize)
         }
         uint4 *q = panel + a_slot;
         q[0] = *reinterpret_cast<uint4 *>(&rh);
@@ -831,23 +854,19 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
             for (int ks = 0; ks < 2; ++ks) {
                 const uint4 *fi = buf + ((wi * 2 + ks) * 4) * 64 + lane;     // rows i: MFMA B operand (tile columns)
                 const uint4 *fj = buf + ((wj * 2 + ks) * 4) * 64 + lane;     // rows j: MFMA A operand (tile rows)
-                const half8 ir_h = as_half8(fi[0]), ir_l = as_half8(fi[64]), ii_h = as_half8(fi[128]), ii_l = as_half8(fi[192]);
+                const half8 ir_h = as_half8(fi[0]), ii_h = as_half8(fi[128]);
                 const uint4 ujr_h = fj[0], ujr_l = fj[64], uji_h = fj[128], uji_l = fj[192];
                 const half8 jr_h = as_half8(ujr_h), jr_l = as_half8(ujr_l), ji_h = as_half8(uji_h), ji_l = as_half8(uji_l);
                 const half8 nji_h = neg_half8(uji_h), nji_l = neg_half8(uji_l);
-                // re G(i,j) = sum ar_i ar_j + ai_i ai_j ;  im G(i,j) = sum ai_i ar_j - ar_i ai_j   (h h + h l + l h each)
+                // re A(i,j) = sum ar_i ar_j + ai_i ai_j ;  im A(i,j) = sum ai_i ar_j - ar_i ai_j   (h h + (2 l) h: herm_symmetrize)
                 re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_h, re[g], 0, 0, 0);
                 im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_h, im[g], 0, 0, 0);
                 re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_h, re[g], 0, 0, 0);
                 im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_h, im[g], 0, 0, 0);
                 re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ir_h, re[g], 0, 0, 0);
                 im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ii_h, im[g], 0, 0, 0);
-                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ir_l, re[g], 0, 0, 0);
-                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_l, im[g], 0, 0, 0);
                 re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_l, ii_h, re[g], 0, 0, 0);
                 im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_l, ir_h, im[g], 0, 0, 0);
-                re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_l, re[g], 0, 0, 0);
-                im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_l, im[g], 0, 0, 0);
             }
         }
     };
@@ -884,6 +903,8 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
             }
         }
     }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) herm_symmetrize(re[g], im[g], reinterpret_cast<float2 *>(smem), wi, wj, lane);
     const int gi = wi * 32 + (lane & 31);
     const long long po = ((long long)t * nsplit + split) * rows * rows;
     if (gi < rows) {
