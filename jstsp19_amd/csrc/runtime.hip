@@ -286,9 +286,13 @@ int ensure_side_streams(jstsp_ctx *ctx)
     // lowest priority: what runs there has slack, the chain on the context's stream is the critical path of an iteration
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    static const bool prio = getenv("JSTSP_SIDE_PRIO") ? atoi(getenv("JSTSP_SIDE_PRIO")) != 0 : false;      // (measured at configs[1]: 3.96 vs 3.92 ms per iteration with / without)
+    // JSTSP_SIDE_PRIO: 1 - both side streams at the lowest priority (measured at configs[1]: 3.96 vs 3.92 ms per iteration
+    // with / without); 2 - the svt chain (Gram pass -> eigen-decomposition, side stream 0: with the shorter pass of round 3 it
+    // is the longest chain of the window) at the HIGHEST priority, the norm chain at the lowest
+    static const int prio = getenv("JSTSP_SIDE_PRIO") ? atoi(getenv("JSTSP_SIDE_PRIO")) : 0;
     for (int i = 0; i < 2; ++i)
-        if (!ctx->side[i]) JSTSP_HIP(hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, prio ? lo : 0));
+        if (!ctx->side[i])
+            JSTSP_HIP(hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, prio == 1 ? lo : (prio == 2 ? (i == 0 ? hi : lo) : 0)));
     for (int i = 0; i < 8; ++i)
         if (!ctx->ev[i]) JSTSP_HIP(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     return 0;
