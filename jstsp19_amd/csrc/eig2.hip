@@ -194,6 +194,39 @@ __global__ __launch_bounds__(NT) void jacobi2_kernel(int mode, int n, const floa
     const int MAX_SWEEPS = max_sweeps;
     int sweeps_done = 0;
     for (int sweep = 0; sweep < MAX_SWEEPS; ++sweep) {
+        // Function-aware rule on the matrix AS IT STANDS (round 3): the rule below learns the levels a sweep started from only
+        // while rotating, i.e. it confirms convergence with one sweep that changes nothing Y can see.  One pass over the
+        // off-diagonal entries (a hundredth of a sweep) measures the same two quantities before rotating: with a warm start
+        // the basis of the previous ADMM iteration often already satisfies the rule (2.25 -> 1.3 sweeps per call at
+        // BASELINE configs[1]).  Same thresholds, same guarantee; the plain rule keeps its start-of-sweep semantics.
+        if (tv0 > 0.f) {
+            if (tid == 0) { red[0] = 0.f; red[3] = 0.f; }
+            __syncthreads();
+            float cw = 0.f, cf = 0.f;
+            for (int e = tid; e < NE * NE; e += NT) {
+                const int p = e % NE, q = e / NE;
+                if (p >= q) continue;
+                const float a = G[p + LD * p].x, dd = G[q + LD * q].x;
+                const float2 bq = G[p + LD * q];
+                const float ab = __builtin_amdgcn_sqrtf(bq.x * bq.x + bq.y * bq.y);
+                const float scale = __builtin_amdgcn_sqrtf(fabsf(a) * fabsf(dd));
+                if (ab > 0.f && ab > 1e-8f * scale) {
+                    cw = fmaxf(cw, ab * __builtin_amdgcn_rcpf(fmaxf(scale, 1e-3f * dmax)));
+                    const float lo2 = fminf(a, dd);
+                    cf = fmaxf(cf, (lo2 > tv0 * tv0) ? tv0 * ab * __builtin_amdgcn_rcpf(scale + lo2) : 3.0e38f);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { cw = fmaxf(cw, __shfl_xor(cw, o)); cf = fmaxf(cf, __shfl_xor(cf, o)); }
+            if ((tid & 63) == 0) {
+                atomicMax(reinterpret_cast<int *>(&red[0]), __float_as_int(cw));
+                atomicMax(reinterpret_cast<int *>(&red[3]), __float_as_int(cf));
+            }
+            __syncthreads();
+            const float w0 = red[0], f0 = red[3];
+            __syncthreads();
+            if (w0 < 1e-2f && f0 < fn_lim) break;
+        }
         ++sweeps_done;
         if (tid == 0) { red[0] = 0.f; red[3] = 0.f; }
         float worst = 0.f, worst_fn = 0.f;
