@@ -199,7 +199,7 @@ size_t hgemm_pack_bytes(int Kd, int J, int count);
 int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax);
 // b(kk, j) = B[t*sBt + kk*sBk + j*sBj] (conjugated if conj), kk < Kd, j < J; each B[t] spans n_contig contiguous elements
 int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long sBt, long long sBk, long long sBj,
-               int conj, int Kd, int J, int count, long long n_contig);
+               int conj, int Kd, int J, int count, long long n_contig, const uint32_t *bmax_known = nullptr);
 int hgemm_repack(jstsp_ctx *ctx, const HPack &p, const float2 *B, long long sBt, long long sBk, long long sBj, int conj,
                  int Kd, int J, const uint32_t *bmax);
 int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name = nullptr);
@@ -240,7 +240,7 @@ int launch_update_c(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, co
                     float2 *V2, float2 *C, const TrialParams *prm);
 int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const float2 *RRes,
                   float2 *V, float2 *S, const int32_t *rank, int cnt, const TrialParams *prm,
-                  double *ce3, int Imax, int it, float2 *RV = nullptr);    // RV != nullptr: RV += alpha * RRes as well
+                  double *ce3, int Imax, int it, float2 *RV = nullptr, int waves8 = 0);    // RV != nullptr: RV += alpha * RRes as well
 int launch_soft(jstsp_ctx *ctx, int g, int batch, const float2 *V, float2 *S, const int32_t *rank,
                 int cnt, const TrialParams *prm);
 int launch_inv_d(jstsp_ctx *ctx, long long nm, int batch, const float *Omega, float scale2rho,

@@ -1173,6 +1173,45 @@ int fused_probe_toeplitz(jstsp_ctx *ctx, Arena &ar, const float2 *B, long long s
     return 0;
 }
 
+// ---- G_B = B B^H of a block-Toeplitz dictionary from its first block row.  With B(ld Gt + g, m) = B0(g, m - ld) for m >= ld,
+//      block (ld, ld') of G_B, ld <= ld', d = ld' - ld, is
+//        G(0, d)  -  sum_{m < d} B(g, m) conj(B(d Gt + g', m))                 (what block (0, d) owes to its leading columns)
+//                 -  sum_{u = M - ld}^{M - 1} B(g, u) conj(B(g', u - d))       (the ld last terms of the shifted sum)
+//                 +  sum_{m < ld'} B(ld Gt + g, m) conj(B(ld' Gt + g', m))     (the true leading columns of both blocks)
+//      so one Gt x G2 product (1 / L of the G2 x G2 one: 7 -> 1 ms at BASELINE configs[1]) and at most 3 (L - 1) fp32 terms per
+//      entry give all of it; the lower block triangle is the conjugate transpose.
+__global__ __launch_bounds__(256) void toeplitz_gram_kernel(const float2 *B, long long sBt, int G2, int M, int gt, const float2 *G0,
+                                                            float2 *G)
+{
+    const int t = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= G2 * G2) return;
+    const int r = idx % G2, c = idx / G2;
+    const int ld = r / gt, g = r - ld * gt, l2 = c / gt, g2 = c - l2 * gt;
+    if (ld > l2) return;                                    // written by the mirror entry
+    const int d = l2 - ld;
+    const float2 *b = B + (long long)t * sBt;
+    float2 v = G0[(long long)t * gt * G2 + g + (long long)gt * (d * gt + g2)];
+    auto mac = [&](float2 x, float2 y, float sgn) {         // v += sgn x conj(y)
+        v.x += sgn * (x.x * y.x + x.y * y.y);
+        v.y += sgn * (x.y * y.x - x.x * y.y);
+    };
+    for (int m = 0; m < d; ++m) mac(b[g + (long long)G2 * m], b[d * gt + g2 + (long long)G2 * m], -1.f);
+    for (int u = M - ld; u < M; ++u) mac(b[g + (long long)G2 * u], b[g2 + (long long)G2 * (u - d)], -1.f);
+    for (int m = 0; m < l2; ++m) mac(b[r + (long long)G2 * m], b[c + (long long)G2 * m], 1.f);
+    float2 *o = G + (long long)t * G2 * G2;
+    o[r + (long long)G2 * c] = v;
+    if (ld < l2) o[c + (long long)G2 * r] = make_float2(v.x, -v.y);
+}
+
+int toeplitz_gram_assemble(jstsp_ctx *ctx, const float2 *B, long long sBt, int G2, int M, int gt, int nB, const float2 *G0, float2 *G)
+{
+    hipLaunchKernelGGL(toeplitz_gram_kernel, dim3((unsigned)((G2 * G2 + 255) / 256), nB), dim3(256), 0, ctx->stream, B, sBt, G2, M, gt,
+                       G0, G);
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
 int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts, int gt, int v2)
 {
     f.parts = parts;

@@ -951,7 +951,7 @@ int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, in
 }
 
 int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long sBt, long long sBk, long long sBj,
-               int conj, int Kd, int J, int count, long long n_contig)
+               int conj, int Kd, int J, int count, long long n_contig, const uint32_t *bmax_known)
 {
     p.KS = 4 * ((Kd + 63) / 64);           // k padded to 64: an even number of 32-k stages (hgemm2_kernel, PD = 2)
     p.JT = 4 * ((J + 127) / 128);          // j padded to the 128-wide tile of the 8-wave kernel
@@ -960,7 +960,9 @@ int hgemm_pack(jstsp_ctx *ctx, HPack &p, Arena &ar, const float2 *B, long long s
     p.data = ar.get<uint4>((size_t)count * p.st);
     p.bmax = ar.get<uint32_t>(count);
     JSTSP_REQUIRE(p.data && p.bmax, JSTSP_E_NOMEM, "workspace exhausted (packed dictionary)");
-    JSTSP_TRY(hgemm_absmax(ctx, B, n_contig, sBt, count, p.bmax));
+    // (bmax_known: the maxima of the same array from an earlier pack in the other orientation - one pass over it less)
+    if (bmax_known) JSTSP_HIP(hipMemcpyAsync(p.bmax, bmax_known, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    else JSTSP_TRY(hgemm_absmax(ctx, B, n_contig, sBt, count, p.bmax));
     const long long slots = (long long)p.JT * p.KS * 64;
     pack_b_kernel<<<dim3((unsigned)((slots + 255) / 256), count), 256, 0, ctx->stream>>>(B, sBt, sBk, sBj, conj, Kd, J,
                                                                                          p.KS, p.JT, p.bmax, p.data);

@@ -183,6 +183,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const bool want_fused = allow_fused && (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : true) && approx &&
                             Imax > 1 && fused_shape_ok(N, M, G2, fparts);
     if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);
+    need += rnd256((size_t)nB * (G2 / 2 + 1) * G2 * sizeof(float2)) + 1024;      // first block row of G_B (block-Toeplitz B), probe flags
     if (memspace == JSTSP_HOST) {
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
                 rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
@@ -235,16 +236,40 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     if (angles) JSTSP_TRY(launch_rank_from_index(ctx, (int)g, batch, indx_S, w.rank));
 
     const Mat Am{A, strideA, N}, Bm{B, strideB, G2};
+    // JSTSP_TOEPLITZ (fused.hip): 0 - the dictionary is taken as unstructured; 1 - a block-Toeplitz one gets the compact HBM image
+    // of the fused pass (bit-identical results); 2 (default) - also the window kernel for block height 64 (fp32-equivalent, not
+    // bit-identical)
+    const int toep_env = getenv("JSTSP_TOEPLITZ") ? atoi(getenv("JSTSP_TOEPLITZ")) : 2;
+    int toep_gt = 0;
+    bool toep_probed = false;
     const Mat GAm{w.GA, strideA ? (long long)Gr * Gr : 0, Gr}, GBm{w.GB, strideB ? (long long)G2 * G2 : 0, G2};
     // G_A = A^H A (Gr x Gr), G_B = B B^H (G2 x G2):  R = K2'*K2 = G_B^T (x) G_A
     JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
     if (w.h2) {
         // pack the dictionary first: G_B = B B^H is itself "a = B, b = conj(B)^T" on the split-f16 path
         JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
-        JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M));
-        HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, w.GB,
-                     (long long)G2 * G2, G2, G2, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
-        JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
+        JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M, w.Bc.bmax));
+        // Opt-in (JSTSP_TOEPLITZ_GRAM=1): a block-Toeplitz dictionary (probed: fused.hip) needs only the first block row of G_B,
+        // 1 / L of the product (7 -> 1 ms per call at BASELINE configs[1], +1.4 % channel-estimates/s).  Off by default: every
+        // block on a block diagonal then carries the SAME rounding error of that one row, which adds up coherently in
+        // G_A V G_B instead of averaging out - max |dNMSE| against the float64 port 8.1e-7 -> 1.36e-6 over 48 trials.
+        const bool toep_gram = getenv("JSTSP_TOEPLITZ_GRAM") ? atoi(getenv("JSTSP_TOEPLITZ_GRAM")) != 0 : false;
+        if (toep_env >= 2 && toep_gram) {
+            JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
+            toep_probed = true;
+        }
+        if (toep_gt && toep_gram) {
+            float2 *G0 = ctx->arena.get<float2>((size_t)nB * toep_gt * G2);
+            JSTSP_REQUIRE(G0, JSTSP_E_NOMEM, "workspace exhausted (G_B block row)");
+            HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, G0,
+                         (long long)toep_gt * G2, toep_gt, toep_gt, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
+            JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
+            JSTSP_TRY(toeplitz_gram_assemble(ctx, B, strideB, G2, M, toep_gt, nB, G0, w.GB));
+        } else {
+            HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, w.GB,
+                         (long long)G2 * G2, G2, G2, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
+            JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
+        }
     } else
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
 
@@ -351,9 +376,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         // JSTSP_TOEPLITZ=2 (default): block height 64 with Y formed in the pass takes the window kernel (fused_pass64_kernel:
         // 20-KiB LDS tile, element-wise operands prefetched into LDS; the leading columns as fp32 corrections - not
         // bit-identical, fp32-equivalent); 1: the compact HBM image only (bit-identical to 0)
-        const int toep_env = getenv("JSTSP_TOEPLITZ") ? atoi(getenv("JSTSP_TOEPLITZ")) : 2;
-        int toep_gt = 0;
-        if (toep_env != 0) JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
+        if (toep_env != 0 && !toep_probed) JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
         ctx->last_dict_block = toep_gt;
         JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts, toep_gt, toep_env >= 2 && fusedy));
         JSTSP_TRY(fused_pack_b(ctx, fw, B, strideB, G2, M, nB, w.Bs.bmax));
@@ -371,8 +394,11 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // `it` is issued in the NEXT loop iteration, behind the three-Gram pass of that window; 0: as in round 2.
     // With that, the Gram partials of the three norms are double-buffered by iteration parity (gn / gn2) and ALL three
     // lambda_max of an iteration are ONE launch (3 x batch matrices fill the chip once) instead of two half-empty ones.
-    const int ce_gate = getenv("JSTSP_CE_GATE") ? atoi(getenv("JSTSP_CE_GATE")) : 1;
-    const int svt_order_env = getenv("JSTSP_SVT_ORDER") ? atoi(getenv("JSTSP_SVT_ORDER")) : 0;
+    // End of round 3, with the shorter pass and the Jacobi that stops a sweep earlier (eig2.hip): the Gram pass starts with the
+    // window, the eigen-decomposition behind the G_B apply (JSTSP_SVT_ORDER=2), the norm chain as in round 2 (JSTSP_CE_GATE=0)
+    // and an eight-wave step kernel (admm.hip) - 3.040 against 3.078 ms per iteration for (0, 1, 16 waves), three runs each.
+    const int ce_gate = getenv("JSTSP_CE_GATE") ? atoi(getenv("JSTSP_CE_GATE")) : 0;
+    const int svt_order_env = getenv("JSTSP_SVT_ORDER") ? atoi(getenv("JSTSP_SVT_ORDER")) : 2;
     const int svt_gatepos = getenv("JSTSP_SVT_GATEPOS") ? atoi(getenv("JSTSP_SVT_GATEPOS")) : 0;
     hipEvent_t ev_q1 = ctx->ev[7];
     const bool dbuf = ce_gate && fusedp && zfly && want_ce;
@@ -553,7 +579,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             }
             //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
-                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr));
+                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr, svt_order != 0));
         } else {
             //    v = U\(L\k) = pinv(A) K pinv(B)   [ = G_A^-1 (A^H Tc) G_B^-1 on the Gram route: GA / GB hold the inverses ]  (:53)
             float2 *left = PB ? w.V : w.P1;        // result of the A side; the B side (if any) finishes into V

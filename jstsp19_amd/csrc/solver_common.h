@@ -147,6 +147,8 @@ struct FusedDesc {
 bool fused_shape_ok(int N, int M, int G2, int parts);
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts);
 int fused_probe_toeplitz(jstsp_ctx *ctx, Arena &ar, const float2 *B, long long sBt, int G2, int M, int nB, int *gt);   // syncs
+// G_B = B B^H (G2 x G2, column-major) of a block-Toeplitz dictionary from its first block row G0 = B(0:gt, :) B^H (gt x G2)
+int toeplitz_gram_assemble(jstsp_ctx *ctx, const float2 *B, long long sBt, int G2, int M, int gt, int nB, const float2 *G0, float2 *G);
 int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts, int gt, int v2);
 int fused_pack_b(jstsp_ctx *ctx, FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax);
 int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int M, int batch, const uint32_t *wmax);

@@ -76,7 +76,10 @@ def test_probe_finds_the_block_and_results_are_bit_identical(Nt, L, T, batch):
     _same(r1, r0)
     r2, gt2, n2 = _solve(inp, 12)
     assert gt2 == Nt and n2 == 0
-    (_close if Nt == 64 else _same)(r2, r0)
+    (_close if Nt == 64 else _same)(r2, r0)                      # (default: the window kernel for block height 64)
+    r3, gt3, _ = _solve(inp, 12, {"JSTSP_TOEPLITZ_GRAM": "1"})     # opt-in: G_B from its first block row
+    assert gt3 == Nt
+    _close(r3, r0)
 
 
 def test_headline_shape_shared_and_per_trial_pilots():
@@ -99,6 +102,8 @@ def test_headline_shape_shared_and_per_trial_pilots():
     z0, _, _ = _solve(inp, 8, {"JSTSP_TOEPLITZ": "0"}, B=Bz)
     assert gt == 64
     _same(z2, z0)
+    z3, _, _ = _solve(inp, 8, {"JSTSP_TOEPLITZ_GRAM": "1"}, B=Bz)   # (G_B from its first block row: equal to rounding only)
+    _close(z3, z0)
     sh = build_trials(p, 0, 9, seed=5, shared_pilots=True)
     s0, _, _ = _solve(sh, 8, {"JSTSP_TOEPLITZ": "0"}, B=sh["B"][0])
     for env, cmp in (({"JSTSP_TOEPLITZ": "1"}, _same), (None, _close)):
@@ -147,6 +152,9 @@ def test_gaussian_pilots_of_the_training_model(T):
     r0, _, _ = _solve(inp, 10, {"JSTSP_TOEPLITZ": "0"})
     assert gt1 == 16
     _same(r1, r0)
+    r2, gt2, _ = _solve(inp, 10, {"JSTSP_TOEPLITZ_GRAM": "1"})
+    assert gt2 == 16
+    _close(r2, r0)
 
 
 def test_leading_columns_are_free_and_one_changed_entry_ends_the_structure():
@@ -162,12 +170,15 @@ def test_leading_columns_are_free_and_one_changed_entry_ends_the_structure():
         B[:, ld * Gt:(ld + 1) * Gt, :ld] = 0.3 * torch.complex(torch.randn(blk.shape, generator=g, device=B.device),
                                                                torch.randn(blk.shape, generator=g, device=B.device))
     assert B.stride() == inp["B"].stride()
-    r1, gt1, _ = _solve(inp, 10, B=B)
+    r1, gt1, _ = _solve(inp, 10, {"JSTSP_TOEPLITZ": "1"}, B=B)
     r0, _, _ = _solve(inp, 10, {"JSTSP_TOEPLITZ": "0"}, B=B)
     assert gt1 == Gt
     _same(r1, r0)
-    ref, _, _ = _solve(inp, 10)
-    assert r1[0].tobytes() != ref[0].tobytes()                   # (the changed columns do reach the result)
+    r4, gt4, _ = _solve(inp, 10, {"JSTSP_TOEPLITZ_GRAM": "1"}, B=B)   # opt-in: G_B from its first block row + the leading columns
+    assert gt4 == Gt
+    _close(r4, r0)
+    ref, _, _ = _solve(inp, 10, {"JSTSP_TOEPLITZ": "0"})
+    assert np.max(np.abs(r1[0] - ref[0])) > 1e-3 * np.max(np.abs(ref[0]))     # (the changed columns do reach the result)
     # one entry of one trial's dictionary off by one ulp, deep inside: no structure any more, same results as without probe
     B2 = inp["B"].clone()
     v = torch.view_as_real(B2)
