@@ -183,7 +183,12 @@ struct HGemmDesc {
     uint32_t *amax_v2;          // EPI_UPDATE_C: optional [batch] atomicMax of max(|re|,|im|) of the new V2
     // optional: the a operand packed like b (hgemm_pack with j = i): then A is not read, amax = the pack's bmax
     const uint4 *Ap; long long sApt; int aKS;
+    // the product is Hermitian (a Gram: b = conj(a)^T): tiles entirely below the diagonal are not computed - the caller fills the
+    // lower triangle from the upper one (hermitian_fill_lower)
+    int herm_upper;
 };
+// G[r, c] = conj(G[c, r]) for r > c, count matrices of order n (column-major, leading dimension n, stride sGt)
+int hermitian_fill_lower(jstsp_ctx *ctx, float2 *G, long long sGt, int n, int count);
 // Gram partials of a rows x cols matrix, rows <= 64 (same layout as the GEMM_GRAM split-K output):
 // Gpart[(t*nsplit + s)*rows*rows + i + rows*j];  amax[t] bounds max(|re|,|im|) of Z[t]
 // skip_prm != nullptr: problems with prm[t].tauY_rho <= 2^-27 amax[t] are skipped (see jacobi2_kernel)

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
     const int rem = slot % tiles;
     const int ti = rem % tiles_i, tj = rem / tiles_i;
     const int i0 = ti * 64, j0 = tj * 32 * WJ;
+    if (d.herm_upper && i0 >= j0 + 32 * WJ) return;     // Hermitian product: this tile lies below the diagonal
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
@@ -1015,6 +1016,34 @@ int launch_hgram3(jstsp_ctx *ctx, const float2 *X, const float2 *V1, long long s
         hgram3_kernel<false><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx,
                                                                        Gv, count);
     prof_end(ctx, "gram");
+    JSTSP_HIP(hipGetLastError());
+    return 0;
+}
+
+// lower triangle of a Hermitian matrix from its upper one: tile (bi, bj), bi >= bj, is the conjugate transpose of tile (bj, bi)
+__global__ __launch_bounds__(256) void herm_fill_kernel(float2 *G, long long sGt, int n)
+{
+    __shared__ float2 tl[32][33];
+    const int nt = (n + 31) / 32;
+    const int bi = blockIdx.x % nt, bj = blockIdx.x / nt;
+    if (bi < bj) return;
+    float2 *g = G + (long long)blockIdx.y * sGt;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) {                      // upper tile: rows 32 bj + tx, columns 32 bi + y
+        const int r = 32 * bj + tx, c = 32 * bi + y;
+        tl[y][tx] = (r < n && c < n) ? g[r + (long long)n * c] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) {                      // lower tile: rows 32 bi + tx, columns 32 bj + y
+        const int r = 32 * bi + tx, c = 32 * bj + y;
+        if (r < n && c < n && r > c) g[r + (long long)n * c] = make_float2(tl[tx][y].x, -tl[tx][y].y);
+    }
+}
+
+int hermitian_fill_lower(jstsp_ctx *ctx, float2 *G, long long sGt, int n, int count)
+{
+    const int nt = (n + 31) / 32;
+    herm_fill_kernel<<<dim3((unsigned)(nt * nt), count), 256, 0, ctx->stream>>>(G, sGt, n);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

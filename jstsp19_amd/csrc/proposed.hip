@@ -266,9 +266,12 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
             JSTSP_TRY(toeplitz_gram_assemble(ctx, B, strideB, G2, M, toep_gt, nB, G0, w.GB));
         } else {
+            // (G_B is Hermitian: the tiles below its diagonal - 12 of 32 at G2 = 512 - are not computed but mirrored)
             HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, w.GB,
                          (long long)G2 * G2, G2, G2, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
+            hb.herm_upper = getenv("JSTSP_GB_HERM") ? atoi(getenv("JSTSP_GB_HERM")) != 0 : 1;
             JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
+            if (hb.herm_upper) JSTSP_TRY(hermitian_fill_lower(ctx, w.GB, (long long)G2 * G2, G2, nB));
         }
     } else
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
