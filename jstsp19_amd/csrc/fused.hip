@@ -159,6 +159,31 @@ __global__ __launch_bounds__(256) void toeplitz_probe_kernel(const float2 *B, lo
     if ((threadIdx.x & 63) == 0 && (bad & ~__atomic_load_n(mism, __ATOMIC_RELAXED))) atomicOr(mism, bad);
 }
 
+// the same for ONE block height over all dictionaries (the confirming pass): four entries per thread, 16-byte loads
+__global__ __launch_bounds__(256) void toeplitz_verify_kernel(const float2 *B, long long sBt, int G2, int M, int c, uint32_t *mism)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;     // quad of rows g = 4 (q mod G2/4) .. + 3 of column q / (G2/4)
+    const uint32_t qpc = (uint32_t)G2 >> 2;
+    uint32_t bad = 0;
+    if (q < qpc * (uint32_t)M) {
+        const int m = (int)(q / qpc), g = 4 * (int)(q - (uint32_t)m * qpc);
+        const int gt = 16 << c, ld = g >> (4 + c);
+        if (ld >= 1 && m >= ld) {
+            const uint4 *b = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint2 *>(B) + (long long)blockIdx.y * sBt);
+            const uint32_t e = (uint32_t)g + (uint32_t)G2 * (uint32_t)m;     // (even: 16-byte aligned pairs)
+            const uint4 x0 = b[e >> 1], x1 = b[(e >> 1) + 1];
+            const uint32_t f = e - (uint32_t)gt - (uint32_t)G2;
+            const uint4 y0 = b[f >> 1], y1 = b[(f >> 1) + 1];
+            if (x0.x != y0.x || x0.y != y0.y || x0.z != y0.z || x0.w != y0.w || x1.x != y1.x || x1.y != y1.y || x1.z != y1.z ||
+                x1.w != y1.w)
+                bad = 1u << c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && (bad & ~__atomic_load_n(mism, __ATOMIC_RELAXED))) atomicOr(mism, bad);
+}
+
 __global__ __launch_bounds__(256) void pack_e_kernel(const float2 *B, long long sBt, int G2, int M, int gt, int ecols, int ehalo,
                                                      const uint32_t *bmax, int sbmax, uint4 *out, long long sOut)
 {
@@ -1161,7 +1186,11 @@ int fused_probe_toeplitz(jstsp_ctx *ctx, Arena &ar, const float2 *B, long long s
     // nearly every entry: testing all five on the whole batch is five times the traffic for nothing)
     for (int step = 0; step < (nB > 1 ? 2 : 1) && cand; ++step) {
         JSTSP_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(toeplitz_probe_kernel, dim3(nblk, step ? nB : 1), dim3(256), 0, ctx->stream, B, sBt, G2, M, cand, flag);
+        if (step && sBt % 2 == 0)
+            hipLaunchKernelGGL(toeplitz_verify_kernel, dim3((nblk + 3) / 4, nB), dim3(256), 0, ctx->stream, B, sBt, G2, M,
+                               31 - __builtin_clz(cand), flag);
+        else
+            hipLaunchKernelGGL(toeplitz_probe_kernel, dim3(nblk, step ? nB : 1), dim3(256), 0, ctx->stream, B, sBt, G2, M, cand, flag);
         JSTSP_HIP(hipGetLastError());
         uint32_t bad = ~0u;
         JSTSP_HIP(hipMemcpyAsync(&bad, flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
