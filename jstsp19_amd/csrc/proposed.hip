@@ -408,12 +408,13 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     auto gn_of = [&](int i) -> GramWS & { return (dbuf && (i & 1)) ? w.gn2 : w.gn; };
     int ce_pending = -1;
     const uint32_t *ce_nmax = nullptr;
-    auto issue_ce_v2 = [&](int itc, const uint32_t *nmax_it, hipEvent_t gate) -> int {
+    auto issue_ce_v2 = [&](int itc, const uint32_t *nmax_it, hipEvent_t gate, hipEvent_t gate2 = nullptr) -> int {
         JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
         if (gate) JSTSP_HIP(hipStreamWaitEvent(s2, gate, 0));
         StreamScope sc(ctx, s2);
         JSTSP_TRY(gram_partials_range(ctx, gn_of(itc), w.X, snm, 2 * batch, batch, nmax_it));
         JSTSP_HIP(hipEventRecord(ev_gv2, s2));
+        if (gate2) JSTSP_HIP(hipStreamWaitEvent(s2, gate2, 0));      // (the lambda_max launch also reads G_x, G_v1 of the Gram pass)
         if (dbuf) JSTSP_TRY(lmax_from_partials(ctx, gn_of(itc), w.lam, true));
         else JSTSP_TRY(lmax_from_partials_range(ctx, gn_of(itc), 2 * batch, batch, w.lam, true));
         JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, itc));
@@ -481,7 +482,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
                                         w.prm, w.gz.Gpart, gn_of(it).Gpart, gn_of(it).Gpart + (size_t)batch * N * N * w.gn.nsplit));
                 JSTSP_HIP(hipEventRecord(ev_gxv, s1));
-                if (ce_pending >= 0) {      // the previous iteration's Gram of V2, lambda_max and ratio: behind this Gram pass
+                if (ce_pending >= 0 && ce_gate != 2) {      // the previous iteration's Gram of V2, lambda_max and ratio: behind this Gram pass
                     JSTSP_TRY(issue_ce_v2(ce_pending, ce_nmax, ev_gxv));
                     ce_pending = -1;
                 }
@@ -536,6 +537,11 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         //  partial sums inside the pass: the device-scope fence it needs writes the L2 back, 3.95 -> 4.36 ms)
         if (passed) {
             JSTSP_TRY(fused_reduce(ctx, fw, G2, M, batch, w.Tc));
+            if (ce_gate == 2 && ce_pending >= 0) {      // (experiment: the Gram of V2 behind the head of the critical chain only)
+                JSTSP_HIP(hipEventRecord(ev_q1, sm));
+                JSTSP_TRY(issue_ce_v2(ce_pending, ce_nmax, ev_q1, ev_gxv));
+                ce_pending = -1;
+            }
         } else if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
             JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, M, batch, Mat{w.ZK, snm, N}, Mat{PB, strideB ? (long long)M * G2 : 0, M},
                            w.Tc, sng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
