@@ -810,7 +810,6 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
     // forms Z = X - V1 / rho of its block there and writes it as split-f16 fragments - the four waves of a column half
     // read fragments (8 reads per tile and lane) instead of every one of them reading and converting X and V1 (32 reads)
     const uint32_t so = 128u * nb + 16u * (l & 7) + 512u * (16 * kh + (l >> 3));
-    unsigned char *const sdst = stag + (l >> 3) * SCOL + (l & 7) * 16;       // + field SFLD + j 8 SCOL
     // rows n' = 16 nb + 2 (l & 7), + 1: k-step nb >> 1, q = 2 (nb & 1) + ((l & 7) >> 2), halves 2 (l & 3), + 1 of the chunk
     const float sz = ldexpf(1.f, fscale_exp(d.zmax_in[t]));
 #define F64_FLD(pc_) ((pc_) < 7 ? ((pc_) - 3) & 1 : 2 + (((pc_) - 7) >> 1))
@@ -851,7 +850,11 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                 asm volatile("" : "+v"(lo_));                                                                                \
                 *reinterpret_cast<u32x4 *>(stag + SINV + (lo_ >> 2) * ICOL + (lo_ & 3) * 16) = src_;                         \
             }                                                                                                                \
-            else *reinterpret_cast<u32x4 *>(sdst + F64_FLD(pc_) * SFLD + F64_J(pc_) * 8 * SCOL) = src_;                      \
+            else {      /* (lane offset formed here, not kept in a register across the tile) */                              \
+                int ls_ = l;                                                                                                 \
+                asm volatile("" : "+v"(ls_));                                                                                \
+                *reinterpret_cast<u32x4 *>(stag + (ls_ >> 3) * SCOL + (ls_ & 7) * 16 + F64_FLD(pc_) * SFLD + F64_J(pc_) * 8 * SCOL) = src_; \
+            }                                                                                                                \
             if ((pc_) == 4 || (pc_) == 6) {                                                                                  \
                 const f32x4 xv_ = __builtin_bit_cast(f32x4, rf[(((pc_) - 1) >> 2) & 1][((pc_) - 1) & 3]);                    \
                 const f32x4 vv_ = __builtin_bit_cast(f32x4, src_);                                                           \
