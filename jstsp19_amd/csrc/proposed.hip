@@ -248,7 +248,8 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     if (w.h2) {
         // pack the dictionary first: G_B = B B^H is itself "a = B, b = conj(B)^T" on the split-f16 path
         JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
-        JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M, w.Bc.bmax));
+        // (the synthesis orientation w.Bs is packed at its first use: with the fused pass that is the last iteration of a
+        //  three-output call and never in a two-output call - pack_bs below)
         // Opt-in (JSTSP_TOEPLITZ_GRAM=1): a block-Toeplitz dictionary (probed: fused.hip) needs only the first block row of G_B,
         // 1 / L of the product (7 -> 1 ms per call at BASELINE configs[1], +1.4 % channel-estimates/s).  Off by default: every
         // block on a block diagonal then carries the SAME rounding error of that one row, which adds up coherently in
@@ -382,7 +383,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         if (toep_env != 0 && !toep_probed) JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
         ctx->last_dict_block = toep_gt;
         JSTSP_TRY(fused_alloc(ctx->arena, fw, M, G2, nB, batch, fparts, toep_gt, toep_env >= 2 && fusedy));
-        JSTSP_TRY(fused_pack_b(ctx, fw, B, strideB, G2, M, nB, w.Bs.bmax));
+        JSTSP_TRY(fused_pack_b(ctx, fw, B, strideB, G2, M, nB, w.Bc.bmax));
         JSTSP_HIP(hipMemsetAsync(fw.ovf, 0, (size_t)batch * sizeof(uint32_t), sm));
     }
     // headroom (bits) of the k scale the pass predicts from the previous iteration's maximum; JSTSP_FUSED_KBACK is a
@@ -603,6 +604,9 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(launch_soft(ctx, (int)g, batch, w.V, w.S, w.rank, (int)cnt_ll, w.prm));     // (:56)
         }
         // -- Xs = A S B                                                                      (:58)
+        // (the last iteration of a two-output call on the fused path: Xs only feeds X, V2 and convergence_error, none of which
+        //  is returned - S is final, Y was stored by the last pass)
+        if (fusedp && !want_ce && it + 1 == Imax) break;
         if (w.h2) {
             GemmDesc dw = make_gemm('N', 'N', N, G2, Gr, batch, Am, Mat{w.S, sg, Gr}, w.W, sng, N);
             dw.amax_out = w.wmax;                       // max|A S| for the split-f16 synthesis
@@ -617,7 +621,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_HIP(hipMemsetAsync(nx, 0, 8 * (size_t)batch * sizeof(uint32_t), sm));
             JSTSP_TRY(fused_pack_as(ctx, fw, w.W, sng, G2, M, batch, w.wmax));
             JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));          // Y of the next iteration (side stream s1)
-            FusedDesc fd{fw.Bf, strideB ? fw.sBf : 0, w.Bs.bmax, strideB ? 1 : 0, fw.ASp, fw.sAS, w.wmax, w.kmax,
+            FusedDesc fd{fw.Bf, strideB ? fw.sBf : 0, w.Bc.bmax, strideB ? 1 : 0, fw.ASp, fw.sAS, w.wmax, w.kmax,
                          w.X, w.V1, w.V2, subY, w.Y, w.invD, snm, w.prm, fw.Ppart,
                          nx, nx + batch, nx + 2 * (size_t)batch, nx + 4 * (size_t)batch, w.nmax + 2 * (size_t)batch, fw.ovf,
                          M, G2, batch, fparts,
@@ -633,6 +637,8 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             static const bool apack = getenv("JSTSP_H2_APACK") ? atoi(getenv("JSTSP_H2_APACK")) != 0 : true;
             if (apack)      // a(i, k = g) = W[i + N g] in fragment order, once per iteration instead of once per j-tile
                 JSTSP_TRY(hgemm_repack(ctx, w.Wp, w.W, sng, N, 1, 0, G2, N, w.wmax));
+            if (!w.Bs.data)
+                JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M, w.Bc.bmax));
             HGemmDesc hs{w.W, sng, N, w.wmax, w.Bs.data, strideB ? w.Bs.st : 0, w.Bs.bmax, strideB ? 1 : 0, w.Bs.KS,
                          w.Bs.JT, w.Xs, snm, N, N, M, G2, batch, fz ? EPI_UPDATE_C : EPI_NONE, w.prm, w.X, w.V2,
                          hmax ? w.nmax + 2 * (size_t)batch : nullptr, apack ? w.Wp.data : nullptr, w.Wp.st, w.Wp.KS};
