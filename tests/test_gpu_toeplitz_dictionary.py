@@ -192,3 +192,28 @@ def test_leading_columns_are_free_and_one_changed_entry_ends_the_structure():
     B3 = B3.permute(0, 2, 1).contiguous().permute(0, 2, 1)       # column-major like the builder's
     _, gt3, _ = _solve(inp, 4, B=B3)
     assert gt3 == 0
+
+
+@pytest.mark.parametrize("L,T,batch,Imax", [(8, 1, 1, 2),        # one trial, one tile per... M = 64: 2 tiles, ONE pass
+                                            (8, 2, 7, 3),        # batch not a multiple of the 8 XCDs, M = 128: 4 tiles in 4 ranges
+                                            (2, 17, 3, 5),       # M = 1088: 34 tiles in 2 ranges
+                                            (8, 11, 19, 4),      # M = 704: 22 tiles in 2 ranges, 19 trials
+                                            (4, 5, 300, 3)])     # more trials than CUs
+def test_window_kernel_at_odd_batch_sizes_and_frame_lengths(L, T, batch, Imax):
+    from jstsp19_amd.system_model import build_trials
+    import jstsp19_amd as J
+    p = _params(64, L, T)
+    inp = build_trials(p, 0, batch, seed=100 + batch)
+    os.environ["JSTSP_H2"] = "2"                                 # (frames this short would not take the split-f16 path otherwise)
+    try:
+        r0, _, _ = _solve(inp, Imax, {"JSTSP_TOEPLITZ": "0"})
+        r1, gt1, n1 = _solve(inp, Imax, {"JSTSP_TOEPLITZ": "1"})
+        r2, gt2, n2 = _solve(inp, Imax)
+        w0, _, _ = _solve(inp, Imax, {"JSTSP_TOEPLITZ": "0"}, want_ce=False)
+        w2, gtw, _ = _solve(inp, Imax, want_ce=False)
+    finally:
+        os.environ.pop("JSTSP_H2", None)
+    assert gt1 == 64 and gt2 == 64 and gtw == 64 and n1 == 0 and n2 == 0
+    _same(r1, r0)
+    _close(r2, r0)
+    _close(w2, w0)
