@@ -214,7 +214,9 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
 
 /* x = vamp(y, A, sigma, L)   benchmark_algorithms/vamp.m:1-55 (VampGlmEst.m:347-511 with the
  * Bernoulli-Gaussian denoiser SparseScaEstim/CAwgnEstimIn and the CAwgnEstimOut likelihood).
- * Dense dictionary A: M x N with min(M, N) <= 128 (strideA 0 = shared); y: M x batch; x_out: N x batch.
+ * Dense dictionary A: M x N with min(M, N) <= 2048 (strideA 0 = shared); y: M x batch; x_out: N x batch.  Above order 128 the
+ * eigen-decomposition of A*A' (or A'*A) is the library's block Jacobi (csrc/eig_large.hip): the drivers' own call
+ * vamp(y, kron((B*B').', A), 1, numOfnz) with its 512 x 512 dictionary (plot_errorVSsnr.m:79-80,100) goes through unchanged.
  * M <= N runs VampGlmEst.m:402-406 with U, d from A*A'; M > N runs :407-411 with V, d from the eigen-decomposition of
  * A'*A - vamp.m passes opt.U and opt.d but no opt.V, so VampGlmEst.m:196-218 recomputes both in that case.
  * sigma = noise variance passed to the likelihood (every driver passes 1), L = expected number of
@@ -223,7 +225,7 @@ int jstsp_vamp_c32(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c32 *y, 
                    long long strideA, double sigma, double L, int nit, jstsp_c32 *x_out, int memspace);
 
 /* The same for the dictionary the drivers actually pass (plot_errorVSsnr.m:79-80,100):
- *   Phi = kron(Gb.', Af),  y = vec(Y),  Af: Na x Gr (min(Na, Gr) <= 128; Na > Gr is the M > N branch),  Gb: G2 x G2 Hermitian (G2 <= 8192; above 128
+ *   Phi = kron(Gb.', Af),  y = vec(Y),  Af: Na x Gr (min(Na, Gr) <= 2048; Na > Gr is the M > N branch),  Gb: G2 x G2 Hermitian (G2 <= 8192; above 128
  *   its eigen-decomposition is the library's block Jacobi (csrc/eig_large.hip) - as is every Gram eigenproblem above order 128:
  *   svt / mc_svt / mc_admm / proposed_algorithm with min(rows, cols) in 129..2048, sparse_admm with max(Mr, Mt) in 129..2048).
  * Phi is never formed.  Y: Na x G2 x batch; X_out: Gr x G2 x batch (x = vec(X)). */

@@ -224,7 +224,8 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
     float2 *Ub = a.get<float2>((size_t)nG * G2 * G2);
     float *lamA = a.get<float>((size_t)nA * Na), *lamB = a.get<float>((size_t)nG * G2);
     const int nea = (Na + 1) & ~1, neb = (G2 + 1) & ~1;
-    float2 *Vga = a.get<float2>((size_t)nA * nea * nea), *Vgb = a.get<float2>(G2 <= 128 ? (size_t)nG * neb * neb : 16);
+    // (orders above 128 go to the block Jacobi of eig_large.hip, which brings its own stream-ordered temporaries)
+    float2 *Vga = a.get<float2>(Da <= 128 ? (size_t)nA * nea * nea : 16), *Vgb = a.get<float2>(G2 <= 128 ? (size_t)nG * neb * neb : 16);
     VampScal *sc = a.get<VampScal>(batch);
     JSTSP_REQUIRE(r1 && x1 && r2 && x2 && u3 && p1 && p2 && z2 && z2o && Ar2 && E && T1 && T2 && tq && tdq && q && dq &&
                       AAh && Ua && Ub && lamA && lamB && Vga && Vgb && sc,
@@ -291,11 +292,11 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
 static size_t vamp_bytes(int Na, int Gr, int G2, int batch, int nA, int nG)
 {
     const size_t bN = (size_t)batch * Gr * G2, bM = (size_t)batch * Na * G2;
-    const int nea = (Na + 1) & ~1, neb = (G2 + 1) & ~1;
+    const int Da = std::min(Na, Gr), nea = (Da + 1) & ~1, neb = (G2 + 1) & ~1;
     return 6 * rnd256(bN * sizeof(float2)) + 10 * rnd256(bM * sizeof(float2)) + 2 * rnd256(bM * sizeof(float)) +
            2 * rnd256((size_t)nA * Na * Na * sizeof(float2)) + rnd256((size_t)nG * G2 * G2 * sizeof(float2)) +
            rnd256((size_t)nA * Na * sizeof(float)) + rnd256((size_t)nG * G2 * sizeof(float)) +
-           rnd256((size_t)nA * nea * nea * sizeof(float2)) + rnd256((G2 <= 128 ? (size_t)nG * neb * neb : 16) * sizeof(float2)) +
+           rnd256((Da <= 128 ? (size_t)nA * nea * nea : 16) * sizeof(float2)) + rnd256((G2 <= 128 ? (size_t)nG * neb * neb : 16) * sizeof(float2)) +
            rnd256(batch * sizeof(VampScal)) + 4096;
 }
 
@@ -313,8 +314,10 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
     JSTSP_REQUIRE(Y_ && Af_ && Gb_ && X_out, JSTSP_E_NULL, "vamp_kron: NULL array argument");
     JSTSP_REQUIRE(Na > 0 && Gr > 0 && G2 > 0 && batch > 0 && nit >= 1, JSTSP_E_SHAPE, "vamp_kron: bad shape");
     JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
-    JSTSP_REQUIRE(std::min(Na, Gr) <= 128 && G2 <= 8192, JSTSP_E_UNSUPPORTED,
-                  "vamp_kron: min(Na, Gr) = %d, G2 = %d: the factor eigenproblems are limited to orders 128 and 8192",
+    // the dense call of the drivers, vamp(y, kron((B*B').', A), 1, numOfnz) (plot_errorVSsnr.m:79-80,100), arrives here with
+    // G2 = 1 and a 512 x 512 "A factor": orders above 128 take the block Jacobi of eig_large.hip on either side
+    JSTSP_REQUIRE(std::min(Na, Gr) <= 2048 && G2 <= 8192, JSTSP_E_UNSUPPORTED,
+                  "vamp_kron: min(Na, Gr) = %d, G2 = %d: the factor eigenproblems are limited to orders 2048 and 8192",
                   std::min(Na, Gr), G2);
     JSTSP_REQUIRE(sigma > 0 && Lnz > 0 && Lnz < 2.0 * Gr * G2, JSTSP_E_ARG, "vamp: need sigma > 0 and 0 < L < nx");
     JSTSP_ENTER(ctx);
@@ -338,7 +341,7 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
     return 0;
 }
 
-// x = vamp(y, A, sigma, L) with a dense dictionary A (M x N, M <= min(N, 128)): the Kronecker form
+// x = vamp(y, A, sigma, L) with a dense dictionary A (M x N, min(M, N) <= 2048): the Kronecker form
 // with G2 = 1, Gb = 1.
 int jstsp_vamp_c32(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c32 *y, const jstsp_c32 *A, long long strideA,
                    double sigma, double Lnz, int nit, jstsp_c32 *x_out, int memspace)

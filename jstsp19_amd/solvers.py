@@ -432,7 +432,8 @@ def omp_kron(Af, Bf, y, m, *, ctx=None):
 
 
 def vamp(y, A, sigma, L, *, nit=100, ctx=None):
-    """benchmark_algorithms/vamp.m:1 — ``x = vamp(y, A, sigma, L)`` (dense dictionary, M <= min(N, 128)).
+    """benchmark_algorithms/vamp.m:1 — ``x = vamp(y, A, sigma, L)`` (dense dictionary, min(M, N) <= 2048:
+    the drivers' 512 x 512 ``kron((B*B').', A)`` included).
     ``y``: (M,) or (batch, M).  ``nit`` = 100 is what the reference always runs."""
     a_A = _Arg(A, np.complex64, "A")
     tor = _is_torch(y)

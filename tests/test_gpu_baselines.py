@@ -211,6 +211,49 @@ def test_vamp_statistical_parity_over_48_trials():
         assert abs((e_hip >= 1.0).mean() - (e_ref >= 1.0).mean()) <= 0.15, db
 
 
+def test_vamp_dense_at_the_drivers_size_is_the_unchanged_call():
+    """The reference's own call (plot_errorVSsnr.m:73-80,100): ``Phi = kron((B*B').', A)`` - 512 x 512 at the driver's
+    parameters - ``y = vec(Y*B')``, ``x = vamp(y, Phi, 1, numOfnz)``.  Dense dictionaries above order 128 take the block
+    Jacobi of csrc/eig_large.hip (round 4; the entry refused them before): the dense result follows the literal float64
+    restatement (dense real-stacked SVD, oracle.vamp.vamp_literal) over the first iterations and equals the factored form
+    ``vamp_kron`` of the same system; per-trial dictionaries are one batched call."""
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    from oracle import solvers as O
+    from oracle import vamp as V
+    nt, numOfnz = 3, 100                                                   # plot_errorVSsnr.m:26
+    p = SweepParams(Nt=4, Nr=32, L=4, T=35, Mr=4, snr_db=6.0)
+    inp = build_trials(p, 0, nt, seed=616, with_hbf=True)
+    Bh = inp["B_hbf"].cpu().numpy().astype(np.complex128)                 # (nt, L*Gt, T_hbf)           :76-78
+    Yh = inp["Y_hbf"].cpu().numpy().astype(np.complex128)
+    A = inp["A_hbf"].cpu().numpy().astype(np.complex128)                  # W'*Dr                        :75
+    Gb = Bh @ Bh.conj().transpose(0, 2, 1)
+    Ym = Yh @ Bh.conj().transpose(0, 2, 1)
+    Phi = np.stack([np.kron(Gb[t].T, A) for t in range(nt)])              # :79
+    y = np.stack([Ym[t].flatten("F") for t in range(nt)])                 # :80
+    assert Phi.shape == (nt, 512, 512)
+    for nit, tol in ((1, 2e-5), (5, 2e-4), (12, 1e-2)):
+        xd = np.asarray(J.vamp(y, Phi, 1.0, numOfnz, nit=nit))             # batched: one dictionary per trial
+        xk = np.asarray(J.vamp_kron(Ym, A, Gb, 1.0, numOfnz, nit=nit))
+        for t in range(nt):
+            ref = V.vamp_literal(y[t], Phi[t], 1.0, numOfnz, nit=nit)
+            assert rel_err(xd[t], ref) < tol, (nit, t, rel_err(xd[t], ref))
+            assert rel_err(xd[t], xk[t].flatten("F")) < 2 * tol, (nit, t)
+    # single (2-D) call == the batched call's first problem; 100 iterations: finite, same quality as the factored form
+    x1 = np.asarray(J.vamp(y[0], Phi[0], 1.0, numOfnz, nit=5))
+    assert rel_err(x1, np.asarray(J.vamp(y, Phi, 1.0, numOfnz, nit=5))[0]) < 1e-5
+    xd = np.asarray(J.vamp(y, Phi, 1.0, numOfnz))
+    assert np.all(np.isfinite(xd))
+    zb = inp["Zbar"].cpu().numpy()
+    e_d = np.array([O.nmse_capped(xd[t].reshape(32, 16, order="F"), zb[t]) for t in range(nt)])
+    e_r = np.array([O.nmse_capped(V.vamp_literal(y[t], Phi[t], 1.0, numOfnz).reshape(32, 16, order="F"), zb[t]) for t in range(nt)])
+    assert abs(e_d.mean() - e_r.mean()) < 0.25 * e_r.mean() + 0.05, (e_d, e_r)
+    # the limit that remains is stated: order 2049 is refused
+    with pytest.raises(J.JstspError):
+        J.vamp(np.zeros(2049, np.complex64), np.zeros((2049, 2050), np.complex64), 1.0, 10, nit=1)
+
+
 def test_vamp_m_greater_n_branch():
     """VampGlmEst.m:407-411 (M > N; V and d from eig(A'A) as :196-218 recompute them): dense 30 x 12 and Kronecker with
     Na = 10 > Gr = 4 against the literal float64 restatement's fixture, per iteration count; batched == single."""

@@ -71,3 +71,32 @@ def test_bench_under_the_launcher_with_one_rank_uses_rccl():
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 1 and json.loads(lines[0])["value"] > 0
+
+
+def test_bench_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """The first N > 1 RCCL run of this code should not be the driver's 8-GPU scaling run: on any box with at least two GPUs
+    this launches `bench.py --gpus 2` (headline step and configs[3] sweep; bench.py starts its two ranks itself) and checks
+    the line - trials of both ranks counted, the sweep's per-point means equal to the one-rank run's (the trial -> rank
+    partition must not change a result: inputs are keyed by global (point, trial) ids, the NMSE sums meet in ONE all-reduce).
+    Self-skips on the 1-GPU boxes of the test pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % torch.cuda.device_count())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = lambda args: subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--small"] + args, capture_output=True,
+                                      text=True, timeout=1200, cwd=ROOT, env=env)
+    r = run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert abs(j["value"] - 2 * 8 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3          # whole-job: both ranks' trials
+    two = run(["--gpus", "2", "--sweep", "--sweep-trials", "12", "--batch", "8"])
+    one = run(["--sweep", "--sweep-trials", "12", "--batch", "8"])
+    assert two.returncode == 0 and one.returncode == 0, (two.stderr[-1500:], one.stderr[-1500:])
+    j2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
+    assert j2["mean_nmse_proposed"] == pytest.approx(j1["mean_nmse_proposed"], abs=2e-6)
+    assert j2["mean_nmse_angles"] == pytest.approx(j1["mean_nmse_angles"], abs=2e-6)

@@ -227,3 +227,31 @@ def test_gateway_omp_svt_and_the_baselines(mex):
     assert rel(Sl, np.linalg.pinv(A) @ Yl @ np.linalg.pinv(B)) < 1e-3
     (nm,) = call(mex, 1, "nmse", Sl, 1.3 * Sl)
     assert abs(float(nm.reshape(-1)[0]) - O.nmse_capped(Sl, 1.3 * Sl)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_gateway_vamp_with_the_drivers_dense_512_dictionary(mex):
+    """plot_errorVSsnr.m:73-80,100 through the gateway, as the driver writes it: ``Phi = kron((B*B').', A)`` (512 x 512),
+    ``y = vec(Y*B')``, ``vamp(y, Phi, 1, numOfnz)``.  The gateway always runs the reference's 100 iterations, where VAMP in this
+    configuration is chaotic, so what is checked here is the plumbing - shapes, finiteness, agreement of
+    the dense call with the factored ``vamp_kron`` command in estimation quality; tests/test_gpu_baselines.py holds the
+    per-iteration comparison with the float64 restatement."""
+    from oracle import solvers as O
+    rng = np.random.default_rng(12)
+    c = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    Nr, Gr, G2, Th = 32, 32, 16, 16
+    A = c(Nr, Gr) / np.sqrt(Nr)
+    B = c(G2, Th) / np.sqrt(Th)
+    Z = np.zeros((Gr, G2), complex)
+    Z.flat[rng.choice(Gr * G2, 6, replace=False)] = 4 * c(6)
+    Y = A @ Z @ B + 0.05 * c(Nr, Th)
+    Gb = B @ B.conj().T
+    Phi = np.kron(Gb.T, A)                                                 # :79
+    y = (Y @ B.conj().T).flatten("F")                                      # :80
+    assert Phi.shape == (512, 512)
+    (x,) = call(mex, 1, "vamp", y, Phi, 1.0, 100)                          # :100
+    assert x.shape in ((512, 1), (512,)) and np.all(np.isfinite(x))
+    (Xk,) = call(mex, 1, "vamp_kron", Y @ B.conj().T, A, Gb, 1.0, 100)
+    e_d = O.nmse_capped(x.reshape(Gr, G2, order="F"), Z)
+    e_k = O.nmse_capped(Xk, Z)
+    assert abs(e_d - e_k) < 0.25 * max(e_k, 0.05) + 0.05, (e_d, e_k)

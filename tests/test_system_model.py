@@ -251,3 +251,15 @@ def test_convergence_curve_and_zy_runners_with_oracle_solver():
     np.testing.assert_allclose(one[0, 0], _oracle_curves(inp, 12)[0][0].numpy(), rtol=1e-12)
     zy = run_zy([pts[0].replace(rho_scale=0.5)], 3, Imax=10, batch=2, device=torch.device("cpu"), solve_fn=_oracle_zy).numpy()
     assert zy.shape == (1, 2) and np.all(zy > 0) and np.all(zy <= 1)
+
+
+def test_published_admmiters_panel_has_the_oracles_decay_shape():
+    """results/errorVSadmmiters.fig, first panel ('N_T=4, L_R=24, SNR=5db'), against the float64 oracle as the solver hook
+    (CPU tier of tests/test_gpu_published_curves.py::test_published_convergence_curves_have_our_decay_shape; 8 realisations)."""
+    from test_gpu_published_curves import admmiters_panel_points, admmiters_published, check_admmiters_shape
+    from jstsp19_amd.montecarlo import run_convergence_curves
+    pub = admmiters_published()
+    pts = admmiters_panel_points(pub)
+    assert (pts[1].Nt, pts[1].Mr, pts[2].snr_db, pts[3].Mr) == (8, 24, 15.0, 19)
+    cur = run_convergence_curves(pts[:1], 8, Imax=70, batch=8, device=torch.device("cpu"), solve_fn=_oracle_curves).numpy()
+    check_admmiters_shape(cur, pub, [0])
