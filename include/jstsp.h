@@ -70,6 +70,31 @@ const char *jstsp_version(void);
 /* Device bytes currently held by the context's workspace. */
 size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
 
+/* ---- Environment ----------------------------------------------------------------------
+ * The library reads these variables and no others.  All are diagnostic or opt-in; every one is parsed ONCE at the entry of
+ * each API call (none is latched for the process), so a setting may differ from call to call and is constant within one.
+ * Unset = the default, which is the path every reported number and every parity statement refers to.
+ *   JSTSP_H2=0            strict complex-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every contraction; default 1: contractions of
+ *                         at least 2^22 complex MACs per problem run as split-f16 MFMA with fp32 accumulation (fp32-equivalent,
+ *                         see "Accuracy" below); 2: split-f16 whatever the size
+ *   JSTSP_FUSED=0         proposed_algorithm: three kernels per iteration instead of the one-pass kernel (csrc/fused.hip)
+ *   JSTSP_FUSED_PARTS=n   column ranges per problem in that pass (default: 4, 2 or 1 by divisibility of M / 32)
+ *   JSTSP_FUSED_KBACK=b   headroom bits of the operand scale the pass predicts (default 4; a negative value is the test hook
+ *                         that forces the per-trial re-solve, jstsp_last_fused_fallbacks)
+ *   JSTSP_TOEPLITZ=0|1    0: the dictionary is not probed for block-Toeplitz structure; 1: probed, compact image with the
+ *                         general pass kernel only; default 2: block height 64 also takes the window kernel
+ *   JSTSP_TOEPLITZ_GRAM=1 opt-in: B*B' of a block-Toeplitz dictionary from its first block row (measured max |dNMSE| 1.4e-6:
+ *                         outside the parity statement, hence off)
+ *   JSTSP_RV_REFRESH=n    proposed_algorithm 'approximate': R*v recomputed from v every n iterations (default 4; 1 = always)
+ *   JSTSP_OVERLAP=0|1     side streams between the kernels of an iteration (default: on with the one-pass kernel)
+ *   JSTSP_SVT_SKIP=1      opt-in: a trial whose svt threshold is below 2^-27 max|Z| skips its eigen-decomposition (Y = Z is
+ *                         then the fp32 answer); never used for a reported number
+ *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
+ *   JSTSP_EIG128=0        general Jacobi kernel (basis in HBM) for Gram orders 65..128
+ *   JSTSP_OMP_GRAM=0      jstsp_omp_kron: measurement-space OMP instead of the coefficient-domain kernel
+ *   JSTSP_BJ_TRACE=1      print the block Jacobi's convergence (orders above 128) per sweep to stderr
+ * (JSTSP_DEVICE=<id> is read by the MEX gateway, not by the library.) */
+
 /* ---- kernel-level entry points (the north-star correlation / synthesis) ------------ */
 
 /* Accuracy of the two products below (and of the same contractions inside the solvers).  Results are fp32.  Large
@@ -136,8 +161,15 @@ int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count);
  * dictionaries of the reference's drivers stack L delayed copies of one pilot frame under the transmit steering vectors
  * (errorVSsnr.m:36-47), which makes them block-Toeplitz: B(ld*Gt + g, m) == B(g, m - ld) for m >= ld, G2 = L*Gt.  The
  * library PROBES that (exact comparison of every entry, once per call) and, where it holds, streams only the first block
- * in each iteration; results are bit-identical to the unstructured path.  *gt = the block height used, 0 = none found
- * (any B is accepted; an unstructured one just costs the full read).  JSTSP_TOEPLITZ=0 in the environment skips the probe. */
+ * in each iteration.  *gt = the block height used, 0 = none found (any B is accepted; an unstructured one just costs the
+ * full read).  JSTSP_TOEPLITZ=0 in the environment skips the probe.
+ * What the structure changes in the results: with JSTSP_TOEPLITZ=1 (compact image, same kernel, same products) NOTHING -
+ * bit-identical to the unstructured path.  With the default (2), block height 64 takes the window kernel, which applies the
+ * leading columns of each delayed block as separate fp32 terms: fp32-EQUIVALENT to the unstructured path (same accuracy
+ * against float64, S within 2e-5 relative of it), not bit-identical.  The probe covers ALL dictionaries of a call and the
+ * kernel is chosen per call: one unstructured B among per-trial dictionaries moves every trial of that call to the general
+ * kernel, so a trial's result BITS (not its accuracy) can depend on its batch mates.  Results of one call with given inputs
+ * are bit-reproducible from run to run. */
 int jstsp_last_dictionary_block(jstsp_ctx *ctx, int *gt);
 
 /* S_ls = pinv(A)*Y*pinv(B)   — the LS baseline of the drivers (plot_errorVSsnr.m:83).

@@ -307,9 +307,7 @@ int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const flo
 {
     // waves8 (the caller runs an eigen-decomposition beside this kernel): eight waves per problem - a workgroup that fits on a
     // CU beside a resident Jacobi, 16 waves x 106 registers do not; alone, the 16-wave form is 25 % faster
-    // (JSTSP_STEPV_NT=512 / 1024 forces one of them)
-    static const int nt_env = getenv("JSTSP_STEPV_NT") ? atoi(getenv("JSTSP_STEPV_NT")) : 0;
-    if (g >= 8192 && (nt_env == 512 || (nt_env == 0 && waves8)))
+    if (g >= 8192 && waves8)
         hipLaunchKernelGGL(step_v_kernel<512>, dim3(batch), dim3(512), 0, ctx->stream, g, Res, RRes, V, S, rank,
                            cnt, prm, ce3, Imax, it, RV);
     else if (g >= 8192)

@@ -468,22 +468,20 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     // BASELINE configs[1]: only the 4096-term correlation needs it for |dNMSE| <= 1e-6 (1.2e-7 with
     // the threshold at 2048, 1.7e-7 at 256, 4e-6 without); 512/1024-term chains stay on the faster
     // 128-wide fp32 kernel.
-    static const int long_k = getenv("JSTSP_M64_MINK") ? atoi(getenv("JSTSP_M64_MINK")) : 2048;
+    const int long_k = 2048;
     const int kper = (d.k + d.splitk - 1) / d.splitk;
     // Grams only feed the SVT projector / spectral norms (not the gradient): plain fp32 chains are enough
     // Short contractions (the k = 64 products of the gradient step: A^H Tc, G_A Res, A S) take the 64-wide tile whatever n
     // is: 109 instead of 179 registers per lane and 33 instead of 50 KiB of LDS, i.e. 4 instead of 2 workgroups per CU alone and
     // 2 instead of 1 beside a resident eigen-decomposition / Gram workgroup - these launches are all prologue and epilogue,
     // what hides their latency is the number of workgroups in flight (round 3: 340 -> ? us beside the side chains).
-    static const int bn64_maxk = getenv("JSTSP_BN64_MAXK") ? atoi(getenv("JSTSP_BN64_MAXK")) : 64;
+    const int bn64_maxk = 64;
     const bool small_k = tag == GEMM_MISC && d.epi == EPI_NONE && kper <= bn64_maxk;
     const int variant = (kper >= long_k && tag != GEMM_GRAM && d.epi == EPI_NONE) ? 2 : ((d.n > 64 && !small_k) ? 1 : 0);
     const int bn = variant == 1 ? 128 : 64;
-    // 3M only where it pays and was validated: the two dominant contractions (JSTSP_M3=0 disables)
-    static const int m3_mask = getenv("JSTSP_M3") ? atoi(getenv("JSTSP_M3")) : 15;
-    static const int m3_mink = getenv("JSTSP_M3_MINK") ? atoi(getenv("JSTSP_M3_MINK")) : 256;
-    const bool m3 = (tag == GEMM_CORRELATE && (m3_mask & 1)) || (tag == GEMM_SYNTH && (m3_mask & 2)) ||
-                    (tag == GEMM_GRAM && (m3_mask & 4)) || (tag == GEMM_MISC && kper >= m3_mink && (m3_mask & 8));
+    // 3M where it pays and was validated: the dominant contractions, the Grams, and other products of 256 terms or more
+    const int m3_mink = 256;
+    const bool m3 = tag == GEMM_CORRELATE || tag == GEMM_SYNTH || tag == GEMM_GRAM || (tag == GEMM_MISC && kper >= m3_mink);
     const int tiles_n = (d.n + bn - 1) / bn;
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_m * tiles_n * d.splitk;

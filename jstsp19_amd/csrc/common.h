@@ -55,9 +55,33 @@ struct DeviceScope {
     DeviceScope(const DeviceScope &) = delete;
     DeviceScope &operator=(const DeviceScope &) = delete;
 };
+// Environment switches of the library (JSTSP_*; the list and what each one is for: include/jstsp.h, "Environment").  They
+// are diagnostic / opt-in settings, parsed ONCE at the entry of every API call (JSTSP_ENTER) into this struct - no switch is
+// latched in a static, none is read anywhere else - so a test can change them between two calls of one process and a call
+// sees one consistent setting from its first launch to its last.
+struct Tuning {
+    int h2 = 1;             // JSTSP_H2: 0 strict complex-fp32 MFMA everywhere, 1 split-f16 MFMA for big contractions, 2 always
+    int fused = 1;          // JSTSP_FUSED: 0 three-kernel ADMM iteration instead of the fused pass
+    int fused_parts = 0;    // JSTSP_FUSED_PARTS: column ranges per problem in the pass (0: chosen from M)
+    int fused_kback = 4;    // JSTSP_FUSED_KBACK: headroom bits of the predicted k scale (test hook: negative forces the re-solve)
+    int toeplitz = 2;       // JSTSP_TOEPLITZ: 0 dictionary taken as unstructured, 1 compact image only, 2 + window kernel (block 64)
+    int toeplitz_gram = 0;  // JSTSP_TOEPLITZ_GRAM: 1 G_B from its first block row (opt-in: 1.36e-6 max |dNMSE|)
+    int rv_refresh = 4;     // JSTSP_RV_REFRESH: R v recomputed from v every this many iterations
+    int overlap = -1;       // JSTSP_OVERLAP: side streams between the kernels of an iteration (-1: on with the fused pass)
+    int svt_skip = 0;       // JSTSP_SVT_SKIP: 1 trials whose threshold is below fp32 resolution skip the eigen-decomposition (opt-in)
+    int lanczos = 1;        // JSTSP_LANCZOS: 0 Householder + Sturm instead of Lanczos for the convergence_error norms
+    int eig128 = 1;         // JSTSP_EIG128: 0 general Jacobi kernel for Gram orders 65..128
+    int omp_gram = 1;       // JSTSP_OMP_GRAM: 0 measurement-space OMP on a Kronecker dictionary
+    int exp_ga = 1, exp_gb = 1;   // (experiment, to be removed) float64 G_A; G_B: 0 split-f16, 1 fp32 MFMA with fp64 masters, 2 float64 kernel
+    int bj_trace = 0;       // JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
+};
+const Tuning &tune();       // the calling thread's setting, as parsed by the API call in progress
+void load_tuning();
+
 #define JSTSP_ENTER(ctx)                                                                 \
     jstsp::DeviceScope dev_scope_((ctx)->device);                                        \
-    JSTSP_HIP(dev_scope_.err)
+    JSTSP_HIP(dev_scope_.err);                                                           \
+    jstsp::load_tuning()
 
 // Per-problem scalars of the ADMM solvers, resident on the device.
 struct TrialParams {

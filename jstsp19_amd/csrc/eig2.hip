@@ -765,22 +765,10 @@ static int launch_jacobi2_t(jstsp_ctx *ctx, int mode, int n, int batch, const fl
     // fp32 resolution — and the confirming sweep a 3e-7 threshold would cost (one of ~4 with a warm start) buys
     // nothing: 3.4 instead of 4.3 sweeps per warm-started call at BASELINE configs[1], parity unchanged
     // (|dNMSE| 1e-7 at both benchmark shapes).
-    static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 1e-4f;
-    static const int maxsw = getenv("JSTSP_JACOBI_SWEEPS") ? atoi(getenv("JSTSP_JACOBI_SWEEPS")) : 14;
-    static const int fn_aware = getenv("JSTSP_JACOBI_FN") ? atoi(getenv("JSTSP_JACOBI_FN")) : 1;
-    static int *stat = nullptr;
-    if (getenv("JSTSP_JACOBI_STAT") && !stat) { (void)hipMalloc((void **)&stat, 4); (void)hipMemset(stat, 0, 4); }
+    const float tol = 1e-4f;
+    const int maxsw = 14, fn_aware = 1;       // (the stop rule that bounds what the remaining couplings can do to Q Z: DESIGN section 5)
     hipLaunchKernelGGL((jacobi2_kernel<NE, NT>), dim3(batch), dim3(NT), sh, ctx->stream, mode, n, Gpart, sGt, nsplit,
-                       sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, stat, skip_amax, fn_aware);
-    if (stat) {
-        static int calls = 0;
-        if (++calls % 100 == 0) {
-            int h = 0;
-            (void)hipMemcpy(&h, stat, 4, hipMemcpyDeviceToHost);
-            (void)hipMemset(stat, 0, 4);
-            fprintf(stderr, "[jacobi] avg sweeps over last 100 launches: %.2f\n", h / (100.0 * batch));
-        }
-    }
+                       sGs, prm, tau, Q, lam_out, Uwarm, warm, tol, maxsw, (int *)nullptr, skip_amax, fn_aware);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }
@@ -794,11 +782,7 @@ int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gp
     if (n <= 32)
         return launch_jacobi2_t<32, 256>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
                                          skip_amax);
-    // JSTSP_JACOBI_NT=512: half the threads per matrix, two 2 x 2 blocks each (a lighter resident: 8 instead of 16 waves per CU)
-    static const int nt64 = getenv("JSTSP_JACOBI_NT") ? atoi(getenv("JSTSP_JACOBI_NT")) : 1024;
-    if (nt64 == 512)
-    return launch_jacobi2_t<64, 512>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
-                                      skip_amax);
+    // (512 threads per matrix - two 2 x 2 blocks each, a lighter resident - measured 790 instead of 600 us, round 3: dropped)
     return launch_jacobi2_t<64, 1024>(ctx, mode, n, batch, Gpart, sGt, nsplit, sGs, prm, tau, Q, lam_out, Uwarm, warm,
                                       skip_amax);
 }
@@ -838,12 +822,9 @@ int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long
 {
     if (n > 128) return launch_eig_large(ctx, EIG_LMAX, n, batch, Gpart, sGt, nsplit, sGs, nullptr, nullptr, nullptr, lam_out);
     JSTSP_REQUIRE(n >= 1, JSTSP_E_UNSUPPORTED, "launch_lmax: n = %d", n);
-    const bool lz = lanczos && (getenv("JSTSP_LANCZOS") ? atoi(getenv("JSTSP_LANCZOS")) != 0 : true);
+    const bool lz = lanczos && tune().lanczos != 0;
     if (lz) {
-        // waves per matrix at order <= 64 (JSTSP_LANCZOS_NW = 1 / 2 / 4)
-        const int nw = getenv("JSTSP_LANCZOS_NW") ? atoi(getenv("JSTSP_LANCZOS_NW")) : 4;
-        if (n <= 64 && nw == 1) return launch_lanczos_t<64, 1>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
-        if (n <= 64 && nw == 2) return launch_lanczos_t<64, 2>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+        // four waves per matrix (one or two measured slower: too little parallelism per matrix, round 2)
         if (n <= 64) return launch_lanczos_t<64, 4>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
         return launch_lanczos_t<128, 4>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
     }

@@ -266,8 +266,8 @@ int launch_eig128(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long lo
     JSTSP_REQUIRE(n > 64 && n <= 128, JSTSP_E_UNSUPPORTED, "launch_eig128: n = %d outside (64, 128]", n);
     const size_t sh = (size_t)NE * LD * sizeof(float2) + (size_t)(4 * H + 24 + NE) * sizeof(float);
     JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    static const float tol = getenv("JSTSP_JACOBI_TOL") ? (float)atof(getenv("JSTSP_JACOBI_TOL")) : 1e-4f;
-    static const int maxsw = getenv("JSTSP_JACOBI_SWEEPS") ? atoi(getenv("JSTSP_JACOBI_SWEEPS")) : 16;
+    const float tol = 1e-4f;
+    const int maxsw = 16;
     hipLaunchKernelGGL(jacobi128_kernel, dim3(batch), dim3(NT), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs, prm, tau, Q,
                        tol, maxsw, (int *)nullptr, Uwarm, warm);
     JSTSP_HIP(hipGetLastError());

@@ -929,8 +929,7 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
 // extra absmax launches and the tile padding (m x n x k complex MACs per problem).
 bool use_hgemm(long long m, long long n, long long k)
 {
-    const char *e = getenv("JSTSP_H2");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = tune().h2;
     if (mode == 0) return false;
     if (mode >= 2) return true;
     return m * n * k >= (1ll << 22) && k >= 64 && n >= 64;
@@ -1054,17 +1053,15 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
     JSTSP_REQUIRE(d.KS >= 2 * ((d.k + 31) / 32) && d.JT >= 2 * ((d.n + 63) / 64), JSTSP_E_ARG,
                   "hgemm: packed operand smaller than the product");
     // 64 x 128 tiles (8 waves) for long contractions whose a operand is split in the kernel: half as many splits
-    static const int wj_env = getenv("JSTSP_H2_WJ") ? atoi(getenv("JSTSP_H2_WJ")) : 4;
-    const bool wide = wj_env == 4 && !d.Ap && d.epi == EPI_NONE && d.n >= 128 && d.JT * 32 >= ((d.n + 127) / 128) * 128;
+    const bool wide = !d.Ap && d.epi == EPI_NONE && d.n >= 128 && d.JT * 32 >= ((d.n + 127) / 128) * 128;
     const int tiles_i = (d.m + 63) / 64, tiles_j = wide ? (d.n + 127) / 128 : (d.n + 63) / 64;
     const long long groups = (d.batch + 7) / 8;
     const long long grid = groups * 8 * tiles_i * tiles_j;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
-    // v2 (hgemm2_kernel): one row tile, b fragments straight to registers.  JSTSP_H2_V2: bit 0 (default) packed-a
-    // products (the synthesis); bit 1 fp32-a products of up to 1024 terms (the G_B applies: 185 -> 135 us each, but
-    // their single-level 512-term sums feed the cancellation Res = A^H Tc - G_A V G_B and triple the rounding noise
-    // in S, 1.9e-6 -> 5.9e-6 relative: off by default)
-    const int v2_mask = getenv("JSTSP_H2_V2") ? atoi(getenv("JSTSP_H2_V2")) : 1;
+    // v2 (hgemm2_kernel): one row tile, b fragments straight to registers.  Bit 0: packed-a products (the synthesis); bit 1:
+    // fp32-a products of up to 1024 terms (the G_B applies: 185 -> 135 us each, but their single-level 512-term sums feed the
+    // cancellation Res = A^H Tc - G_A V G_B and triple the rounding noise in S, 1.9e-6 -> 5.9e-6 relative: not used)
+    const int v2_mask = 1;
     const bool pack_ok = d.JT * 32 >= ((d.n + 127) / 128) * 128;       // j padded to 128 columns: 4 waves x 32
     if (d.m <= 64 && pack_ok && d.Ap && (v2_mask & 1) && d.aKS == d.KS && (d.KS % 4) == 0) {
         const int tj2 = (d.n + 127) / 128;
@@ -1090,8 +1087,7 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
         return 0;
     }
     if (prof_name) prof_begin(ctx, prof_name);
-    static const bool even_ok = getenv("JSTSP_H2_EVEN") ? atoi(getenv("JSTSP_H2_EVEN")) != 0 : true;
-    if (wide && even_ok && (d.k % 32) == 0 && ((d.KS / 2) % 2) == 0 && d.KS == 2 * (d.k / 32)) {
+    if (wide && (d.k % 32) == 0 && ((d.KS / 2) % 2) == 0 && d.KS == 2 * (d.k / 32)) {
         hgemm_kernel<EPI_NONE, false, 4, true><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     } else if (wide) {
         hgemm_kernel<EPI_NONE, false, 4><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);

@@ -450,9 +450,8 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
         // Coefficient-domain OMP (omp_gram_kernel): one correlation, the two factor Grams, one kernel for all m
         // iterations.  JSTSP_OMP_GRAM=0 keeps the measurement-space Gram-Schmidt below (also used when the
         // Cholesky factor does not fit in LDS).
-        const char *e = getenv("JSTSP_OMP_GRAM");
         const size_t lds = (size_t)m * m * 16 + 3 * (size_t)m * 16 + 3 * (size_t)m * 4;
-        if ((!e || atoi(e) != 0) && lds <= 150 * 1024) {
+        if (tune().omp_gram != 0 && lds <= 150 * 1024) {
             const int size_d = Gr * G2, nA = strideA ? batch : 1, nB = strideB ? batch : 1;
             const size_t nm = (size_t)N * M, ng = (size_t)N * G2, g = (size_t)size_d;
             const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;

@@ -27,7 +27,7 @@ struct ProposedWS {
     int32_t *rank;
     double *ce;
     float *lam;            // 3 * batch
-    GramWS gz, gn, gn2;    // SVT of Z; spectral norms of V1, V2, X (gn2: the second buffer of their Gram partials, by iteration parity)
+    GramWS gz, gn;         // SVT of Z; spectral norms of V1, V2, X
     // split-f16 path (hgemm.hip): B packed once per solve in both orientations, per-problem operand maxima
     bool h2 = false;
     HPack Bc, Bs;          // b(k = m, j = g) = conj(B) for K B^H ;  b(k = g, j = m) = B for (A S) B
@@ -45,9 +45,9 @@ static int gram3_nsplit(int N, int M, int G2, bool want_ce)
 {
     // (measured at configs[1], chunks of 512 / 1024 / 2048 columns: 493 / 497 / 496 channel-estimates/s — more splits
     //  shorten the single-level fp32 chains but every consumer of the Gram sums the partials again)
-    static const int JSTSP_G3_CHUNK = getenv("JSTSP_G3_CHUNK") ? atoi(getenv("JSTSP_G3_CHUNK")) : 1024;
+    const int chunk = 1024;
     if (!(want_ce && N <= 64 && N <= M && use_hgemm(N, G2, M))) return 0;
-    return std::max(1, std::min(32, (M + JSTSP_G3_CHUNK - 1) / JSTSP_G3_CHUNK));
+    return std::max(1, std::min(32, (M + chunk - 1) / chunk));
 }
 
 static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, int nB, bool angles,
@@ -66,7 +66,7 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     b += rnd256(3 * (size_t)batch * sizeof(float));
     const int ns3 = gram3_nsplit(N, M, G2, want_ce);
     b += GramWS::bytes(N, M, batch, true, ns3);
-    if (want_ce) b += 2 * GramWS::bytes(N, M, 3 * batch, false, ns3);
+    if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false, ns3);
     if (use_hgemm(N, G2, M))
         b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(8 * batch * sizeof(uint32_t)) +
              hgemm_pack_bytes(G2, N, batch);
@@ -101,7 +101,7 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
                   JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
     const int ns3 = gram3_nsplit(N, M, G2, want_ce);
     JSTSP_TRY(w.gz.alloc(a, N, M, batch, true, ns3));
-    if (want_ce) { JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false, ns3)); JSTSP_TRY(w.gn2.alloc(a, N, M, 3 * batch, false, ns3)); }
+    if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false, ns3));
     w.h2 = use_hgemm(N, G2, M);
     if (w.h2) {
         // operand maxima of one iteration, one block zeroed once per iteration: kmax | X | V1 | V2 | Znext | wmax | pmax x2.
@@ -177,13 +177,14 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // one pass over the dictionary per iteration (fused.hip); JSTSP_FUSED_PARTS = column ranges per problem
     // (measured at configs[1], 8 / 4 ranges: 4.42 / 4.34 ms per iteration - fewer partial sums to write and add)
     // (when M / 32 is not a multiple of 4: 2 ranges, or 1)
+    const Tuning &tn = tune();          // the switches of this call (common.h), parsed at JSTSP_ENTER
     const int ftiles = (M % 32 == 0) ? M / 32 : 0;
-    const int fparts = std::max(1, getenv("JSTSP_FUSED_PARTS") ? atoi(getenv("JSTSP_FUSED_PARTS"))
-                                                                : (ftiles % 4 == 0 ? 4 : (ftiles % 2 == 0 ? 2 : 1)));
-    const bool want_fused = allow_fused && (getenv("JSTSP_FUSED") ? atoi(getenv("JSTSP_FUSED")) != 0 : true) && approx &&
-                            Imax > 1 && fused_shape_ok(N, M, G2, fparts);
+    const int fparts = tn.fused_parts > 0 ? tn.fused_parts : (ftiles % 4 == 0 ? 4 : (ftiles % 2 == 0 ? 2 : 1));
+    const bool want_fused = allow_fused && tn.fused != 0 && approx && Imax > 1 && fused_shape_ok(N, M, G2, fparts);
     if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);
-    need += rnd256((size_t)nB * (G2 / 2 + 1) * G2 * sizeof(float2)) + 1024;      // first block row of G_B (block-Toeplitz B), probe flags
+    need += 1024;                                                                 // probe flags of the block-Toeplitz test
+    // (opt-in JSTSP_TOEPLITZ_GRAM=1 only: room for the first block row of G_B - block height at most G2 / 2)
+    if (tn.toeplitz_gram && tn.toeplitz >= 2) need += rnd256((size_t)nB * (G2 / 2 + 1) * G2 * sizeof(float2));
     if (memspace == JSTSP_HOST) {
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
                 rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
@@ -239,12 +240,13 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // JSTSP_TOEPLITZ (fused.hip): 0 - the dictionary is taken as unstructured; 1 - a block-Toeplitz one gets the compact HBM image
     // of the fused pass (bit-identical results); 2 (default) - also the window kernel for block height 64 (fp32-equivalent, not
     // bit-identical)
-    const int toep_env = getenv("JSTSP_TOEPLITZ") ? atoi(getenv("JSTSP_TOEPLITZ")) : 2;
+    const int toep_env = tn.toeplitz;
     int toep_gt = 0;
     bool toep_probed = false;
     const Mat GAm{w.GA, strideA ? (long long)Gr * Gr : 0, Gr}, GBm{w.GB, strideB ? (long long)G2 * G2 : 0, G2};
     // G_A = A^H A (Gr x Gr), G_B = B B^H (G2 x G2):  R = K2'*K2 = G_B^T (x) G_A
-    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
+    if (tn.exp_ga) JSTSP_TRY(gram_f64(ctx, 'L', A, strideA, N, Gr, nA, w.GA, (long long)Gr * Gr));
+    else JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
     if (w.h2) {
         // pack the dictionary first: G_B = B B^H is itself "a = B, b = conj(B)^T" on the split-f16 path
         JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
@@ -254,11 +256,14 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         // 1 / L of the product (7 -> 1 ms per call at BASELINE configs[1], +1.4 % channel-estimates/s).  Off by default: every
         // block on a block diagonal then carries the SAME rounding error of that one row, which adds up coherently in
         // G_A V G_B instead of averaging out - max |dNMSE| against the float64 port 8.1e-7 -> 1.36e-6 over 48 trials.
-        const bool toep_gram = getenv("JSTSP_TOEPLITZ_GRAM") ? atoi(getenv("JSTSP_TOEPLITZ_GRAM")) != 0 : false;
+        const bool toep_gram = tn.toeplitz_gram != 0;
         if (toep_env >= 2 && toep_gram) {
             JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
             toep_probed = true;
         }
+        if (tn.exp_gb == 2) JSTSP_TRY(gram_f64(ctx, 'R', B, strideB, G2, M, nB, w.GB, (long long)G2 * G2));
+        else if (tn.exp_gb == 1) JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
+        else
         if (toep_gt && toep_gram) {
             float2 *G0 = ctx->arena.get<float2>((size_t)nB * toep_gt * G2);
             JSTSP_REQUIRE(G0, JSTSP_E_NOMEM, "workspace exhausted (G_B block row)");
@@ -270,9 +275,9 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             // (G_B is Hermitian: the tiles below its diagonal - 12 of 32 at G2 = 512 - are not computed but mirrored)
             HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, w.GB,
                          (long long)G2 * G2, G2, G2, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
-            hb.herm_upper = getenv("JSTSP_GB_HERM") ? atoi(getenv("JSTSP_GB_HERM")) != 0 : 1;
+            hb.herm_upper = 1;
             JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
-            if (hb.herm_upper) JSTSP_TRY(hermitian_fill_lower(ctx, w.GB, (long long)G2 * G2, G2, nB));
+            JSTSP_TRY(hermitian_fill_lower(ctx, w.GB, (long long)G2 * G2, G2, nB));
         }
     } else
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
@@ -329,17 +334,15 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // BASELINE configs[1], but co-running kernels stretch each other (the K B^H launch goes from
     // 2.66 to 4.26 ms), which muddles per-kernel accounting — off until the side chains are
     // lighter than the MFMA-bound Grams they currently contain.
-    // (read at every call, not cached in statics: tests switch them inside one process)
     // R v (`R*v` of :47) is recomputed from v every 4th iteration and carried by R v += alpha R res (the `R*res` of :48
     // is computed anyway) in between.  Measured at configs[1], 6 trials against the float64 oracle, refresh period
     // 1 / 4 / 8 / never: 514 / 529 / 533 / 536 channel-estimates/s, max |dNMSE| 2.4e-7 / 2.7e-7 / 2.7e-7 / 4.4e-7,
     // max |dS|/max|S| 2.5e-6 / 2.8e-6 / 3.2e-6 / 4.6e-6.  JSTSP_RV_REFRESH=1 recomputes every iteration.
-    const int rv_refresh = std::max(1, getenv("JSTSP_RV_REFRESH") ? atoi(getenv("JSTSP_RV_REFRESH")) : 4);
-    const bool fuse = getenv("JSTSP_FUSE") ? atoi(getenv("JSTSP_FUSE")) != 0 : true;
+    const int rv_refresh = std::max(1, tn.rv_refresh);
     // With the fused pass the work between two passes is three short independent chains (Gram + eigen-decomposition of
     // the next Z | partial sums -> gradient step -> A S | spectral norms): there the side streams are on by default
     // (4.35 -> 4.21 ms per iteration at configs[1]).
-    const bool overlap = getenv("JSTSP_OVERLAP") ? atoi(getenv("JSTSP_OVERLAP")) != 0 : want_fused;
+    const bool overlap = tn.overlap >= 0 ? tn.overlap != 0 : want_fused;
     uint32_t *const kmax0 = w.kmax;
     JSTSP_TRY(ensure_side_streams(ctx));
     hipStream_t sm = ctx->stream, s1 = overlap ? ctx->side[0] : sm, s2 = overlap ? ctx->side[1] : sm;
@@ -350,29 +353,26 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         JSTSP_TRY(launch_form_z(ctx, snm, batch, w.X, w.V1, w.prm, w.Zb));
         JSTSP_TRY(svt_prepare(ctx, w.gz, w.Zb, w.prm, nullptr, true));
     }
-    const bool fz = fuse && w.gz.left;          // fused epilogues (need the Z - Q Z orientation)
+    const bool fz = w.gz.left;                  // fused epilogues (need the Z - Q Z orientation)
     // opt-in: problems whose threshold is below the fp32 resolution of Z skip the Gram + eigen-decomposition (Y = Z)
-    const bool svt_skip = getenv("JSTSP_SVT_SKIP") ? atoi(getenv("JSTSP_SVT_SKIP")) != 0 : false;
+    const bool svt_skip = tn.svt_skip != 0;
     const bool hmax = w.h2 && fz && N <= 64;    // the epilogues also deliver max|X|, |V1|, |V2|, |Znext|: split-f16 Grams
     // The svt argument Z = X - V1/rho is never stored on that path: the Gram kernel and the (I - Q) Z product form it
     // from X and V1 on the fly (both were written by the kernel before and are re-read while still close), which saves
-    // one N x M array write per iteration in the X/K/V1 epilogue.  JSTSP_ZFLY=0: store Znext as round 1 did.
+    // one N x M array write per iteration in the X/K/V1 epilogue.
     // Only with convergence_error, where the Gram pass over X and V1 exists anyway and delivers G_z with it
     // (hgram3_kernel); a Z-only Gram from two sources costs more than the saved write.
-    const bool zfly = hmax && want_ce && gram3_nsplit(N, M, G2, want_ce) > 0 && w.gz.nsplit == w.gn.nsplit &&
-                      (getenv("JSTSP_ZFLY") ? atoi(getenv("JSTSP_ZFLY")) != 0 : true) &&
-                      (getenv("JSTSP_PZ") ? atoi(getenv("JSTSP_PZ")) != 0 : true);     // (needs the (I - Q) Z form)
+    const bool zfly = hmax && want_ce && gram3_nsplit(N, M, G2, want_ce) > 0 && w.gz.nsplit == w.gn.nsplit;
     float2 *Zbuf[2] = {w.Zb, w.Zb2};            // svt argument of iteration it lives in Zbuf[it & 1]
     // Fused pass (fused.hip): after the gradient step of iteration it, ONE kernel forms Xs = A S B, the V2 / X / V1 / k
     // updates of :61-65 and of the next iteration's :38-43, and the first factor K B^H of the next :47 - the dictionary
     // is read once per iteration instead of twice.  The next iteration then starts at the gradient step.
-    // Y = (I - Q) Z formed inside the pass (JSTSP_FUSED_Y=0: by a GEMM before it, from X and V1)
-    const bool fy_env = getenv("JSTSP_FUSED_Y") ? atoi(getenv("JSTSP_FUSED_Y")) != 0 : true;
+    // Y = (I - Q) Z is formed inside the pass
     // with convergence_error: G_z comes from the three-Gram pass over X, V1 (zfly); without: from the Z the pass stores
     // (round 3: the opt-in short-cut JSTSP_SVT_SKIP=1 no longer switches the pass off - a skipped trial's Q = 0 becomes
     //  I - Q = I in the pass's fragments)
-    const bool fusedp = want_fused && hmax && (want_ce ? zfly : fy_env);
-    const bool fusedy = fusedp && fy_env;
+    const bool fusedp = want_fused && hmax && (want_ce ? zfly : true);
+    const bool fusedy = fusedp;
     FusedWS fw;
     if (fusedp) {
         // a block-Toeplitz dictionary (what the reference's drivers build) is kept as its first block only: probed exactly,
@@ -388,40 +388,17 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     }
     // headroom (bits) of the k scale the pass predicts from the previous iteration's maximum; JSTSP_FUSED_KBACK is a
     // test hook: a negative value makes every pass overflow, which must end in the per-trial re-solve below
-    const int fused_kback = getenv("JSTSP_FUSED_KBACK") ? atoi(getenv("JSTSP_FUSED_KBACK")) : 4;
+    const int fused_kback = tn.fused_kback;
     bool passed = false;                        // X, V1, k-partials of this iteration came from the previous pass
-    // Order inside the window between two passes (round 3).  Three chains start when a pass ends: the gradient step (critical:
-    // the next pass waits for its A S), the three-Gram pass -> eigen-decomposition (the next pass waits for I - Q), and the norms
-    // of convergence_error (Gram of V2 -> lambda_max; only the Gram must be done before the next pass overwrites V2).  Started
-    // together, the two Gram passes (1.6 GB) and the first products of the gradient step fight for HBM and the critical chain's
-    // first 70-us product takes 500 us (profiles/r03_windows_before.txt).  JSTSP_CE_GATE=1 (default): the Gram of V2 of iteration
-    // `it` is issued in the NEXT loop iteration, behind the three-Gram pass of that window; 0: as in round 2.
-    // With that, the Gram partials of the three norms are double-buffered by iteration parity (gn / gn2) and ALL three
-    // lambda_max of an iteration are ONE launch (3 x batch matrices fill the chip once) instead of two half-empty ones.
-    // End of round 3, with the shorter pass and the Jacobi that stops a sweep earlier (eig2.hip): the Gram pass starts with the
-    // window, the eigen-decomposition behind the G_B apply (JSTSP_SVT_ORDER=2), the norm chain as in round 2 (JSTSP_CE_GATE=0)
-    // and an eight-wave step kernel (admm.hip) - 3.040 against 3.078 ms per iteration for (0, 1, 16 waves), three runs each.
-    const int ce_gate = getenv("JSTSP_CE_GATE") ? atoi(getenv("JSTSP_CE_GATE")) : 0;
-    const int svt_order_env = getenv("JSTSP_SVT_ORDER") ? atoi(getenv("JSTSP_SVT_ORDER")) : 2;
-    const int svt_gatepos = getenv("JSTSP_SVT_GATEPOS") ? atoi(getenv("JSTSP_SVT_GATEPOS")) : 0;
+    // Order inside the window between two passes (measured in round 3).  Three chains start when a pass ends:
+    // the gradient step (critical: the next pass waits for its A S), the three-Gram pass -> eigen-decomposition (the next pass
+    // waits for I - Q), and the norms of convergence_error (Gram of V2 -> lambda_max; only the Gram must be done before the
+    // next pass overwrites V2).  The Gram pass starts with the window, the eigen-decomposition behind the G_B apply of the
+    // gradient step (a resident Jacobi workgroup leaves that apply no room on its CU), and beside a Jacobi the step kernel
+    // runs with eight waves.  The alternatives that were measured and lost (Gram of V2 one window late with double-buffered
+    // norm partials, the whole side chain behind the step's head, other gate positions, stream priorities) are gone from
+    // the code; their numbers are in DESIGN.md.
     hipEvent_t ev_q1 = ctx->ev[7];
-    const bool dbuf = ce_gate && fusedp && zfly && want_ce;
-    auto gn_of = [&](int i) -> GramWS & { return (dbuf && (i & 1)) ? w.gn2 : w.gn; };
-    int ce_pending = -1;
-    const uint32_t *ce_nmax = nullptr;
-    auto issue_ce_v2 = [&](int itc, const uint32_t *nmax_it, hipEvent_t gate, hipEvent_t gate2 = nullptr) -> int {
-        JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
-        if (gate) JSTSP_HIP(hipStreamWaitEvent(s2, gate, 0));
-        StreamScope sc(ctx, s2);
-        JSTSP_TRY(gram_partials_range(ctx, gn_of(itc), w.X, snm, 2 * batch, batch, nmax_it));
-        JSTSP_HIP(hipEventRecord(ev_gv2, s2));
-        if (gate2) JSTSP_HIP(hipStreamWaitEvent(s2, gate2, 0));      // (the lambda_max launch also reads G_x, G_v1 of the Gram pass)
-        if (dbuf) JSTSP_TRY(lmax_from_partials(ctx, gn_of(itc), w.lam, true));
-        else JSTSP_TRY(lmax_from_partials_range(ctx, gn_of(itc), 2 * batch, batch, w.lam, true));
-        JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, itc));
-        JSTSP_HIP(hipEventRecord(ev_ce, s2));
-        return 0;
-    };
     for (int it = 0; it < Imax; ++it) {
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
         // every operand maximum of this iteration starts from zero (one memset instead of four)
@@ -442,12 +419,8 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         } else if (fz) {
             // Y = Z - Q Z with the X / K / V1 updates (and the next Z) applied to the tile in registers (:35-43,:64)
             // Y = Z - Q Z as (I - Q) Z: the beta-term form reads the Z tile a second time from HBM (PMC: +0.5 GB)
-            static const bool pz = getenv("JSTSP_PZ") ? atoi(getenv("JSTSP_PZ")) != 0 : true;
-            if (pz) JSTSP_TRY(launch_eye_minus(ctx, N, batch, w.gz.Q, w.gz.Q));
-            GemmDesc dq = pz ? make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{Zc, snm, N},
-                                         w.Y, snm, N)
-                             : make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{Zc, snm, N},
-                                         w.Y, snm, N, -1.f, Zc, snm, N, 1.f);
+            JSTSP_TRY(launch_eye_minus(ctx, N, batch, w.gz.Q, w.gz.Q));
+            GemmDesc dq = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{Zc, snm, N}, w.Y, snm, N);
             dq.epi = EPI_UPDATE_X; dq.prm = w.prm;
             dq.e_rw0 = w.V1; dq.e_w1 = w.X; dq.e_w2 = w.ZK;
             dq.e_r0 = w.V2; dq.e_r2 = w.Xs; dq.e_r3 = subY; dq.e_f0 = w.invD;
@@ -474,20 +447,15 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             if (zfly) {
               if (stage != 2) {
                 // (the spectral norms of X, V1 of the previous iteration read the G_x, G_v1 partials this pass overwrites)
-                // (double-buffered: the buffer of this parity was last read by the lambda_max launch of iteration it - 2)
-                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, dbuf ? ev_ce : ev_lxv, 0));
+                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_lxv, 0));
                 // (Until the library was compiled without packed-fp32 instructions - see build.py - this pass also had to
                 // wait for the previous iteration's lambda_max kernels: the Lanczos kernel, whose complex arithmetic hipcc had
                 // turned into v_pk_fma_f32 chains, returned different Ritz values when MFMA-heavy waves shared its SIMDs.)
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
-                                        w.prm, w.gz.Gpart, gn_of(it).Gpart, gn_of(it).Gpart + (size_t)batch * N * N * w.gn.nsplit));
+                                        w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
                 JSTSP_HIP(hipEventRecord(ev_gxv, s1));
-                if (ce_pending >= 0 && ce_gate != 2) {      // the previous iteration's Gram of V2, lambda_max and ratio: behind this Gram pass
-                    JSTSP_TRY(issue_ce_v2(ce_pending, ce_nmax, ev_gxv));
-                    ce_pending = -1;
-                }
-                if (fusedp && !dbuf) {       // lambda_max of G_x, G_v1 now (beside the pass), not after it with G_v2: the next Gram
+                if (fusedp) {       // lambda_max of G_x, G_v1 now (beside the pass), not after it with G_v2: the next Gram
                                     // pass then never waits for them
                     JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));
                     StreamScope sc2(ctx, s2);
@@ -497,17 +465,8 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
               }
               if (stage == 1) return 0;
                 JSTSP_TRY(svt_prepare(ctx, w.gz, w.X, w.prm, nullptr, true, w.zmax, svt_skip, nullptr, true));
-                if (fusedy) {       // the pass at the end of this iteration forms Y = (I - Q) Z itself: fragments of I - Q
-                    JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
-                } else if (fusedp) {       // Y of the next iteration = (I - Q) Z, consumed by the pass at the end of this one
-                    JSTSP_TRY(launch_eye_minus(ctx, N, batch, w.gz.Q, w.gz.Q));
-                    GemmDesc dy = make_gemm('N', 'N', N, M, N, batch, Mat{w.gz.Q, (long long)N * N, N}, Mat{w.X, snm, N},
-                                            w.Y, snm, N);
-                    dy.epi = EPI_UPDATE_X; dy.prm = w.prm; dy.B2 = w.V1; dy.epi_store_c = 2;    // Z formed in the panel loader
-                    dy.e_rw0 = w.V1; dy.e_w1 = w.X; dy.e_w2 = w.ZK; dy.e_r0 = w.V2; dy.e_r2 = w.Xs; dy.e_r3 = subY;
-                    dy.e_f0 = w.invD;                                                            // (alignment checks only)
-                    JSTSP_TRY(launch_cgemm(ctx, dy, GEMM_MISC));
-                }
+                // the pass at the end of this iteration forms Y = (I - Q) Z itself: fragments of I - Q
+                if (fusedy) JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
             } else {
                 JSTSP_TRY(svt_prepare(ctx, w.gz, Zn, w.prm, nullptr, true, hmax ? w.zmax : nullptr, svt_skip));
                 if (fusedy) JSTSP_TRY(fused_pack_wq(ctx, fw, w.gz.Q, batch));
@@ -515,19 +474,14 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_HIP(hipEventRecord(ev_svt, s1));
             return 0;
         };
-        // JSTSP_SVT_ORDER (fused pass with convergence_error only): 0 - the whole side chain starts with the window; 1 - it
-        // starts when the gradient step's bandwidth-heavy head (partial sums ... (G_A Res) G_B) is through; 2 - the Gram pass
-        // starts with the window, the eigen-decomposition behind that head (a resident Jacobi workgroup leaves the G_B apply
-        // no room on its CU: profiles/r03_fused_iteration_timeline.txt)
-        const int svt_order = (passed && fusedp && zfly && it + 1 < Imax) ? svt_order_env : 0;
-        if (it + 1 < Imax) {
-            if (svt_order == 0) JSTSP_TRY(issue_s1(0));
-            else if (svt_order == 2) JSTSP_TRY(issue_s1(1));
-        }
+        // behind a pass (with convergence_error): the Gram pass starts with the window, the eigen-decomposition behind the
+        // gradient step's bandwidth-heavy head (profiles/r03_fused_iteration_timeline.txt); otherwise the whole side chain now
+        const bool svt_split = passed && fusedp && zfly && it + 1 < Imax;
+        if (it + 1 < Imax) JSTSP_TRY(issue_s1(svt_split ? 1 : 0));
         if (want_ce && !(zfly && it + 1 < Imax)) {              // s2: Gram of [X | V1]
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_x, 0));
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, gn_of(it), w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr));
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gxv, s2));
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
@@ -538,11 +492,6 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         //  partial sums inside the pass: the device-scope fence it needs writes the L2 back, 3.95 -> 4.36 ms)
         if (passed) {
             JSTSP_TRY(fused_reduce(ctx, fw, G2, M, batch, w.Tc));
-            if (ce_gate == 2 && ce_pending >= 0) {      // (experiment: the Gram of V2 behind the head of the critical chain only)
-                JSTSP_HIP(hipEventRecord(ev_q1, sm));
-                JSTSP_TRY(issue_ce_v2(ce_pending, ce_nmax, ev_q1, ev_gxv));
-                ce_pending = -1;
-            }
         } else if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
             JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, M, batch, Mat{w.ZK, snm, N}, Mat{PB, strideB ? (long long)M * G2 : 0, M},
                            w.Tc, sng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
@@ -576,20 +525,15 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
                            -1.f));
             //    R*res for alpha = res'*res / (res'*R*res)                                    (:48)
-            if (svt_order && svt_gatepos == 1) {       // (gate behind the first product of the step only)
-                JSTSP_HIP(hipEventRecord(ev_q1, sm));
-                JSTSP_HIP(hipStreamWaitEvent(s1, ev_q1, 0));
-                JSTSP_TRY(issue_s1(svt_order == 1 ? 0 : 2));
-            }
             JSTSP_TRY(apply_R(w.Res, w.RRes));
-            if (svt_order && svt_gatepos == 0) {
+            if (svt_split) {
                 JSTSP_HIP(hipEventRecord(ev_q1, sm));
                 JSTSP_HIP(hipStreamWaitEvent(s1, ev_q1, 0));
-                JSTSP_TRY(issue_s1(svt_order == 1 ? 0 : 2));
+                JSTSP_TRY(issue_s1(2));
             }
             //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
-                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr, svt_order != 0));
+                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr, svt_split));
         } else {
             //    v = U\(L\k) = pinv(A) K pinv(B)   [ = G_A^-1 (A^H Tc) G_B^-1 on the Gram route: GA / GB hold the inverses ]  (:53)
             float2 *left = PB ? w.V : w.P1;        // result of the A side; the B side (if any) finishes into V
@@ -634,14 +578,13 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             passed = true;
         } else
         if (w.h2) {
-            static const bool apack = getenv("JSTSP_H2_APACK") ? atoi(getenv("JSTSP_H2_APACK")) != 0 : true;
-            if (apack)      // a(i, k = g) = W[i + N g] in fragment order, once per iteration instead of once per j-tile
-                JSTSP_TRY(hgemm_repack(ctx, w.Wp, w.W, sng, N, 1, 0, G2, N, w.wmax));
+            // a(i, k = g) = W[i + N g] in fragment order, once per iteration instead of once per j-tile
+            JSTSP_TRY(hgemm_repack(ctx, w.Wp, w.W, sng, N, 1, 0, G2, N, w.wmax));
             if (!w.Bs.data)
                 JSTSP_TRY(hgemm_pack(ctx, w.Bs, ctx->arena, B, strideB, 1, G2, 0, G2, M, nB, (long long)G2 * M, w.Bc.bmax));
             HGemmDesc hs{w.W, sng, N, w.wmax, w.Bs.data, strideB ? w.Bs.st : 0, w.Bs.bmax, strideB ? 1 : 0, w.Bs.KS,
                          w.Bs.JT, w.Xs, snm, N, N, M, G2, batch, fz ? EPI_UPDATE_C : EPI_NONE, w.prm, w.X, w.V2,
-                         hmax ? w.nmax + 2 * (size_t)batch : nullptr, apack ? w.Wp.data : nullptr, w.Wp.st, w.Wp.KS};
+                         hmax ? w.nmax + 2 * (size_t)batch : nullptr, w.Wp.data, w.Wp.st, w.Wp.KS};
             JSTSP_TRY(launch_hgemm(ctx, hs, "synthesize"));
             if (!fz) JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
         } else if (fz) {
@@ -657,21 +600,15 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(launch_update_c(ctx, snm, batch, w.X, w.Xs, w.V2, w.C, w.prm));
         }
         // -- convergence_error(i,1:2) = norm(V1)^2/norm(X)^2, norm(V2)^2/norm(X)^2           (:67,:69)
-        if (want_ce && ce_gate && passed && fusedp && zfly && it + 2 < Imax) {
-            // (a pass has just been launched and another window with a three-Gram pass follows: issue it there)
-            JSTSP_HIP(hipEventRecord(ev_c, sm));
-            ce_pending = it;
-            ce_nmax = hmax ? w.nmax : nullptr;
-        } else
         if (want_ce) {
             JSTSP_HIP(hipEventRecord(ev_c, sm));
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
             if (zfly) JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));      // G_x, G_v1 came from the side stream s1
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, gn_of(it), w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr));
             JSTSP_HIP(hipEventRecord(ev_gv2, s2));
-            if (fusedp && zfly && it + 1 < Imax && !dbuf) JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 2 * batch, batch, w.lam, true));
-            else JSTSP_TRY(lmax_from_partials(ctx, gn_of(it), w.lam, true));
+            if (fusedp && zfly && it + 1 < Imax) JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 2 * batch, batch, w.lam, true));
+            else JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam, true));
             JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));
             JSTSP_HIP(hipEventRecord(ev_ce, s2));
         }

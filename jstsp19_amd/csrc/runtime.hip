@@ -10,6 +10,37 @@ namespace jstsp {
 
 static thread_local char g_err[512] = "";
 
+static thread_local Tuning g_tune;
+const Tuning &tune() { return g_tune; }
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+// every switch of the library, read here and nowhere else (common.h: Tuning; include/jstsp.h: "Environment")
+void load_tuning()
+{
+    Tuning t;
+    t.h2 = env_int("JSTSP_H2", t.h2);
+    t.fused = env_int("JSTSP_FUSED", t.fused);
+    t.fused_parts = env_int("JSTSP_FUSED_PARTS", t.fused_parts);
+    t.fused_kback = env_int("JSTSP_FUSED_KBACK", t.fused_kback);
+    t.toeplitz = env_int("JSTSP_TOEPLITZ", t.toeplitz);
+    t.toeplitz_gram = env_int("JSTSP_TOEPLITZ_GRAM", t.toeplitz_gram);
+    t.rv_refresh = env_int("JSTSP_RV_REFRESH", t.rv_refresh);
+    t.overlap = env_int("JSTSP_OVERLAP", t.overlap);
+    t.svt_skip = env_int("JSTSP_SVT_SKIP", t.svt_skip);
+    t.lanczos = env_int("JSTSP_LANCZOS", t.lanczos);
+    t.eig128 = env_int("JSTSP_EIG128", t.eig128);
+    t.omp_gram = env_int("JSTSP_OMP_GRAM", t.omp_gram);
+    t.bj_trace = env_int("JSTSP_BJ_TRACE", t.bj_trace);
+    t.exp_ga = env_int("JSTSP_EXP_GA", t.exp_ga);
+    t.exp_gb = env_int("JSTSP_EXP_GB", t.exp_gb);
+    g_tune = t;
+}
+
 void set_error(const char *fmt, ...)
 {
     va_list ap;
@@ -244,8 +275,7 @@ int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
     }
     // orders 65..128: G in LDS, the eigenvector basis in registers (eig3.hip); JSTSP_EIG128=0: the general kernel with
     // the basis in HBM (eig.hip)
-    const char *e128 = getenv("JSTSP_EIG128");
-    if (w.n <= 128 && (!e128 || atoi(e128) != 0)) {
+    if (w.n <= 128 && tune().eig128 != 0) {
         // warm start (successive calls of an ADMM loop): G <- Uw^H (G Uw) with the previous basis, two batched GEMMs
         const int warm = (sequence && w.warm && w.nsplit == 1 && w.Uwarm && w.Twarm) ? 1 : 0;
         if (warm) {
@@ -283,16 +313,10 @@ int svt_batched(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
 
 int ensure_side_streams(jstsp_ctx *ctx)
 {
-    // lowest priority: what runs there has slack, the chain on the context's stream is the critical path of an iteration
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // JSTSP_SIDE_PRIO: 1 - both side streams at the lowest priority (measured at configs[1]: 3.96 vs 3.92 ms per iteration
-    // with / without); 2 - the svt chain (Gram pass -> eigen-decomposition, side stream 0: with the shorter pass of round 3 it
-    // is the longest chain of the window) at the HIGHEST priority, the norm chain at the lowest
-    static const int prio = getenv("JSTSP_SIDE_PRIO") ? atoi(getenv("JSTSP_SIDE_PRIO")) : 0;
+    // (default priority: lowest-priority side streams measured 3.96 vs 3.92 ms per iteration at configs[1], a high-priority
+    //  svt chain no better - rounds 2 and 3; the switch for it is gone)
     for (int i = 0; i < 2; ++i)
-        if (!ctx->side[i])
-            JSTSP_HIP(hipStreamCreateWithPriority(&ctx->side[i], hipStreamNonBlocking, prio == 1 ? lo : (prio == 2 ? (i == 0 ? hi : lo) : 0)));
+        if (!ctx->side[i]) JSTSP_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i)
         if (!ctx->ev[i]) JSTSP_HIP(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     return 0;

@@ -16,6 +16,10 @@ int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat
          long long sCt, int ldc, float alpha = 1.f, const float2 *D = nullptr, long long sDt = 0,
          int ldd = 0, float beta = 0.f, int tag = GEMM_MISC, int splitk = 1, long long sCsplit = 0);
 
+// Gram of a dictionary factor with float64 products and sums (gram64.hip): side 'L' G = X^H X (cols x cols), 'R' G = X X^H
+// (rows x rows); X rows x cols column-major (ld = rows), sXt = 0: shared; G order n, ld = n, exactly Hermitian
+int gram_f64(jstsp_ctx *ctx, char side, const float2 *X, long long sXt, int rows, int cols, int count, float2 *G, long long sGt);
+
 // Descriptor only (the caller may attach a fused epilogue before launch_cgemm).
 GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C, long long sCt,
                    int ldc, float alpha = 1.f, const float2 *D = nullptr, long long sDt = 0, int ldd = 0,

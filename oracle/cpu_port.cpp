@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -258,6 +259,25 @@ double spectral_norm_sq(const Planar &X, Planar &Xh, Planar &G)   // norm(X)^2 =
     return herm_lmax(X.rows, G);
 }
 
+// Precision study (tools/precision_study.py): JSTSP_PORT_ROUND is a bit mask of intermediate arrays that are rounded to
+// float32 where the HIP path stores or produces them in fp32 - which rounding the NMSE is sensitive to.  Unset / 0 (every
+// test, the bench baseline and every parity statement): pure float64, nothing below executes.
+inline void round32(Planar &p)
+{
+    for (size_t i = 0; i < p.re.size(); ++i) { p.re[i] = (double)(float)p.re[i]; p.im[i] = (double)(float)p.im[i]; }
+}
+// a product whose accumulation carried a relative error `rel` (uniform in [-rel, rel], fixed pseudo-random sequence)
+inline void jitter(Planar &p, double rel, uint64_t &state)
+{
+    for (size_t i = 0; i < p.re.size(); ++i) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const double u = ((double)(state >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const double v = ((double)(state >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+        p.re[i] *= 1.0 + rel * u; p.im[i] *= 1.0 + rel * v;
+    }
+}
+
 inline double soft(double v, double t) { return v > t ? v - t : (v < -t ? v + t : 0.0); }
 inline double ratio(double a, double b) { return b == 0.0 ? (a == 0.0 ? std::numeric_limits<double>::quiet_NaN() : std::numeric_limits<double>::infinity()) : a / b; }
 
@@ -277,6 +297,14 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
     GA.init(Gr, Gr); GB.init(G2, G2);
     gemm(Ah, A, GA);                                              // R = K2'*K2 = (B B')^T (x) (A'A)      (:25)
     gemm(B, Bh, GB);
+    const char *rm_env = std::getenv("JSTSP_PORT_ROUND");
+    const unsigned rm = rm_env ? (unsigned)std::strtoul(rm_env, nullptr, 0) : 0u;
+    const char *rj_env = std::getenv("JSTSP_PORT_JITTER");
+    const double rj = rj_env ? std::atof(rj_env) : 0.0;
+    uint64_t jst = 0x9E3779B97F4A7C15ull ^ (uint64_t)(subY_[0] * 1e9);
+    if (rm & 16384u) jitter(GA, rj, jst);
+    if (rm & 32768u) jitter(GB, rj, jst);
+    if (rm & 128u) { round32(GA); round32(GB); }
     std::vector<double> inv_d(nm), omega_s(indx_S ? g : 0, 0.0), lam;
     for (size_t i = 0; i < nm; ++i) inv_d[i] = 1.0 / (Omega[i] + 2.0 * rho);     // iK1                        (:14-20)
     std::fill(ce, ce + (size_t)3 * Imax, 0.0);
@@ -309,6 +337,7 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
             gemm(Uf, Uh, Q);
             gemm(Q, Z, Y);
         }
+        if (rm & 256u) round32(Y);
         // X = (V1 + rho Y + subY + V2 + rho C + rho Xs) ./ (Omega + 2 rho);  K = X - V2/rho - C             (:38-43)
         for (size_t i = 0; i < nm; ++i) {
             X.re[i] = (V1.re[i] + rho * Y.re[i] + subY.re[i] + V2.re[i] + rho * C.re[i] + rho * Xs.re[i]) * inv_d[i];
@@ -316,14 +345,24 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
             K.re[i] = X.re[i] - ir * V2.re[i] - C.re[i];
             K.im[i] = X.im[i] - ir * V2.im[i] - C.im[i];
         }
+        if (rm & 1u) { round32(X); round32(K); }
         // res = K2'*k - R*v = A^H K B^H - G_A V G_B ; alpha = res'res / res'R res ; v += alpha res        (:47-50)
         gemm(K, Bh, T1);
+        if (rm & 2048u) jitter(T1, rj, jst);
+        if (rm & 8u) round32(T1);
         gemm(Ah, T1, Res);
+        if (rm & 16u) round32(Res);
         gemm(GA, V, T2);
+        if (rm & 16u) round32(T2);
         gemm(T2, GB, RRes);
+        if (rm & 4096u) jitter(RRes, rj, jst);
+        if (rm & 16u) round32(RRes);
         for (size_t i = 0; i < g; ++i) { Res.re[i] -= RRes.re[i]; Res.im[i] -= RRes.im[i]; }
+        if (rm & 16u) round32(Res);
         gemm(GA, Res, T2);
+        if (rm & 32u) round32(T2);
         gemm(T2, GB, RRes);
+        if (rm & 32u) round32(RRes);
         double nr = 0.0, dr = 0.0, di = 0.0, nv = 0.0;
         for (size_t i = 0; i < g; ++i) {
             nr += Res.re[i] * Res.re[i] + Res.im[i] * Res.im[i];
@@ -340,13 +379,18 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
             dv += sr * sr + si * si;
         }
         ce[(size_t)(it - 1) + (size_t)Imax * 2] = ratio(dv, nv);                                            // (:51)
+        if (rm & 4u) round32(V);
         // s = soft(re) + j soft(im) (.* Omega_S);  Xs = A S B                                              (:56-58, angles :68)
         for (size_t i = 0; i < g; ++i) {
             const double m = indx_S ? omega_s[i] : 1.0;
             S.re[i] = m * soft(V.re[i], tS); S.im[i] = m * soft(V.im[i], tS);
         }
+        if (rm & 4u) round32(S);
         gemm(A, S, W);
+        if (rm & 512u) round32(W);
         gemm(W, B, Xs);
+        if (rm & 8192u) jitter(Xs, rj, jst);
+        if (rm & 64u) round32(Xs);
         // C, V1, V2                                                                                         (:61-65)
         for (size_t i = 0; i < nm; ++i) {
             C.re[i] = cc * (X.re[i] - Xs.re[i] - ir * V2.re[i]);
@@ -354,6 +398,7 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
             V1.re[i] += rho * (Y.re[i] - X.re[i]); V1.im[i] += rho * (Y.im[i] - X.im[i]);
             V2.re[i] += rho * (C.re[i] - X.re[i] + Xs.re[i]); V2.im[i] += rho * (C.im[i] - X.im[i] + Xs.im[i]);
         }
+        if (rm & 2u) { round32(V1); round32(V2); round32(C); }
         if (want_ce) {                                            // norm(V1)^2/norm(X)^2, norm(V2)^2/norm(X)^2     (:67,:69)
             const double nx = spectral_norm_sq(X, Zh, G);
             ce[(size_t)(it - 1)] = ratio(spectral_norm_sq(V1, Zh, G), nx);
