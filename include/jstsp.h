@@ -83,9 +83,13 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         that forces the per-trial re-solve, jstsp_last_fused_fallbacks)
  *   JSTSP_TOEPLITZ=0|1    0: the dictionary is not probed for block-Toeplitz structure; 1: probed, compact image with the
  *                         general pass kernel only; default 2: block height 64 also takes the window kernel
- *   JSTSP_TOEPLITZ_GRAM=1 opt-in: B*B' of a block-Toeplitz dictionary from its first block row (measured max |dNMSE| 1.4e-6:
- *                         outside the parity statement, hence off)
- *   JSTSP_RV_REFRESH=n    proposed_algorithm 'approximate': R*v recomputed from v every n iterations (default 4; 1 = always)
+ *   JSTSP_GRAM_REFINE=0   proposed_algorithm 'approximate': the Grams A'*A, B*B' as plain fp32-accuracy products without low-order
+ *                         parts (round 3; measured rms |dNMSE| 3.9e-7, max 1.95e-6 - outside the accuracy statement).  Default 1:
+ *                         both Grams in float64, kept as two floats, the low-order parts applied whenever R*v is recomputed
+ *   JSTSP_RV_REFRESH=n    proposed_algorithm 'approximate': R*v recomputed from v every n iterations (default 4; 1 = always);
+ *   JSTSP_RV_ALWAYS=n     ... and in each of the first n iterations (default 0)
+ *   JSTSP_GRAD_HEAD=3     opt-in: the 64-term products of the gradient step on the f16 pipe in one launch (jstsp_gradient_head_c32);
+ *                         faster (+2 %) and individually more accurate, but measured WORSE against float64 (rms 2.2e-7 vs 1.7e-7)
  *   JSTSP_OVERLAP=0|1     side streams between the kernels of an iteration (default: on with the one-pass kernel)
  *   JSTSP_SVT_SKIP=1      opt-in: a trial whose svt threshold is below 2^-27 max|Z| skips its eigen-decomposition (Y = Z is
  *                         then the fp32 answer); never used for a reported number
@@ -122,6 +126,16 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
                          const jstsp_c32 *S, const jstsp_c32 *A, long long strideA,
                          const jstsp_c32 *B, long long strideB,
                          jstsp_c32 *out, int memspace);
+
+/* Res = A' * Tc - RV  and  P1 = GA * Res   (Gr x G2): the 64-term products of the gradient step - the second factor of
+ * `K2'*k - R*v` and the first factor of `R*res`, proposed_algorithm.m:47-48 - exactly as the solver runs them between two
+ * passes over the dictionary (N = Gr = 64, G2 a multiple of 64; else JSTSP_E_UNSUPPORTED).  These sums live in the space of
+ * the iterate v, where the iteration forgets nothing, so they are formed to fp32-OUTPUT accuracy: operands split three ways
+ * into f16 (33 bits: the fp32 values exactly), exact f16 x f16 products, float64 final sums.
+ * Tc: N x G2 x batch; A: N x Gr; GA: Gr x Gr Hermitian (strides 0 = shared); RV: Gr x G2 x batch or NULL. */
+int jstsp_gradient_head_c32(jstsp_ctx *ctx, int N, int Gr, int G2, int batch, const jstsp_c32 *Tc,
+                            const jstsp_c32 *A, long long strideA, const jstsp_c32 *GA, long long strideG,
+                            const jstsp_c32 *RV, jstsp_c32 *Res_out, jstsp_c32 *P1_out, int memspace);
 
 /* ---- solvers ------------------------------------------------------------------------ */
 

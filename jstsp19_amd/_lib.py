@@ -50,6 +50,8 @@ SIGNATURES = {
                                     c_void_p, c_ll, c_void_p, c_int]),
     "jstsp_synthesize_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll,
                                      c_void_p, c_ll, c_void_p, c_int]),
+    "jstsp_gradient_head_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
+                                        c_void_p, c_void_p, c_void_p, c_int]),
     "jstsp_proposed_algorithm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                              c_void_p, c_ll, c_void_p, c_ll, c_int, c_dp, c_dp, c_dp, c_int,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int]),

@@ -627,3 +627,39 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
 }
 
 }  // extern "C"
+
+// Res = A' * Tc - RV,  P1 = GA * Res   (Gr x G2 per problem; N = Gr = 64, G2 a multiple of 64): the gradient step's 64-term
+// products `K2'*k - R*v` (second factor) and the first factor of `R*res` (proposed_algorithm.m:47-48) as the solver runs them
+// (csrc/hsmall.hip: three-way split-f16 operands, float64 final sums).  Tc: N x G2 x batch; A: N x Gr (strideA 0 = shared); GA: Gr x Gr
+// Hermitian (strideG 0 = shared); RV: Gr x G2 x batch or NULL.
+extern "C" int jstsp_gradient_head_c32(jstsp_ctx *ctx, int N, int Gr, int G2, int batch, const jstsp_c32 *Tc_, const jstsp_c32 *A_,
+                                       long long strideA, const jstsp_c32 *GA_, long long strideG, const jstsp_c32 *RV_,
+                                       jstsp_c32 *Res_out, jstsp_c32 *P1_out, int memspace)
+{
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
+    JSTSP_REQUIRE(Tc_ && A_ && GA_ && Res_out && P1_out, JSTSP_E_NULL, "gradient_head: NULL array argument");
+    JSTSP_REQUIRE(batch > 0 && grad_head_shape_ok(N, Gr, G2), JSTSP_E_UNSUPPORTED,
+                  "gradient_head: N = %d, Gr = %d, G2 = %d (needs N = Gr = 64, G2 a multiple of 64)", N, Gr, G2);
+    const size_t ng = (size_t)N * G2, g = (size_t)Gr * G2;
+    const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)N * Gr : (size_t)N * Gr;
+    const size_t szG = strideG ? (size_t)strideG * (batch - 1) + (size_t)Gr * Gr : (size_t)Gr * Gr;
+    size_t need = 2 * rnd256(batch * g * sizeof(float2));
+    if (memspace == JSTSP_HOST)
+        need += rnd256(batch * ng * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szG * sizeof(float2)) + rnd256(batch * g * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *Tc, *A, *GA, *RV = nullptr;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(Tc_), batch * ng, memspace, &Tc));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(GA_), szG, memspace, &GA));
+    if (RV_) JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(RV_), batch * g, memspace, &RV));
+    float2 *Res = ctx->arena.get<float2>(batch * g), *P1 = ctx->arena.get<float2>(batch * g);
+    JSTSP_REQUIRE(Res && P1, JSTSP_E_NOMEM, "gradient_head: workspace exhausted");
+    JSTSP_TRY(launch_grad_head(ctx, G2, batch, Tc, (long long)ng, 0, 1, nullptr, nullptr, 0, A, strideA, GA, strideG, RV, nullptr, Res, P1,
+                               nullptr));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Res_out), Res, batch * g, memspace));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(P1_out), P1, batch * g, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}

@@ -368,6 +368,9 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                         o.y += d.beta * dv.y;
                     }
                     const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
+                    if (M64 && EPI == EPI_NONE && d.C_lo)       // what the fp32 result leaves of the float64 sum
+                        d.C_lo[(long long)t * d.sCt + gi + (long long)gj * d.ldc] =
+                            make_float2((float)(mst[nb][0][r] - (double)vr), (float)(mst[nb][1][r] - (double)vi));
                     if (EPI == EPI_UPDATE_C) {
                         // o = Xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (= the reference's :61 + :65, C == -V2)
                         const float rho = d.prm[t].rho, omc = 1.f - d.prm[t].c_coef;
@@ -477,7 +480,9 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     // what hides their latency is the number of workgroups in flight (round 3: 340 -> ? us beside the side chains).
     const int bn64_maxk = 64;
     const bool small_k = tag == GEMM_MISC && d.epi == EPI_NONE && kper <= bn64_maxk;
-    const int variant = (kper >= long_k && tag != GEMM_GRAM && d.epi == EPI_NONE) ? 2 : ((d.n > 64 && !small_k) ? 1 : 0);
+    const int variant = ((kper >= long_k && tag != GEMM_GRAM && d.epi == EPI_NONE) || (d.force_m64 && d.epi == EPI_NONE && d.splitk == 1))
+                            ? 2 : ((d.n > 64 && !small_k) ? 1 : 0);
+    JSTSP_REQUIRE(!d.C_lo || (variant == 2 && d.alpha == 1.f && !d.D), JSTSP_E_ARG, "cgemm: C_lo needs the fp64-master variant, alpha = 1, no D");
     const int bn = variant == 1 ? 128 : 64;
     // 3M where it pays and was validated: the dominant contractions, the Grams, and other products of 256 terms or more
     const int m3_mink = 256;

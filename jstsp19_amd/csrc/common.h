@@ -65,14 +65,17 @@ struct Tuning {
     int fused_parts = 0;    // JSTSP_FUSED_PARTS: column ranges per problem in the pass (0: chosen from M)
     int fused_kback = 4;    // JSTSP_FUSED_KBACK: headroom bits of the predicted k scale (test hook: negative forces the re-solve)
     int toeplitz = 2;       // JSTSP_TOEPLITZ: 0 dictionary taken as unstructured, 1 compact image only, 2 + window kernel (block 64)
-    int toeplitz_gram = 0;  // JSTSP_TOEPLITZ_GRAM: 1 G_B from its first block row (opt-in: 1.36e-6 max |dNMSE|)
     int rv_refresh = 4;     // JSTSP_RV_REFRESH: R v recomputed from v every this many iterations
     int overlap = -1;       // JSTSP_OVERLAP: side streams between the kernels of an iteration (-1: on with the fused pass)
     int svt_skip = 0;       // JSTSP_SVT_SKIP: 1 trials whose threshold is below fp32 resolution skip the eigen-decomposition (opt-in)
     int lanczos = 1;        // JSTSP_LANCZOS: 0 Householder + Sturm instead of Lanczos for the convergence_error norms
     int eig128 = 1;         // JSTSP_EIG128: 0 general Jacobi kernel for Gram orders 65..128
     int omp_gram = 1;       // JSTSP_OMP_GRAM: 0 measurement-space OMP on a Kronecker dictionary
-    int exp_ga = 1, exp_gb = 1;   // (experiment, to be removed) float64 G_A; G_B: 0 split-f16, 1 fp32 MFMA with fp64 masters, 2 float64 kernel
+    int grad_head = 0;      // JSTSP_GRAD_HEAD: bit 0 - Res / P1 of the gradient step, bit 1 - the first factor of a recomputed R v, on the
+                            // f16 pipe in one launch (hsmall.hip) instead of fp32-MFMA products; measured: more accurate products,
+                            // +2 % channel-estimates/s, but WORSE parity (rms |dNMSE| 2.18e-7 against 1.73e-7, a +5e-8 bias): off
+    int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
+    int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
     int bj_trace = 0;       // JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
 };
 const Tuning &tune();       // the calling thread's setting, as parsed by the API call in progress
@@ -169,6 +172,11 @@ struct GemmDesc {
     uint32_t *amax_x, *amax_v1, *amax_z;    // EPI_UPDATE_X: optional [batch] maxima of the new X, V1, Znext
     uint32_t *amax_out;                     // optional [batch]: atomicMax of max(|re|,|im|) (float bits) over the
                                             // stored product (EPI_NONE) / over K (EPI_UPDATE_X); caller zeroes it
+    // Products that become OPERATORS of the iteration (the Grams of the dictionary factors, gram64.hip's note): fp64 master
+    // accumulators whatever k (force_m64), and the part of the float64 sum that the fp32 result C does not hold stored beside
+    // it (C_lo, same layout as C; alpha = 1, no D): C + C_lo carries the product to about 1e-9 relative
+    int force_m64;
+    float2 *C_lo;
 };
 // The N x M array C of the reference is never stored: with cc = rho/(rho+1), D = X - Xs,
 //   C   = cc (D - V2/rho)                       (proposed_algorithm.m:61)
@@ -276,6 +284,8 @@ int launch_inv_d(jstsp_ctx *ctx, long long nm, int batch, const float *Omega, fl
                  const TrialParams *prm, float *invD);
 int launch_rank_from_index(jstsp_ctx *ctx, int g, int batch, const int32_t *indx, int32_t *rank);
 int launch_eye_minus(jstsp_ctx *ctx, int n, int count, const float2 *Q, float2 *P);
+// Y[t] += X[t]  (n complex elements per problem, contiguous over the batch)
+int launch_add(jstsp_ctx *ctx, long long n_total, float2 *Y, const float2 *X);
 int launch_ce_ratio(jstsp_ctx *ctx, int batch, const float *lamV1, const float *lamV2,
                     const float *lamX, double *ce, int Imax, int it);
 

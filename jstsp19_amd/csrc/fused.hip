@@ -344,12 +344,15 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float4 *P, int 
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const float4 *p = P + (long long)t * parts * n4 + i;
-    float4 a = p[0];
+    // (float64: the sum of the column ranges is part of the 4096-term sum K B^H, whose error goes straight into v-space -
+    //  hsmall.hip's note; a memory-bound kernel adds in double for free)
+    const float4 a0 = p[0];
+    double ax = a0.x, ay = a0.y, az = a0.z, aw = a0.w;
     for (int s = 1; s < parts; ++s) {
         const float4 b = p[(long long)s * n4];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        ax += b.x; ay += b.y; az += b.z; aw += b.w;
     }
-    out[(long long)t * n4 + i] = a;
+    out[(long long)t * n4 + i] = make_float4((float)ax, (float)ay, (float)az, (float)aw);
 }
 
 // the same with the leading columns of a block-Toeplitz dictionary (v2): Tc[n, g] += sum over m < ld(g) of k[n, m] conj(B[g, m])
@@ -360,19 +363,20 @@ __global__ __launch_bounds__(256) void reduce_parts_delta_kernel(const float4 *P
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const float4 *p = P + (long long)t * parts * n4 + i;
-    float4 a = p[0];
+    const float4 a0 = p[0];
+    double ax = a0.x, ay = a0.y, az = a0.z, aw = a0.w;      // (float64: see reduce_parts_kernel)
     for (int s = 1; s < parts; ++s) {
         const float4 b = p[(long long)s * n4];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        ax += b.x; ay += b.y; az += b.z; aw += b.w;
     }
     const int n = (int)((2 * i) & 63), g = (int)((2 * i) >> 6), ld = g >> 6;
     const float2 *kf = Kf + (long long)t * 512, *b = B + (long long)t * sBt + g * 8;     // (the leading columns row-major)
     for (int m = 0; m < ld; ++m) {
         const float2 k0 = kf[n + 64 * m], k1 = kf[n + 1 + 64 * m], c = b[m];
-        a.x = fmaf(k0.x, c.x, fmaf(k0.y, c.y, a.x)); a.y = fmaf(k0.y, c.x, fmaf(-k0.x, c.y, a.y));
-        a.z = fmaf(k1.x, c.x, fmaf(k1.y, c.y, a.z)); a.w = fmaf(k1.y, c.x, fmaf(-k1.x, c.y, a.w));
+        ax += (double)k0.x * c.x + (double)k0.y * c.y; ay += (double)k0.y * c.x - (double)k0.x * c.y;
+        az += (double)k1.x * c.x + (double)k1.y * c.y; aw += (double)k1.y * c.x - (double)k1.x * c.y;
     }
-    out[(long long)t * n4 + i] = a;
+    out[(long long)t * n4 + i] = make_float4((float)ax, (float)ay, (float)az, (float)aw);
 }
 
 // DBG != 0 (timing experiments only, results are wrong; not instantiated by default): 1 skips the phase-A products,
@@ -1213,7 +1217,7 @@ int fused_probe_toeplitz(jstsp_ctx *ctx, Arena &ar, const float2 *B, long long s
 //      so one Gt x G2 product (1 / L of the G2 x G2 one: 7 -> 1 ms at BASELINE configs[1]) and at most 3 (L - 1) fp32 terms per
 //      entry give all of it; the lower block triangle is the conjugate transpose.
 __global__ __launch_bounds__(256) void toeplitz_gram_kernel(const float2 *B, long long sBt, int G2, int M, int gt, const float2 *G0,
-                                                            float2 *G)
+                                                            const float2 *G0lo, float2 *G, float2 *Glo)
 {
     const int t = blockIdx.y;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1223,23 +1227,37 @@ __global__ __launch_bounds__(256) void toeplitz_gram_kernel(const float2 *B, lon
     if (ld > l2) return;                                    // written by the mirror entry
     const int d = l2 - ld;
     const float2 *b = B + (long long)t * sBt;
-    float2 v = G0[(long long)t * gt * G2 + g + (long long)gt * (d * gt + g2)];
-    auto mac = [&](float2 x, float2 y, float sgn) {         // v += sgn x conj(y)
-        v.x += sgn * (x.x * y.x + x.y * y.y);
-        v.y += sgn * (x.y * y.x - x.x * y.y);
+    const long long i0 = (long long)t * gt * G2 + g + (long long)gt * (d * gt + g2);
+    // float64 throughout (G0 + G0lo is the block row to 1e-9; the corrections are exact products of fp32 numbers): with fp32
+    // sums every block of a block diagonal would carry the SAME rounding error of its source entry, which adds up coherently
+    // in G_A V G_B instead of averaging out (round 3: max |dNMSE| 8.1e-7 -> 1.36e-6 with that)
+    double vr = (double)G0[i0].x + (G0lo ? (double)G0lo[i0].x : 0.0), vi = (double)G0[i0].y + (G0lo ? (double)G0lo[i0].y : 0.0);
+    auto mac = [&](float2 x, float2 y, double sgn) {        // v += sgn x conj(y)
+        vr += sgn * ((double)x.x * y.x + (double)x.y * y.y);
+        vi += sgn * ((double)x.y * y.x - (double)x.x * y.y);
     };
-    for (int m = 0; m < d; ++m) mac(b[g + (long long)G2 * m], b[d * gt + g2 + (long long)G2 * m], -1.f);
-    for (int u = M - ld; u < M; ++u) mac(b[g + (long long)G2 * u], b[g2 + (long long)G2 * (u - d)], -1.f);
-    for (int m = 0; m < l2; ++m) mac(b[r + (long long)G2 * m], b[c + (long long)G2 * m], 1.f);
+    for (int m = 0; m < d; ++m) mac(b[g + (long long)G2 * m], b[d * gt + g2 + (long long)G2 * m], -1.0);
+    for (int u = M - ld; u < M; ++u) mac(b[g + (long long)G2 * u], b[g2 + (long long)G2 * (u - d)], -1.0);
+    for (int m = 0; m < l2; ++m) mac(b[r + (long long)G2 * m], b[c + (long long)G2 * m], 1.0);
+    if (r == c) vi = 0.0;
+    const float hr = (float)vr, hi = (float)vi;
     float2 *o = G + (long long)t * G2 * G2;
-    o[r + (long long)G2 * c] = v;
-    if (ld < l2) o[c + (long long)G2 * r] = make_float2(v.x, -v.y);
+    // (diagonal blocks, ld == l2: both (r, c) and (c, r) have their own thread - one writer per entry)
+    o[r + (long long)G2 * c] = make_float2(hr, hi);
+    if (ld < l2) o[c + (long long)G2 * r] = make_float2(hr, -hi);
+    if (Glo) {
+        float2 *ol = Glo + (long long)t * G2 * G2;
+        const float lr = (float)(vr - (double)hr), li = (float)(vi - (double)hi);
+        ol[r + (long long)G2 * c] = make_float2(lr, li);
+        if (ld < l2) ol[c + (long long)G2 * r] = make_float2(lr, -li);
+    }
 }
 
-int toeplitz_gram_assemble(jstsp_ctx *ctx, const float2 *B, long long sBt, int G2, int M, int gt, int nB, const float2 *G0, float2 *G)
+int toeplitz_gram_assemble(jstsp_ctx *ctx, const float2 *B, long long sBt, int G2, int M, int gt, int nB, const float2 *G0,
+                           const float2 *G0lo, float2 *G, float2 *Glo)
 {
     hipLaunchKernelGGL(toeplitz_gram_kernel, dim3((unsigned)((G2 * G2 + 255) / 256), nB), dim3(256), 0, ctx->stream, B, sBt, G2, M, gt,
-                       G0, G);
+                       G0, G0lo, G, Glo);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -14,7 +14,7 @@ namespace jstsp {
 // G[t][i + n j] = sum_k a(i,k) conj(a(j,k)),  a(i,k) = X[t sXt + i si + k sk] (conjugated if cj)
 // 16 x 16 outputs per workgroup, k in panels of 16 staged through LDS as float64.
 __global__ __launch_bounds__(256) void gram64_kernel(const float2 *X, long long sXt, long long si, long long sk, int cj, int n,
-                                                     int kdim, float2 *G, long long sGt)
+                                                     int kdim, float2 *G, long long sGt, float2 *Glo)
 {
     __shared__ double ar[16][17], ai[16][17], br[16][17], bi[16][17];
     const int t = blockIdx.z, i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
@@ -48,18 +48,26 @@ __global__ __launch_bounds__(256) void gram64_kernel(const float2 *X, long long 
     if (i < n && j < n) {
         float2 *g = G + (long long)t * sGt;
         if (i == j) ci = 0.0;
-        g[i + (long long)n * j] = make_float2((float)cr, (float)ci);
-        if (i0 != j0) g[j + (long long)n * i] = make_float2((float)cr, (float)-ci);
+        const float hr = (float)cr, hi = (float)ci;
+        g[i + (long long)n * j] = make_float2(hr, hi);
+        if (i0 != j0) g[j + (long long)n * i] = make_float2(hr, -hi);
+        if (Glo) {                                         // G + Glo = the float64 sum to 2^-48
+            float2 *gl = Glo + (long long)t * sGt;
+            const float lr = (float)(cr - (double)hr), li = (float)(ci - (double)hi);
+            gl[i + (long long)n * j] = make_float2(lr, li);
+            if (i0 != j0) gl[j + (long long)n * i] = make_float2(lr, -li);
+        }
     }
 }
 
 // side 'L': G = X^H X (cols x cols);  side 'R': G = X X^H (rows x rows).  X: rows x cols column-major, ld = rows.
-int gram_f64(jstsp_ctx *ctx, char side, const float2 *X, long long sXt, int rows, int cols, int count, float2 *G, long long sGt)
+int gram_f64(jstsp_ctx *ctx, char side, const float2 *X, long long sXt, int rows, int cols, int count, float2 *G, long long sGt,
+             float2 *Glo)
 {
     const int n = side == 'L' ? cols : rows, kdim = side == 'L' ? rows : cols;
     const long long si = side == 'L' ? rows : 1, sk = side == 'L' ? 1 : rows;
     const dim3 grid((n + 15) / 16, (n + 15) / 16, count);
-    hipLaunchKernelGGL(gram64_kernel, grid, dim3(256), 0, ctx->stream, X, sXt, si, sk, side == 'L' ? 1 : 0, n, kdim, G, sGt);
+    hipLaunchKernelGGL(gram64_kernel, grid, dim3(256), 0, ctx->stream, X, sXt, si, sk, side == 'L' ? 1 : 0, n, kdim, G, sGt, Glo);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -183,8 +183,10 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const bool want_fused = allow_fused && tn.fused != 0 && approx && Imax > 1 && fused_shape_ok(N, M, G2, fparts);
     if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);
     need += 1024;                                                                 // probe flags of the block-Toeplitz test
-    // (opt-in JSTSP_TOEPLITZ_GRAM=1 only: room for the first block row of G_B - block height at most G2 / 2)
-    if (tn.toeplitz_gram && tn.toeplitz >= 2) need += rnd256((size_t)nB * (G2 / 2 + 1) * G2 * sizeof(float2));
+    if (approx && tn.gram_refine)      // low-order parts of G_A, G_B, the second pack of G_B, R v's correction term, G_B's block row
+        need += rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + rnd256((size_t)nB * G2 * G2 * sizeof(float2)) +
+                rnd256(batch * g * sizeof(float2)) + hgemm_pack_bytes(G2, G2, nB) +
+                2 * rnd256((size_t)nB * (G2 / 2 + 1) * G2 * sizeof(float2));
     if (memspace == JSTSP_HOST) {
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
                 rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
@@ -244,34 +246,59 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     int toep_gt = 0;
     bool toep_probed = false;
     const Mat GAm{w.GA, strideA ? (long long)Gr * Gr : 0, Gr}, GBm{w.GB, strideB ? (long long)G2 * G2 : 0, G2};
-    // G_A = A^H A (Gr x Gr), G_B = B B^H (G2 x G2):  R = K2'*K2 = G_B^T (x) G_A
-    if (tn.exp_ga) JSTSP_TRY(gram_f64(ctx, 'L', A, strideA, N, Gr, nA, w.GA, (long long)Gr * Gr));
-    else JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
+    // G_A = A^H A (Gr x Gr), G_B = B B^H (G2 x G2):  R = K2'*K2 = G_B^T (x) G_A                      (:25)
+    // These two are OPERATORS of the iteration: `R*v` (:47) stands next to `K2'*k`, which is computed through A and B
+    // themselves, in every one of the Imax gradient steps - an error of a Gram is a constant bias of the gradient, not
+    // rounding noise.  Measured (round 4, tools/precision_study.py and tools/parity_fixture_check.py against 2560 float64
+    // solves): with G_A from a 64-term fp32 chain and G_B from the split-f16 product, rms |dNMSE| 3.9e-7, max 1.95e-6; the
+    // fp32 storage of every array of the iteration together contributes 0.9e-7, a G_B held to 22 bits 1.2e-7.  So, for
+    // 'approximate' (JSTSP_GRAM_REFINE=0: the round-3 products):
+    //  * both Grams are formed in float64 from the fp32 inputs (G_A: gram64.hip; G_B: the fp32-MFMA product with fp64 master
+    //    accumulators - of the first block row only when the dictionary is block-Toeplitz, the rest assembled in float64)
+    //    and kept as TWO floats, G = hi + lo;
+    //  * the iterations use hi (G_B as its 22-bit split-f16 pack) and, whenever R v is recomputed from v (every
+    //    JSTSP_RV_REFRESH-th iteration), the low-order parts as well: (G_A,hi + G_A,lo) V, then P (pack(G_B) + pack(residual)).
+    const bool refine = approx && tn.gram_refine != 0;
+    // the 64-term products of the gradient step on the f16 pipe, fused into one launch (hsmall.hip)
+    const bool use_head = refine && tn.grad_head != 0 && grad_head_shape_ok(N, Gr, G2);      // (bit 0: Res / P1; bit 1: first factor of R v)
+    float2 *GAlo = nullptr, *GBlo = nullptr, *RV2 = nullptr;
+    HPack GBp2;
+    if (refine) {
+        GAlo = ctx->arena.get<float2>((size_t)nA * Gr * Gr);
+        GBlo = ctx->arena.get<float2>((size_t)nB * G2 * G2);
+        RV2 = ctx->arena.get<float2>((size_t)batch * g);
+        JSTSP_REQUIRE(GAlo && GBlo && RV2, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted (Gram refinement)");
+        JSTSP_TRY(gram_f64(ctx, 'L', A, strideA, N, Gr, nA, w.GA, (long long)Gr * Gr, GAlo));
+    } else
+    JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
+    // the block-Toeplitz probe (fused.hip) serves the Gram as well as the pass
+    if (toep_env != 0 && (long long)G2 * M < (1ll << 31) && refine) {
+        JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
+        toep_probed = true;
+    }
     if (w.h2) {
         // pack the dictionary first: G_B = B B^H is itself "a = B, b = conj(B)^T" on the split-f16 path
         JSTSP_TRY(hgemm_pack(ctx, w.Bc, ctx->arena, B, strideB, G2, 1, 1, M, G2, nB, (long long)G2 * M));
         // (the synthesis orientation w.Bs is packed at its first use: with the fused pass that is the last iteration of a
         //  three-output call and never in a two-output call - pack_bs below)
-        // Opt-in (JSTSP_TOEPLITZ_GRAM=1): a block-Toeplitz dictionary (probed: fused.hip) needs only the first block row of G_B,
-        // 1 / L of the product (7 -> 1 ms per call at BASELINE configs[1], +1.4 % channel-estimates/s).  Off by default: every
-        // block on a block diagonal then carries the SAME rounding error of that one row, which adds up coherently in
-        // G_A V G_B instead of averaging out - max |dNMSE| against the float64 port 8.1e-7 -> 1.36e-6 over 48 trials.
-        const bool toep_gram = tn.toeplitz_gram != 0;
-        if (toep_env >= 2 && toep_gram) {
-            JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
-            toep_probed = true;
-        }
-        if (tn.exp_gb == 2) JSTSP_TRY(gram_f64(ctx, 'R', B, strideB, G2, M, nB, w.GB, (long long)G2 * G2));
-        else if (tn.exp_gb == 1) JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
-        else
-        if (toep_gt && toep_gram) {
-            float2 *G0 = ctx->arena.get<float2>((size_t)nB * toep_gt * G2);
-            JSTSP_REQUIRE(G0, JSTSP_E_NOMEM, "workspace exhausted (G_B block row)");
-            HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, G0,
-                         (long long)toep_gt * G2, toep_gt, toep_gt, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
-            JSTSP_TRY(launch_hgemm(ctx, hb, nullptr));
-            JSTSP_TRY(toeplitz_gram_assemble(ctx, B, strideB, G2, M, toep_gt, nB, G0, w.GB));
+    }
+    if (refine) {
+        if (toep_gt && toep_env >= 2) {      // (JSTSP_TOEPLITZ=1 stays bit-identical to the unstructured path: full product there)
+            // block (ld, ld') of G_B from block (0, ld' - ld) of the first block row and at most 3 (L - 1) products of leading /
+            // trailing columns (fused.hip: toeplitz_gram_kernel), all in float64: 1 / L of the product
+            float2 *G0 = ctx->arena.get<float2>((size_t)nB * toep_gt * G2), *G0lo = ctx->arena.get<float2>((size_t)nB * toep_gt * G2);
+            JSTSP_REQUIRE(G0 && G0lo, JSTSP_E_NOMEM, "workspace exhausted (G_B block row)");
+            GemmDesc dg = make_gemm('N', 'C', toep_gt, G2, M, nB, Bm, Bm, G0, (long long)toep_gt * G2, toep_gt);
+            dg.force_m64 = 1; dg.C_lo = G0lo;
+            JSTSP_TRY(launch_cgemm(ctx, dg, GEMM_MISC));
+            JSTSP_TRY(toeplitz_gram_assemble(ctx, B, strideB, G2, M, toep_gt, nB, G0, G0lo, w.GB, GBlo));
         } else {
+            GemmDesc dg = make_gemm('N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2);
+            dg.force_m64 = 1; dg.C_lo = GBlo;
+            JSTSP_TRY(launch_cgemm(ctx, dg, GEMM_MISC));
+        }
+    } else if (w.h2) {
+        {
             // (G_B is Hermitian: the tiles below its diagonal - 12 of 32 at G2 = 512 - are not computed but mirrored)
             HGemmDesc hb{B, strideB, G2, w.Bc.bmax, w.Bc.data, w.Bc.st, w.Bc.bmax, 1, w.Bc.KS, w.Bc.JT, w.GB,
                          (long long)G2 * G2, G2, G2, G2, M, nB, EPI_NONE, nullptr, nullptr, nullptr};
@@ -282,9 +309,13 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     } else
     JSTSP_TRY(gemm(ctx, 'N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2));
 
-    if (w.h2g && approx)
+    if (w.h2g && approx) {
         JSTSP_TRY(hgemm_pack(ctx, w.GBp, ctx->arena, w.GB, strideB ? (long long)G2 * G2 : 0, 1, G2, 0, G2, G2, nB,
                              (long long)G2 * G2));
+        if (refine)         // the low-order part as a second pack with its own scale (R v = P (G_B,hi + G_B,lo))
+            JSTSP_TRY(hgemm_pack(ctx, GBp2, ctx->arena, GBlo, strideB ? (long long)G2 * G2 : 0, 1, G2, 0, G2, G2, nB,
+                                 (long long)G2 * G2));
+    }
     // 'std': v = U\(L\k) (:29,:53) is the least-squares solution K2^+ k = vec(pinv(A) K pinv(B)) for K2 = kron(B.', A)
     // of full column rank.  Factors that fit the in-LDS float64 kernel get a true SVD-based pinv (pinv.hip: every shape
     // of the reference's drivers); larger ones the fp32 Gram inverse G^-1 (hinv.hip), kept in GA / GB, with its
@@ -491,7 +522,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         //  and VALU products lose against the MFMA GEMM even at k = 64;  2. the last column range of a problem adding the
         //  partial sums inside the pass: the device-scope fence it needs writes the L2 back, 3.95 -> 4.36 ms)
         if (passed) {
-            JSTSP_TRY(fused_reduce(ctx, fw, G2, M, batch, w.Tc));
+            if (!use_head) JSTSP_TRY(fused_reduce(ctx, fw, G2, M, batch, w.Tc));      // (hsmall.hip sums the partial sums itself)
         } else if (PB) {       // 'std' with a float64 pinv of B:  Tc = K pinv(B)
             JSTSP_TRY(gemm(ctx, 'N', 'N', N, G2, M, batch, Mat{w.ZK, snm, N}, Mat{PB, strideB ? (long long)M * G2 : 0, M},
                            w.Tc, sng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
@@ -503,29 +534,68 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         } else
         JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{w.ZK, snm, N}, Bm, w.Tc, sng, N, 1.f, nullptr, 0, 0,
                        0.f, GEMM_CORRELATE));
+        auto fused_reduce_if = [&](bool p) -> int { return p ? fused_reduce(ctx, fw, G2, M, batch, w.Tc) : 0; };
         const long long cnt_ll = std::min<long long>(10 + 5ll * (it + 1), (long long)g);
-        // (G_A X) G_B: the G2 x G2 factor is packed once per solve; max|G_A X| comes from the first product's epilogue
-        auto apply_R = [&](const float2 *Xin, float2 *out) -> int {
+        // (G_A X) G_B: the G2 x G2 factor is packed once per solve; max|G_A X| comes from the first product's epilogue.
+        // exact (R v itself is being formed from v): with the low-order parts of both Grams (see the setup above), the first factor
+        // on the f16 pipe with G_A = hi + lo (hsmall.hip), the second as the fp32-MFMA product with fp64 master accumulators against
+        // G_B,hi plus the split-f16 product against G_B,lo
+        const Mat GAl{GAlo, strideA ? (long long)Gr * Gr : 0, Gr}, GBl{GBlo, strideB ? (long long)G2 * G2 : 0, G2};
+        auto second_factor = [&](float2 *out, uint32_t *pm, bool exact) -> int {
             if (!w.h2g) {
-                JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAm, Mat{Xin, sg, Gr}, w.P1, sg, Gr));
-                return gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, out, sg, Gr);
+                JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, out, sg, Gr));
+                if (exact) JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBl, out, sg, Gr, 1.f, out, sg, Gr, 1.f));
+                return 0;
             }
-            GemmDesc dp = make_gemm('N', 'N', Gr, G2, Gr, batch, GAm, Mat{Xin, sg, Gr}, w.P1, sg, Gr);
-            uint32_t *pm = w.pmax + (size_t)(apply_no++ & 1) * batch;      // two applies per iteration, one slot each
-            dp.amax_out = pm;
-            JSTSP_TRY(launch_cgemm(ctx, dp, GEMM_MISC));
+            if (exact) {
+                GemmDesc dr = make_gemm('N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, out, sg, Gr);
+                dr.force_m64 = 1;
+                JSTSP_TRY(launch_cgemm(ctx, dr, GEMM_MISC));
+                HGemmDesc hr{w.P1, sg, Gr, pm, GBp2.data, strideB ? GBp2.st : 0, GBp2.bmax, strideB ? 1 : 0,
+                             GBp2.KS, GBp2.JT, RV2, sg, Gr, Gr, G2, G2, batch, EPI_NONE, nullptr, nullptr, nullptr};
+                JSTSP_TRY(launch_hgemm(ctx, hr, nullptr));
+                return launch_add(ctx, (long long)batch * sg, out, RV2);
+            }
             HGemmDesc hg{w.P1, sg, Gr, pm, w.GBp.data, strideB ? w.GBp.st : 0, w.GBp.bmax, strideB ? 1 : 0,
                          w.GBp.KS, w.GBp.JT, out, sg, Gr, Gr, G2, G2, batch, EPI_NONE, nullptr, nullptr, nullptr};
             return launch_hgemm(ctx, hg, nullptr);
         };
+        auto apply_R = [&](const float2 *Xin, float2 *out, bool exact) -> int {
+            uint32_t *pm = w.pmax ? w.pmax + (size_t)(apply_no++ & 1) * batch : nullptr;      // two applies per iteration, one slot each
+            if (use_head && exact && (tn.grad_head & 2)) {
+                JSTSP_TRY(launch_left2(ctx, G2, batch, w.GA, GAlo, strideA ? (long long)Gr * Gr : 0, Xin, w.P1, pm));
+            } else {
+                if (exact) JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, GAl, Mat{Xin, sg, Gr}, w.P1, sg, Gr));      // P1 = G_A,lo X
+                GemmDesc dp = make_gemm('N', 'N', Gr, G2, Gr, batch, GAm, Mat{Xin, sg, Gr}, w.P1, sg, Gr, 1.f, exact ? w.P1 : nullptr, sg,
+                                        Gr, exact ? 1.f : 0.f);
+                dp.amax_out = w.h2g ? pm : nullptr;
+                JSTSP_TRY(launch_cgemm(ctx, dp, GEMM_MISC));
+            }
+            return second_factor(out, pm, exact);
+        };
         if (approx) {
             // R v: recomputed from v every `rv_refresh` iterations, carried by R v += alpha R res in between (both are
             // `R*v` of :47; the recurrence alone drifts in fp32)
-            if (it % rv_refresh == 0) JSTSP_TRY(apply_R(w.V, w.RV));
-            JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
-                           -1.f));
-            //    R*res for alpha = res'*res / (res'*R*res)                                    (:48)
-            JSTSP_TRY(apply_R(w.Res, w.RRes));
+            if (it % rv_refresh == 0 || it < tn.rv_always) JSTSP_TRY(apply_R(w.V, w.RV, refine));
+            if (use_head && !(tn.grad_head & 1)) JSTSP_TRY(fused_reduce_if(passed));
+            if (use_head && (tn.grad_head & 1)) {
+                // Res = A^H Tc - R v and P1 = G_A Res in one kernel on the f16 pipe, straight from the pass's partial sums
+                uint32_t *pm = w.pmax ? w.pmax + (size_t)(apply_no++ & 1) * batch : nullptr;
+                if (passed)
+                    JSTSP_TRY(launch_grad_head(ctx, G2, batch, fw.Ppart, (long long)fw.parts * sng, sng, fw.parts, fw.v2 ? fw.Kf : nullptr,
+                                               fw.Bdl, fw.sBdl, A, strideA, w.GA, strideA ? (long long)Gr * Gr : 0, w.RV, nullptr, w.Res,
+                                               w.P1, pm));
+                else
+                    JSTSP_TRY(launch_grad_head(ctx, G2, batch, w.Tc, sng, 0, 1, nullptr, nullptr, 0, A, strideA, w.GA,
+                                               strideA ? (long long)Gr * Gr : 0, w.RV, nullptr, w.Res, w.P1, pm));
+                //    R*res for alpha = res'*res / (res'*R*res)                                (:48)
+                JSTSP_TRY(second_factor(w.RRes, pm, false));
+            } else {
+                JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
+                               -1.f));
+                //    R*res for alpha = res'*res / (res'*R*res)                                (:48)
+                JSTSP_TRY(apply_R(w.Res, w.RRes, false));
+            }
             if (svt_split) {
                 JSTSP_HIP(hipEventRecord(ev_q1, sm));
                 JSTSP_HIP(hipStreamWaitEvent(s1, ev_q1, 0));

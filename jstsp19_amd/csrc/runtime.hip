@@ -28,7 +28,6 @@ void load_tuning()
     t.fused_parts = env_int("JSTSP_FUSED_PARTS", t.fused_parts);
     t.fused_kback = env_int("JSTSP_FUSED_KBACK", t.fused_kback);
     t.toeplitz = env_int("JSTSP_TOEPLITZ", t.toeplitz);
-    t.toeplitz_gram = env_int("JSTSP_TOEPLITZ_GRAM", t.toeplitz_gram);
     t.rv_refresh = env_int("JSTSP_RV_REFRESH", t.rv_refresh);
     t.overlap = env_int("JSTSP_OVERLAP", t.overlap);
     t.svt_skip = env_int("JSTSP_SVT_SKIP", t.svt_skip);
@@ -36,8 +35,9 @@ void load_tuning()
     t.eig128 = env_int("JSTSP_EIG128", t.eig128);
     t.omp_gram = env_int("JSTSP_OMP_GRAM", t.omp_gram);
     t.bj_trace = env_int("JSTSP_BJ_TRACE", t.bj_trace);
-    t.exp_ga = env_int("JSTSP_EXP_GA", t.exp_ga);
-    t.exp_gb = env_int("JSTSP_EXP_GB", t.exp_gb);
+    t.gram_refine = env_int("JSTSP_GRAM_REFINE", t.gram_refine);
+    t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
+    t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     g_tune = t;
 }
 
@@ -148,6 +148,7 @@ GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Ma
     d.splitk = splitk < 1 ? 1 : splitk; d.sCsplit = sCsplit;
     d.epi = EPI_NONE; d.prm = nullptr; d.e_rw0 = d.e_w1 = d.e_w2 = d.e_w3 = nullptr;
     d.e_r0 = d.e_r1 = d.e_r2 = d.e_r3 = nullptr; d.e_f0 = nullptr; d.epi_store_c = 1; d.amax_out = nullptr; d.amax_x = d.amax_v1 = d.amax_z = nullptr;
+    d.force_m64 = 0; d.C_lo = nullptr;
     return d;
 }
 

@@ -17,8 +17,21 @@ int gemm(jstsp_ctx *ctx, char opA, char opB, int m, int n, int k, int batch, Mat
          int ldd = 0, float beta = 0.f, int tag = GEMM_MISC, int splitk = 1, long long sCsplit = 0);
 
 // Gram of a dictionary factor with float64 products and sums (gram64.hip): side 'L' G = X^H X (cols x cols), 'R' G = X X^H
-// (rows x rows); X rows x cols column-major (ld = rows), sXt = 0: shared; G order n, ld = n, exactly Hermitian
-int gram_f64(jstsp_ctx *ctx, char side, const float2 *X, long long sXt, int rows, int cols, int count, float2 *G, long long sGt);
+// (rows x rows); X rows x cols column-major (ld = rows), sXt = 0: shared; G order n, ld = n, exactly Hermitian; Glo (optional,
+// same layout): the part of the float64 sum that the fp32 G does not hold
+int gram_f64(jstsp_ctx *ctx, char side, const float2 *X, long long sXt, int rows, int cols, int count, float2 *G, long long sGt,
+             float2 *Glo = nullptr);
+
+// The 64-term products of the gradient step on the f16 matrix pipe (hsmall.hip), N = Gr = 64:
+//   Tc = sum of `parts` partial sums (P[t sPt + p sPp + n + 64 g]) [+ leading-column terms of a block-Toeplitz dictionary: Kf, Bdl],
+//   Res = A^H Tc - RV (RV may be NULL), P1 = G_A Res, pmax[t] = max|P1| (atomicMax; may be NULL); Tc stored if non-NULL
+bool grad_head_shape_ok(int N, int Gr, int G2);
+int launch_grad_head(jstsp_ctx *ctx, int G2, int batch, const float2 *P, long long sPt, long long sPp, int parts, const float2 *Kf,
+                     const float2 *Bdl, long long sBdl, const float2 *A, long long sA, const float2 *GA, long long sGA,
+                     const float2 *RV, float2 *Tc, float2 *Res, float2 *P1, uint32_t *pmax);
+//   P1 = (G_hi + G_lo) X, G Hermitian 64 x 64 in two floats (sG = 0: shared), X and P1 64 x G2 per trial
+int launch_left2(jstsp_ctx *ctx, int G2, int batch, const float2 *Ghi, const float2 *Glo, long long sG, const float2 *X, float2 *P1,
+                 uint32_t *pmax);
 
 // Descriptor only (the caller may attach a fused epilogue before launch_cgemm).
 GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Mat B, float2 *C, long long sCt,
@@ -152,7 +165,8 @@ bool fused_shape_ok(int N, int M, int G2, int parts);
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts);
 int fused_probe_toeplitz(jstsp_ctx *ctx, Arena &ar, const float2 *B, long long sBt, int G2, int M, int nB, int *gt);   // syncs
 // G_B = B B^H (G2 x G2, column-major) of a block-Toeplitz dictionary from its first block row G0 = B(0:gt, :) B^H (gt x G2)
-int toeplitz_gram_assemble(jstsp_ctx *ctx, const float2 *B, long long sBt, int G2, int M, int gt, int nB, const float2 *G0, float2 *G);
+int toeplitz_gram_assemble(jstsp_ctx *ctx, const float2 *B, long long sBt, int G2, int M, int gt, int nB, const float2 *G0,
+                           const float2 *G0lo, float2 *G, float2 *Glo);     // G0lo, Glo optional: low-order parts (float64 = hi + lo)
 int fused_alloc(Arena &ar, FusedWS &f, int M, int G2, int nB, int batch, int parts, int gt, int v2);
 int fused_pack_b(jstsp_ctx *ctx, FusedWS &f, const float2 *B, long long sBt, int G2, int M, int nB, const uint32_t *bmax);
 int fused_pack_as(jstsp_ctx *ctx, const FusedWS &f, const float2 *W, long long sWt, int G2, int M, int batch, const uint32_t *wmax);

@@ -233,8 +233,10 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
     hipStream_t st = ctx->stream;
     // ---- decompositions (the `svd(B)` of vamp.m:32 in factored complex form)
     const Mat Am{Af, sA, Na}, Gm{Gb, sG, G2};
-    if (tall) JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, Na, nA, Am, Am, AAh, (long long)Gr * Gr, Gr));     // A'A = Va diag(la) Va'
-    else JSTSP_TRY(gemm(ctx, 'N', 'C', Na, Na, Gr, nA, Am, Am, AAh, (long long)Na * Na, Na));          // A A' = Ua diag(sa^2) Ua'
+    // (the Gram in float64, rounded once: its eigenvalues are the SQUARES of the singular values the reference's svd returns,
+    //  so every digit lost in forming it is lost twice)
+    if (tall) JSTSP_TRY(gram_f64(ctx, 'L', Af, sA, Na, Gr, nA, AAh, (long long)Gr * Gr));              // A'A = Va diag(la) Va'
+    else JSTSP_TRY(gram_f64(ctx, 'R', Af, sA, Na, Gr, nA, AAh, (long long)Na * Na));                   // A A' = Ua diag(sa^2) Ua'
     JSTSP_TRY(launch_eig(ctx, EIG_VECS, Da, nA, AAh, (long long)Da * Da, 1, 0, nullptr, nullptr, Ua, lamA, Vga));
     JSTSP_TRY(launch_eig(ctx, EIG_VECS, G2, nG, Gb, sG, 1, 0, nullptr, nullptr, Ub, lamB, Vgb));
     const Mat Uam{Ua, sA ? (long long)Da * Da : 0, Da}, Ubm{Ub, sG ? (long long)G2 * G2 : 0, G2};

@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import DEVICE, HOST, JstspError, check
 
 __all__ = ["proposed_algorithm", "proposed_algorithm_angles", "svt", "mc_svt", "mc_admm", "OMP", "omp_kron",
-           "sparse_admm", "vamp", "vamp_kron", "ls_estimate", "pinv", "mmv_omp", "tssr", "rate", "correlate", "synthesize", "nmse_spectral", "colmajor",
+           "sparse_admm", "vamp", "vamp_kron", "ls_estimate", "pinv", "mmv_omp", "tssr", "rate", "correlate", "synthesize", "gradient_head", "nmse_spectral", "colmajor",
            "empty_colmajor"]
 
 
@@ -214,6 +214,23 @@ def synthesize(S, A, B, *, ctx=None):
                                       _shared_stride(a_A, N * Gr, batch, "A"), a_B.ptr,
                                       _shared_stride(a_B, G2 * M, batch, "B"), p, mem), "jstsp_synthesize_c32")
     return f(not a_S.batched)
+
+
+def gradient_head(Tc, A, GA, RV=None, *, ctx=None):
+    """``Res = A'*Tc - RV`` and ``P1 = GA*Res`` (Gr x G2 each) — the 64-term products of the gradient step,
+    proposed_algorithm.m:47-48, as the solver forms them (N = Gr = 64, G2 a multiple of 64)."""
+    a_T, a_A, a_G = _Arg(Tc, np.complex64, "Tc"), _Arg(A, np.complex64, "A"), _Arg(GA, np.complex64, "GA")
+    a_R = _Arg(RV, np.complex64, "RV", allow_none=True)
+    batch, N, G2, Gr = a_T.batch, a_T.R, a_T.C, a_A.C
+    if a_A.R != N or (a_G.R, a_G.C) != (Gr, Gr) or (RV is not None and (a_R.batch, a_R.R, a_R.C) != (batch, Gr, G2)):
+        raise ValueError("shape mismatch")
+    c, mem, dev = _ctx_for([a_T, a_A, a_G, a_R], ctx)
+    pr, fr = _out(mem == DEVICE, batch, Gr, G2, np.complex64, dev)
+    pp, fp = _out(mem == DEVICE, batch, Gr, G2, np.complex64, dev)
+    check(c._lib.jstsp_gradient_head_c32(c.handle, N, Gr, G2, batch, a_T.ptr, a_A.ptr, _shared_stride(a_A, N * Gr, batch, "A"),
+                                         a_G.ptr, _shared_stride(a_G, Gr * Gr, batch, "GA"), a_R.ptr, pr, pp, mem),
+          "jstsp_gradient_head_c32")
+    return fr(not a_T.batched), fp(not a_T.batched)
 
 
 def ls_estimate(Y, A, B, *, ctx=None):

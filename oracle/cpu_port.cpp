@@ -278,6 +278,13 @@ inline void jitter(Planar &p, double rel, uint64_t &state)
     }
 }
 
+// x rounded to `bits` significant bits (the split-f16 operand pack keeps 22)
+inline void round_bits(Planar &p, int bits)
+{
+    auto r = [bits](double x) { if (x == 0.0) return 0.0; int e; const double m = std::frexp(x, &e); return std::ldexp(std::nearbyint(std::ldexp(m, bits)), e - bits); };
+    for (size_t i = 0; i < p.re.size(); ++i) { p.re[i] = r(p.re[i]); p.im[i] = r(p.im[i]); }
+}
+
 inline double soft(double v, double t) { return v > t ? v - t : (v < -t ? v + t : 0.0); }
 inline double ratio(double a, double b) { return b == 0.0 ? (a == 0.0 ? std::numeric_limits<double>::quiet_NaN() : std::numeric_limits<double>::infinity()) : a / b; }
 
@@ -295,8 +302,13 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
     X.init(N, M); V1.init(N, M); V2.init(N, M); C.init(N, M); Xs.init(N, M); Y.init(N, M); Z.init(N, M); K.init(N, M);
     S.init(Gr, G2); V.init(Gr, G2); Res.init(Gr, G2); RRes.init(Gr, G2); T1.init(N, G2); T2.init(Gr, G2); W.init(N, G2);
     GA.init(Gr, Gr); GB.init(G2, G2);
+    const char *rm_env0 = std::getenv("JSTSP_PORT_ROUND");
+    const unsigned rm0 = rm_env0 ? (unsigned)std::strtoul(rm_env0, nullptr, 0) : 0u;
+    if (rm0 & 131072u) { round_bits(B, 22); round_bits(Bh, 22); }          // the packed dictionary everywhere (consistent)
     gemm(Ah, A, GA);                                              // R = K2'*K2 = (B B')^T (x) (A'A)      (:25)
     gemm(B, Bh, GB);
+    if (rm0 & 65536u) { round_bits(B, 22); round_bits(Bh, 22); }           // ... in the products only, G_B from the exact one
+    if (rm0 & 262144u) round_bits(GB, 22);                                  // the packed G_B of the apply
     const char *rm_env = std::getenv("JSTSP_PORT_ROUND");
     const unsigned rm = rm_env ? (unsigned)std::strtoul(rm_env, nullptr, 0) : 0u;
     const char *rj_env = std::getenv("JSTSP_PORT_JITTER");

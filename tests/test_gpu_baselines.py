@@ -233,13 +233,20 @@ def test_vamp_dense_at_the_drivers_size_is_the_unchanged_call():
     Phi = np.stack([np.kron(Gb[t].T, A) for t in range(nt)])              # :79
     y = np.stack([Ym[t].flatten("F") for t in range(nt)])                 # :80
     assert Phi.shape == (nt, 512, 512)
-    for nit, tol in ((1, 2e-5), (5, 2e-4), (12, 1e-2)):
+    # (from 2 iterations on: after ONE the literal restatement's x is the eps*1i contamination of r1init itself, 2e-24)
+    errs = {}
+    # (measured: 4e-5 / 1.5e-4 / 7e-4 - the dense route squares the condition number in an fp32 eigen-decomposition of
+    #  Phi*Phi' where the factored route decomposes the two small Grams; both follow the float64 iteration until its chaos takes over)
+    for nit, tol in ((2, 1e-4), (5, 5e-4), (12, 5e-3)):
         xd = np.asarray(J.vamp(y, Phi, 1.0, numOfnz, nit=nit))             # batched: one dictionary per trial
         xk = np.asarray(J.vamp_kron(Ym, A, Gb, 1.0, numOfnz, nit=nit))
         for t in range(nt):
             ref = V.vamp_literal(y[t], Phi[t], 1.0, numOfnz, nit=nit)
-            assert rel_err(xd[t], ref) < tol, (nit, t, rel_err(xd[t], ref))
-            assert rel_err(xd[t], xk[t].flatten("F")) < 2 * tol, (nit, t)
+            errs[(nit, t)] = (rel_err(xd[t], ref), rel_err(xd[t], xk[t].flatten("F")))
+    print("dense vamp 512: (iterations, trial) -> (vs literal float64, vs vamp_kron):", {k: ("%.1e" % a, "%.1e" % b) for k, (a, b) in errs.items()})
+    for (nit, t), (e_lit, e_kron) in errs.items():
+        tol = {2: 1e-4, 5: 5e-4, 12: 5e-3}[nit]
+        assert e_lit < tol and e_kron < 2 * tol, (nit, t, e_lit, e_kron)
     # single (2-D) call == the batched call's first problem; 100 iterations: finite, same quality as the factored form
     x1 = np.asarray(J.vamp(y[0], Phi[0], 1.0, numOfnz, nit=5))
     assert rel_err(x1, np.asarray(J.vamp(y, Phi, 1.0, numOfnz, nit=5))[0]) < 1e-5

@@ -258,3 +258,39 @@ def test_public_correlate_and_synthesize_keep_fp32_accuracy_per_row_under_dynami
     assert float((err.amax(dim=2) / ref.abs().amax(dim=2)).max()) < 1e-6
     assert float((err.amax(dim=1) / ref.abs().amax(dim=1)).max()) < 1e-6
     torch.cuda.synchronize()
+
+
+def test_gradient_head_products_are_accurate_to_the_fp32_output():
+    """csrc/hsmall.hip through the C ABI: Res = A'*Tc - RV and P1 = GA*Res (proposed_algorithm.m:47-48) against float64.
+    These sums live in v-space, where the iteration never forgets an error, so they must be good to
+    the rounding of their fp32 OUTPUT - including entries far below the operand maximum, which the three-way f16 split only
+    represents if small third parts survive: a wide dynamic range of Tc rows and of A entries is part of the test."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(42)
+    c = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    N = Gr = 64
+    G2, batch = 128, 3
+    A = (c(N, Gr) / 8).astype(np.complex64)
+    A[:, ::5] *= 2.0 ** -9                                    # columns far below the maximum
+    GA = (A.astype(np.complex128).conj().T @ A.astype(np.complex128)).astype(np.complex64)
+    Tc = c(batch, N, G2).astype(np.complex64)
+    Tc[:, ::3, :] *= 2.0 ** -11                                # rows 2000 times smaller than the rest
+    RV = (0.3 * c(batch, Gr, G2)).astype(np.complex64)
+    A64, GA64, T64, R64 = (x.astype(np.complex128) for x in (A, GA, Tc, RV))
+    res_ref = np.einsum("na,tng->tag", A64.conj(), T64) - R64
+    Res, P1 = J.gradient_head(Tc, A, GA, RV)
+    Res, P1 = np.asarray(Res), np.asarray(P1)
+    # error relative to the magnitude of the terms of each sum (row-wise bound: |A|^T |Tc|), a few fp32 ulps
+    bound = np.einsum("na,tng->tag", np.abs(A64), np.abs(T64)) + np.abs(R64)
+    err = np.abs(Res - res_ref) / bound
+    assert err.max() < 1.5e-7, float(err.max())
+    assert np.sqrt(np.mean(err ** 2)) < 3e-8, float(np.sqrt(np.mean(err ** 2)))
+    p1_ref = np.einsum("ab,tbg->tag", GA64, Res.astype(np.complex128))      # second product from the kernel's own Res
+    b2 = np.einsum("ab,tbg->tag", np.abs(GA64), np.abs(Res.astype(np.complex128)))
+    e2 = np.abs(P1 - p1_ref) / b2
+    assert e2.max() < 1.5e-7 and np.sqrt(np.mean(e2 ** 2)) < 3e-8, (float(e2.max()), float(np.sqrt(np.mean(e2 ** 2))))
+    # the small columns / rows came through with their own relative accuracy (not just that of the maximum)
+    small = np.abs(res_ref[:, ::5, :])
+    assert np.median(np.abs(Res[:, ::5, :] - res_ref[:, ::5, :]) / np.maximum(small, 1e-30)) < 1e-6
+    with pytest.raises(J.JstspError):
+        J.gradient_head(Tc[:, :32], A[:32], GA)               # N = 32 is not a shape of this kernel

@@ -30,7 +30,7 @@ def main():
         nb = max(1, a.n // 64)
         starts = np.linspace(0, total - 64, nb).astype(int) // 64 * 64
         rows = np.unique(np.concatenate([np.arange(s, s + 64) for s in starts]))
-    res = {}
+    res, per_trial = {}, {}
     for v in a.variants:
         env = dict(kv.split("=") for kv in v.split(",") if kv)
         os.environ.update(env)
@@ -44,10 +44,15 @@ def main():
         res[v or "default"] = {"trials": int(len(rows)), "max": float(np.abs(d).max()), "rms": float(np.sqrt(np.mean(d ** 2))),
                                "p99": float(np.quantile(np.abs(d), 0.99)), "over_1e-6": int(np.sum(np.abs(d) > 1e-6)),
                                "over_5e-7": int(np.sum(np.abs(d) > 5e-7)), "signed_mean": float(d.mean()), "seconds": round(time.time() - t0, 1)}
+        snr = fx[a.group + "/snr_db"][rows]
+        res[v or "default"]["rms_by_snr"] = {"%+d" % int(x): round(float(np.sqrt(np.mean(d[snr == x] ** 2))) * 1e7, 3) for x in np.unique(snr)}
+        res[v or "default"]["mean_by_snr"] = {"%+d" % int(x): round(float(np.mean(d[snr == x])) * 1e7, 3) for x in np.unique(snr)}
+        per_trial[v or "default"] = d
         print(v or "default", json.dumps(res[v or "default"]), flush=True)
     if a.out:
         with open(a.out, "w") as f:
             json.dump({"group": a.group, "results": res}, f, indent=1)
+        np.savez_compressed(a.out.replace(".json", "") + "_per_trial.npz", rows=rows, **{k.replace("=", "_").replace(",", "__") or "default": v for k, v in per_trial.items()})
 
 
 if __name__ == "__main__":

@@ -22,7 +22,9 @@ sys.path.insert(0, ROOT)
 
 NAMES = {1: "X,K stored fp32", 2: "V1,V2 stored fp32", 4: "V,S stored fp32", 8: "Tc = K B^H output fp32", 16: "Res terms fp32 (A^H Tc, G_A V G_B, difference)",
          32: "R res fp32", 64: "Xs = A S B output fp32", 128: "G_A, G_B fp32", 256: "Y fp32", 512: "W = A S fp32",
-         2048: "K B^H accumulation jitter", 4096: "G_A V G_B accumulation jitter", 8192: "A S B accumulation jitter", 16384: "G_A jitter (one-off)", 32768: "G_B jitter (one-off)"}
+         2048: "K B^H accumulation jitter", 4096: "G_A V G_B accumulation jitter", 8192: "A S B accumulation jitter", 16384: "G_A jitter (one-off)", 32768: "G_B jitter (one-off)",
+         65536: "B to 22 bits in K B^H and (A S) B, G_B from exact B", 131072: "B to 22 bits everywhere (consistent)",
+         262144: "G_B to 22 bits"}
 
 
 def main():
