@@ -17,55 +17,11 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 1e-6                      # |NMSE_hip - NMSE_float64| per trial (BASELINE.json north_star; include/jstsp.h)
 IMAX = 100
 
 
-def fixture():
-    z = np.load(os.path.join(HERE, "golden", "fullsize_port.npz"))
-    return {k: z[k] for k in z.files}
-
-
-def solve_group(fx, group, rows, *, want_ce, angles, chunk=256):
-    """HIP results for fixture rows `rows` of `group`: (nmse (n,), ce (n, Imax, 3) or None).  Rows are processed in runs of
-    consecutive trials of one sweep point; every rebuilt trial must reproduce the fixture's fingerprint."""
-    import torch
-    import jstsp19_amd as J
-    from jstsp19_amd.system_model import SweepParams, build_trials
-    from oracle import solvers as O
-    sidx, trial, snr, fp = (fx[group + "/" + k] for k in ("sweep_idx", "trial", "snr_db", "fingerprint"))
-    rows = np.asarray(rows)
-    nmse = np.empty(len(rows))
-    ces = np.empty((len(rows), IMAX, 3)) if want_ce else None
-    i = 0
-    while i < len(rows):
-        j = i + 1
-        while (j < len(rows) and j - i < chunk and sidx[rows[j]] == sidx[rows[i]] and snr[rows[j]] == snr[rows[i]]
-               and trial[rows[j]] == trial[rows[j - 1]] + 1):
-            j += 1
-        r = rows[i:j]
-        p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=float(snr[r[0]]))
-        inp = build_trials(p, int(trial[r[0]]), len(r), sweep_idx=int(sidx[r[0]]))
-        f = torch.stack([inp["subY"].abs().double().sum((1, 2)), inp["B"].abs().double().sum((1, 2)),
-                         inp["Omega"].double().sum((1, 2))], 1).cpu().numpy()
-        np.testing.assert_allclose(f, fp[r][:, :3], rtol=1e-9, err_msg="the generator no longer reproduces the fixture's inputs")
-        # The hyper-parameters are INPUTS of the solver (plot_errorVSsnr.m:127-130): the float64 side was solved with the values
-        # the fixture records, and so is the HIP side.  (The builder's own tau_Y, tau_Z, rho agree with them to fp32 rounding
-        # only - rho = sigma_6 / ||Y||_F comes from a Gram whose split-K count depends on how many trials are built per call.)
-        np.testing.assert_allclose(np.stack([inp[k].numpy() for k in ("tau_Y", "tau_Z", "rho")], 1), fp[r][:, 3:], rtol=2e-6)
-        hyp = [np.ascontiguousarray(fp[r][:, 3 + k]) for k in range(3)]
-        S, _, ce = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], IMAX, *hyp, "approximate",
-                                        indx_S=inp["indx_S"] if angles else None, want_ce=want_ce)
-        torch.cuda.synchronize()
-        assert J.default_context(0).last_fused_fallbacks() == 0
-        Sh = S.cpu().numpy().astype(np.complex128)
-        zb = inp["Zbar"].cpu().numpy().astype(np.complex128)
-        nmse[i:j] = [O.nmse_capped(Sh[t], zb[t]) for t in range(len(r))]
-        if want_ce:
-            ces[i:j] = ce.cpu().numpy()
-        i = j
-    return nmse, ces
+from oracle.fullsize_fixture import fixture, solve_group  # noqa: E402
 
 
 def check_ce(fx, group, rows, ces):

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("variants", nargs="*", default=[""])
     a = ap.parse_args()
     import time
-    from test_gpu_parity_tail import fixture, solve_group
+    from oracle.fullsize_fixture import fixture, solve_group
     fx = fixture()
     total = len(fx[a.group + "/nmse_port"])
     rows = np.arange(total)
