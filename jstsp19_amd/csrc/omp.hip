@@ -382,6 +382,32 @@ static size_t omp_bytes(int meas, int m, int batch)
 
 using namespace jstsp;
 
+// ---- corr = A' * r (OMP.m:17) for FEW right-hand sides per dictionary: one wave per atom, lanes stride over the measurements
+//      (coalesced along the column), fp32 partial sums per lane, float64 wave-shuffle reduction.  A dictionary of its own per
+//      problem, or a shared one with a handful of problems, is a matrix-vector product: HBM-bound on 8 * meas * size_d bytes per
+//      iteration, where the MFMA GEMM with a one-column operand ran at 16 GB/s (0.51 ms per iteration
+//      at BASELINE configs[0]: profiles/r04_cfg1_omp_kernel_stats.csv, before).
+__global__ __launch_bounds__(256) void omp_corr_gemv_kernel(int meas, int size_d, const float2 *A, long long strideA,
+                                                            const float2 *r, float2 *corr)
+{
+    const int t = blockIdx.y, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= size_d) return;
+    const float2 *a = A + (long long)t * strideA + (long long)j * meas, *rv = r + (long long)t * meas;
+    float sr = 0.f, si = 0.f;
+    double dr = 0.0, di = 0.0;
+    int cnt = 0;
+    for (int i = lane; i < meas; i += 64) {
+        const float2 x = a[i], y = rv[i];
+        sr = fmaf(x.x, y.x, fmaf(x.y, y.y, sr));            // conj(a) r
+        si = fmaf(x.x, y.y, fmaf(-x.y, y.x, si));
+        if (++cnt == 32) { dr += sr; di += si; sr = 0.f; si = 0.f; cnt = 0; }      // fp32 chains of at most 32 terms
+    }
+    dr += sr; di += si;
+    for (int o = 32; o > 0; o >>= 1) { dr += __shfl_xor(dr, o); di += __shfl_xor(di, o); }
+    if (lane == 0) corr[(long long)t * size_d + j] = make_float2((float)dr, (float)di);
+}
+
 extern "C" {
 
 int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c32 *A_, long long strideA,
@@ -416,8 +442,12 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
     JSTSP_HIP(hipMemsetAsync(s.nu, 0, batch * sizeof(int), st));
     JSTSP_HIP(hipMemsetAsync(s.Rm, 0, (size_t)batch * m * m * sizeof(float2), st));
     for (int it = 0; it < m; ++it) {                                                                           // :16
-        // A'*r (:17).  Shared dictionary: one GEMM with the residuals of all problems as columns.
-        if (strideA == 0)
+        // A'*r (:17).  Few right-hand sides per dictionary: the matrix-vector kernel above.  Shared dictionary and many problems:
+        // one GEMM with the residuals of all problems as columns.
+        if (strideA != 0 || batch <= 16)
+            hipLaunchKernelGGL(omp_corr_gemv_kernel, dim3((size_d + 3) / 4, batch), dim3(256), 0, st, meas, size_d, A, strideA, s.r,
+                               corr);
+        else if (strideA == 0)
             JSTSP_TRY(gemm(ctx, 'C', 'N', size_d, batch, meas, 1, Mat{A, 0, meas}, Mat{s.r, 0, meas}, corr, 0,
                            size_d));
         else

@@ -70,3 +70,29 @@ def test_all_2816_trials_of_the_bench_batch_and_the_snr_sweep():
         assert np.abs(d).max() < TOL, worst
         assert np.sqrt(np.mean(d ** 2)) < TOL / 3, worst
         assert check_ce(fx, group, np.arange(n), ces) >= 160
+
+
+def test_sweep_runner_at_the_configs3_shape_against_the_fixture():
+    """BASELINE configs[3] at its own shape through the sweep runner (plot_errorVSsnr.m:48-51,170: N=64, M=4096, two SNR points x
+    16 realisations, both solvers, two-output calls, NMSE by the library's spectral-norm kernel): per-trial values against the
+    float64 fixture, and the merged call (trials of both points in one solver call) against one call per point."""
+    import torch
+    from jstsp19_amd.montecarlo import run_sweep
+    from jstsp19_amd.system_model import SweepParams
+    fx = fixture()
+    base = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8)
+    snrs, nt = [-15, -12], 16                                # sweep indices 0 and 1 of the fixture
+    s1, s2 = [], []
+    mean = run_sweep(base, snrs, nt, Imax=IMAX, batch=nt, samples=s1)
+    per_point = run_sweep(base, snrs, nt, Imax=IMAX, batch=nt, samples=s2, merge=False)
+    torch.cuda.synchronize()
+    assert mean.shape == (2, 2) and torch.equal(mean, per_point)          # what else is in the batch does not change a trial
+    for pt in range(2):
+        assert torch.equal(s1[pt], s2[pt])
+        m = (fx["sweep_proposed/sweep_idx"] == pt) & (fx["sweep_proposed/trial"] < nt)
+        ref = fx["sweep_proposed/nmse_port"][m]
+        assert np.array_equal(fx["sweep_proposed/trial"][m], np.arange(nt)) and fx["sweep_proposed/snr_db"][m][0] == snrs[pt]
+        assert np.abs(s1[pt][:, 0].numpy() - ref).max() < TOL, (pt, float(np.abs(s1[pt][:, 0].numpy() - ref).max()))
+        assert abs(float(mean[pt, 0]) - ref.mean()) < TOL
+    ma = (fx["sweep_angles/sweep_idx"] == 0) & (fx["sweep_angles/trial"] < nt)
+    assert np.abs(s1[0][:, 1].numpy() - fx["sweep_angles/nmse_port"][ma]).max() < TOL
