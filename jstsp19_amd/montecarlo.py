@@ -14,8 +14,7 @@ from __future__ import annotations
 
 import torch
 
-from .system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, build_trials,
-                           build_trials_training, draw_trials, draw_trials_training)
+from .system_model import SweepParams, TrainingParams, build_trials, build_trials_training
 
 __all__ = ["partition", "run_sweep", "run_points", "sweep_points", "run_approx_sweep", "driver", "run_driver",
            "admmiters_points", "run_convergence_curves", "zy_points", "run_zy"]
@@ -199,6 +198,15 @@ def _hip_solvers(device, metric="nmse"):
     return solve
 
 
+def _resolve_builder(builder):
+    """None / "hip": the library's own input kernels; otherwise a callable hook (see ``run_points``)."""
+    if builder is None or builder == "hip":
+        return "hip"
+    if not callable(builder):
+        raise ValueError("builder must be None, 'hip' or a callable (p, trial_ids, seed, sweep_idx, device, with_hbf) -> inputs")
+    return builder
+
+
 def _merge_key(p):
     """Sweep points whose trials may share one solver call: same array shapes and the same trial-independent A (the
     SNR, the number of paths and the rho rule only enter the per-trial arrays, which are built per point)."""
@@ -240,9 +248,10 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
     ``baselines=True`` adds the LS and VAMP columns of plot_errorVSsnr.m:83-105 (HIP path only; VAMP is NaN
     where the delay factor's order L*Gt exceeds ``vamp_max_order`` - 128 by default: above that every trial costs one
     block-Jacobi eigen-decomposition of that order, csrc/eig_large.hip).  ``dist``: ``torch.distributed`` (initialised) or None.
-    ``builder``: "hip" — inputs from the library's own kernels (``jstsp_build_trials_c32``; the default with
-    the HIP solvers) or "torch" — the tensor-op builder (the default with a custom ``solve_fn``, runs on CPU too).
-    The two use different generators, so their curves agree statistically, not sample by sample.
+    ``builder``: None / "hip" — inputs from the library's own kernels (``jstsp_build_trials_c32``) — or a callable
+    ``builder(p, trial_ids, seed, sweep_idx, device, with_hbf) -> inputs`` (the CPU-side tests pass the torch tensor-op
+    builder of tests/torch_builder.py, which runs without a GPU; it has its own random streams, so its curves agree with
+    the library builder's statistically, not sample by sample).
     ``samples``: a list that receives, per sweep point, a float64 tensor (trials of THIS rank, ncol) of the per-trial values
     before averaging (what plot_errorVSsnr.m:138-141 computes per realisation) - for distributional checks.
     Returns a float64 tensor (len(points), ncol) identical on every rank.
@@ -251,10 +260,7 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
     world = dist.get_world_size() if dist is not None else 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    if builder is None:
-        builder = "hip" if solve_fn is None else "torch"
-    if builder not in ("hip", "torch"):
-        raise ValueError("builder must be 'hip' or 'torch'")
+    builder = _resolve_builder(builder)
     if metric not in ("nmse", "rate"):
         raise ValueError("metric must be 'nmse' or 'rate'")
     custom = solve_fn is not None
@@ -283,8 +289,7 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
             if builder == "hip":
                 inps.append(build_trials(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device, with_hbf=baselines))
             else:
-                draws = draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device)
-                inps.append(build_inputs(p, draws, with_hbf=baselines))
+                inps.append(builder(p, range(t0, t1), seed, pt, device, baselines))
             chunks.append((pt, t1 - t0))
             total += t1 - t0
             item += t1 - t0
@@ -341,15 +346,14 @@ def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, 
     Returns a float64 tensor (len(Imax_list), len(snr_db_list), 2) — ``[..., 0]`` is mean_error_proposed,
     ``[..., 1]`` mean_error_proposed_approx — identical on every rank.  ``solve_fn(inputs, Imax) -> (e_std, e_approx)``
     defaults to the HIP path; the (sweep point, trial) pairs are sharded over ranks as in ``run_points``.
-    ``builder``: "hip" - the inputs from the library's own kernels (``jstsp_build_trials_c32`` with the training model
-    fields; the default with the HIP solvers) or "torch" - the tensor-op builder (default with a custom ``solve_fn``).
+    ``builder``: None / "hip" - the inputs from the library's own kernels (``jstsp_build_trials_c32`` with the training model
+    fields) - or a callable hook as in ``run_points``.
     """
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    if builder is None:
-        builder = "hip" if solve_fn is None else "torch"
+    builder = _resolve_builder(builder)
     if solve_fn is None:
         solve_fn = _hip_alg12
     pts = [(si, ii) for si in range(len(snr_db_list)) for ii in range(len(Imax_list))]    # loop order of :34-38
@@ -365,7 +369,7 @@ def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, 
         if builder == "hip":
             inp = build_trials_training(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device)
         else:
-            inp = build_inputs_training(p, draw_trials_training(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device))
+            inp = builder(p, range(t0, t1), seed, pt, device, False)
         e1, e2 = solve_fn(inp, int(Imax_list[ii]))
         acc[pt, 0] += float(torch.as_tensor(e1).double().sum())
         acc[pt, 1] += float(torch.as_tensor(e2).double().sum())
@@ -395,7 +399,7 @@ def _generic_sharded(points, n_trials, width, work, *, batch, seed, device, dist
         if builder == "hip":
             inp = build_trials(p, t0, t1 - t0, seed=seed, sweep_idx=pt, device=device)
         else:
-            inp = build_inputs(p, draw_trials(p, list(range(t0, t1)), seed=seed, sweep_idx=pt, device=device))
+            inp = builder(p, range(t0, t1), seed, pt, device, False)
         rows = torch.as_tensor(work(inp, p)).double().reshape(t1 - t0, width).cpu()
         acc[pt, :width] += rows.sum(dim=0)
         acc[pt, width] += t1 - t0
@@ -425,8 +429,7 @@ def run_convergence_curves(points, n_trials=20, *, Imax=100, batch=20, seed=2019
     """
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    if builder is None:
-        builder = "hip" if solve_fn is None else "torch"
+    builder = _resolve_builder(builder)
 
     def hip(inp, Imax_):
         from . import solvers as J
@@ -461,8 +464,7 @@ def run_zy(points=None, n_trials=1, *, Imax=50, batch=32, seed=20190913, device=
         points = zy_points()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    if builder is None:
-        builder = "hip" if solve_fn is None else "torch"
+    builder = _resolve_builder(builder)
 
     def hip(inp, Imax_):
         from . import solvers as J

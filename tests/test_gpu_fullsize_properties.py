@@ -67,7 +67,8 @@ def test_proposed_full_size_invariants_and_oracle_sample():
     for _angles, batched == single, and 2 trials against the float64 oracle to |dNMSE| <= 1e-6."""
     import torch
     import jstsp19_amd as J
-    from jstsp19_amd.system_model import SweepParams, build_inputs, draw_trials
+    from jstsp19_amd.system_model import SweepParams
+    from torch_builder import build_inputs, draw_trials
     from oracle import solvers as O
     p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=5.0)
     inp = build_inputs(p, draw_trials(p, [1000, 1001, 1002, 1003], device="cuda"))

@@ -175,7 +175,8 @@ def test_alg1_vs_alg2_sweep_on_library_built_inputs():
     from jstsp19_amd.system_model import TrainingParams
     base = TrainingParams(Nt=4, Nr=32, L=4, T=70, ratio=0.75)
     a = run_approx_sweep(base, [0.0, 10.0], [20], 48, batch=48)
-    b = run_approx_sweep(base, [0.0, 10.0], [20], 48, batch=48, builder="torch")
+    from torch_builder import builder as torch_builder
+    b = run_approx_sweep(base, [0.0, 10.0], [20], 48, batch=48, builder=torch_builder)
     assert a.shape == (1, 2, 2) and torch.isfinite(a).all()
     assert float((a - b).abs().max()) < 0.35 * float(b.max())
     assert float(a[0, 1, 0]) < float(a[0, 0, 0])                # higher SNR, lower error (Alg. 1)

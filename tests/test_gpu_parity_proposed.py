@@ -204,8 +204,9 @@ def test_alg1_vs_alg2_sweep_on_hip_matches_oracle_per_point():
     from tests.test_system_model import _oracle_alg12
     base = TrainingParams()
     dev = torch.device("cuda:0")
-    hip = run_approx_sweep(base, [-15, 0, 15], [10, 50], 4, batch=4, device=dev, builder="torch").numpy()
-    ref = run_approx_sweep(base, [-15, 0, 15], [10, 50], 4, batch=4, device=dev, solve_fn=_oracle_alg12).numpy()
+    from torch_builder import builder as torch_builder
+    hip = run_approx_sweep(base, [-15, 0, 15], [10, 50], 4, batch=4, device=dev, builder=torch_builder).numpy()
+    ref = run_approx_sweep(base, [-15, 0, 15], [10, 50], 4, batch=4, device=dev, solve_fn=_oracle_alg12, builder=torch_builder).numpy()
     assert hip.shape == (2, 3, 2) and np.all(hip > 0) and np.all(hip <= 1)
     np.testing.assert_allclose(hip, ref, rtol=2e-4, atol=1e-6)
     assert np.all(hip[:, 2, :] < hip[:, 0, :])                              # the NMSE falls with the SNR

@@ -36,6 +36,15 @@ def _oracle_solve(inp, Imax):
     return torch.tensor(e), torch.tensor(ea)
 
 
+def _torch_builder():
+    """The CPU-side input builder (tests/torch_builder.py) as the sweep runner's hook."""
+    tdir = os.path.join(ROOT, "tests")
+    if tdir not in sys.path:
+        sys.path.insert(0, tdir)
+    from torch_builder import builder
+    return builder
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -47,7 +56,7 @@ def _worker(rank, world, port, q):
     torch.set_num_threads(2)
     p = SweepParams(Nt=2, Nr=8, L=2, T=4, Mr=3)
     out = run_sweep(p, [-5.0, 5.0, 15.0], 5, Imax=15, batch=2, device=torch.device("cpu"),
-                    solve_fn=_oracle_solve, dist=dist)
+                    solve_fn=_oracle_solve, dist=dist, builder=_torch_builder())
     q.put((rank, out.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -64,7 +73,7 @@ def _worker_approx(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     out = run_approx_sweep(TrainingParams(Nt=2, Nr=8, L=2, T=12), [0.0, 10.0], [5, 10], 3, batch=2,
-                           device=torch.device("cpu"), solve_fn=_oracle_alg12, dist=dist)
+                           device=torch.device("cpu"), solve_fn=_oracle_alg12, dist=dist, builder=_torch_builder())
     q.put((rank, out.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -87,7 +96,7 @@ def test_two_rank_gloo_sweep_equals_single_process():
     from jstsp19_amd.system_model import SweepParams
     p = SweepParams(Nt=2, Nr=8, L=2, T=4, Mr=3)
     single = run_sweep(p, [-5.0, 5.0, 15.0], 5, Imax=15, batch=2, device=torch.device("cpu"),
-                       solve_fn=_oracle_solve, dist=None).numpy()
+                       solve_fn=_oracle_solve, dist=None, builder=_torch_builder()).numpy()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -109,7 +118,7 @@ def test_two_rank_gloo_alg1_vs_alg2_sweep_equals_single_process():
     from jstsp19_amd.system_model import TrainingParams
     from tests.test_system_model import _oracle_alg12
     single = run_approx_sweep(TrainingParams(Nt=2, Nr=8, L=2, T=12), [0.0, 10.0], [5, 10], 3, batch=2,
-                              device=torch.device("cpu"), solve_fn=_oracle_alg12).numpy()
+                              device=torch.device("cpu"), solve_fn=_oracle_alg12, builder=_torch_builder()).numpy()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

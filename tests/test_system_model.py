@@ -1,11 +1,18 @@
-"""Product-side batched input builder (torch) vs the oracle's per-trial literal restatement of
-plot_errorVSsnr.m:57-136, on the same random draws.  Runs on CPU."""
+"""The torch tensor-op input builder (tests/torch_builder.py: test infrastructure since round 4 - the product builds its
+trials with the library's own kernels) vs the oracle's per-trial literal restatement of plot_errorVSsnr.m:57-136, on the
+same random draws; and the sweep runners of jstsp19_amd.montecarlo on the CPU with that builder and the float64 oracle as
+hooks.  Runs on CPU."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from jstsp19_amd.system_model import (SweepParams, TrainingParams, build_inputs, build_inputs_training, draw_trials,
-                                       draw_trials_training)
+from jstsp19_amd.system_model import SweepParams, TrainingParams
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))      # (also when imported as tests.test_system_model by a spawned worker)
+from torch_builder import build_inputs, build_inputs_training, builder as torch_builder, draw_trials, draw_trials_training
 from oracle import system_model as osm
 
 
@@ -156,7 +163,7 @@ def test_alg1_vs_alg2_sweep_runner_with_oracle_solver():
     from jstsp19_amd.montecarlo import run_approx_sweep
     base = TrainingParams(Nt=2, Nr=8, L=2, T=20, ratio=0.75)
     out = run_approx_sweep(base, [-10.0, 10.0], [5, 20], 3, batch=2, device=torch.device("cpu"),
-                           solve_fn=_oracle_alg12).numpy()
+                           solve_fn=_oracle_alg12, builder=torch_builder).numpy()
     assert out.shape == (2, 2, 2) and np.all(out > 0) and np.all(out <= 1)
     assert np.all(out[:, 1, :] < out[:, 0, :])
     assert np.all(np.abs(out[1, :, 0] - out[1, :, 1]) < 0.5 * out[1, :, 0] + 1e-3)
@@ -242,14 +249,14 @@ def test_convergence_curve_and_zy_runners_with_oracle_solver():
     """plot_errorVSadmmiters.m:32-71 and plot_errorVSzy.m:28-84 on CPU with the oracle as the solver hook."""
     from jstsp19_amd.montecarlo import run_convergence_curves, run_zy
     pts = [SweepParams(Nt=2, Nr=8, L=2, T=12, Mr=4, snr_db=15.0, beamformer="ps", T_prop=12)]
-    cur = run_convergence_curves(pts, 3, Imax=12, batch=2, device=torch.device("cpu"), solve_fn=_oracle_curves).numpy()
+    cur = run_convergence_curves(pts, 3, Imax=12, batch=2, device=torch.device("cpu"), solve_fn=_oracle_curves, builder=torch_builder).numpy()
     assert cur.shape == (1, 2, 12, 3) and np.all(cur >= 0)
     assert np.all(np.isinf(cur[:, :, 0, 2])) and np.all(np.isfinite(cur[:, :, 1:, :]))   # C = 0 before iteration 1: x/0
     assert cur[0, 0, -1, 0] < cur[0, 0, 0, 0]                    # epsilon_1 falls over the iterations
-    one = run_convergence_curves(pts, 1, Imax=12, batch=1, device=torch.device("cpu"), solve_fn=_oracle_curves).numpy()
+    one = run_convergence_curves(pts, 1, Imax=12, batch=1, device=torch.device("cpu"), solve_fn=_oracle_curves, builder=torch_builder).numpy()
     inp = build_inputs(pts[0], draw_trials(pts[0], [0], device="cpu"))
     np.testing.assert_allclose(one[0, 0], _oracle_curves(inp, 12)[0][0].numpy(), rtol=1e-12)
-    zy = run_zy([pts[0].replace(rho_scale=0.5)], 3, Imax=10, batch=2, device=torch.device("cpu"), solve_fn=_oracle_zy).numpy()
+    zy = run_zy([pts[0].replace(rho_scale=0.5)], 3, Imax=10, batch=2, device=torch.device("cpu"), solve_fn=_oracle_zy, builder=torch_builder).numpy()
     assert zy.shape == (1, 2) and np.all(zy > 0) and np.all(zy <= 1)
 
 
@@ -261,5 +268,5 @@ def test_published_admmiters_panel_has_the_oracles_decay_shape():
     pub = admmiters_published()
     pts = admmiters_panel_points(pub)
     assert (pts[1].Nt, pts[1].Mr, pts[2].snr_db, pts[3].Mr) == (8, 24, 15.0, 19)
-    cur = run_convergence_curves(pts[:1], 8, Imax=70, batch=8, device=torch.device("cpu"), solve_fn=_oracle_curves).numpy()
+    cur = run_convergence_curves(pts[:1], 8, Imax=70, batch=8, device=torch.device("cpu"), solve_fn=_oracle_curves, builder=torch_builder).numpy()
     check_admmiters_shape(cur, pub, [0])

@@ -35,7 +35,9 @@ def main():
     ap.add_argument("--snr-db", type=float, default=5.0)
     ap.add_argument("--threads", type=int, default=8)
     a = ap.parse_args()
-    from jstsp19_amd.system_model import SweepParams, build_inputs, draw_trials
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from jstsp19_amd.system_model import SweepParams
+    from torch_builder import build_inputs, draw_trials
     from oracle import build_cpu_port as bp
     from oracle import solvers as O
     lib = bp.load()

@@ -11,7 +11,7 @@ from jstsp19_amd.system_model import SweepParams
 ap = argparse.ArgumentParser()
 ap.add_argument("--trials", type=int, default=64)
 ap.add_argument("--batch", type=int, default=64)
-ap.add_argument("--builder", default="hip", choices=["hip", "torch"])
+ap.add_argument("--builder", default="hip", choices=["hip"], help="(the torch tensor-op builder moved to tests/torch_builder.py)")
 ap.add_argument("--rate", action="store_true", help="rate metric of plot_rateVSframelength.m instead of the NMSE")
 ap.add_argument("--tssr", action="store_true", help="add the TSSR recipe (mc_svt with rho = 0.1, then joint OMP)")
 ap.add_argument("--vamp-large", action="store_true", help="VAMP column also where L*Gt > 128 (one order-L*Gt eigen-decomposition per trial)")
