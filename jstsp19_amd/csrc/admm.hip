@@ -319,38 +319,6 @@ int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const flo
     JSTSP_HIP(hipGetLastError());
     return 0;
 }
-__global__ __launch_bounds__(256) void add_kernel(long long n4, float4 *Y, const float4 *X)
-{
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        float4 y = Y[i];
-        const float4 x = X[i];
-        y.x += x.x; y.y += x.y; y.z += x.z; y.w += x.w;
-        Y[i] = y;
-    }
-}
-__global__ __launch_bounds__(256) void add2_kernel(long long n, float2 *Y, const float2 *X)
-{
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float2 y = Y[i];
-        const float2 x = X[i];
-        y.x += x.x; y.y += x.y;
-        Y[i] = y;
-    }
-}
-int launch_add(jstsp_ctx *ctx, long long n_total, float2 *Y, const float2 *X)
-{
-    if ((n_total & 1) || ((((uintptr_t)Y | (uintptr_t)X) & 15) != 0)) {       // ragged shapes: 8-byte accesses
-        hipLaunchKernelGGL(add2_kernel, dim3((unsigned)std::min<long long>((n_total + 255) / 256, 8192)), dim3(256), 0, ctx->stream,
-                           n_total, Y, X);
-        JSTSP_HIP(hipGetLastError());
-        return 0;
-    }
-    const long long n4 = n_total / 2;
-    hipLaunchKernelGGL(add_kernel, dim3((unsigned)std::min<long long>((n4 + 255) / 256, 8192)), dim3(256), 0, ctx->stream, n4,
-                       reinterpret_cast<float4 *>(Y), reinterpret_cast<const float4 *>(X));
-    JSTSP_HIP(hipGetLastError());
-    return 0;
-}
 int launch_soft(jstsp_ctx *ctx, int g, int batch, const float2 *V, float2 *S, const int32_t *rank,
                 int cnt, const TrialParams *prm)
 {

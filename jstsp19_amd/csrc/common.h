@@ -284,8 +284,6 @@ int launch_inv_d(jstsp_ctx *ctx, long long nm, int batch, const float *Omega, fl
                  const TrialParams *prm, float *invD);
 int launch_rank_from_index(jstsp_ctx *ctx, int g, int batch, const int32_t *indx, int32_t *rank);
 int launch_eye_minus(jstsp_ctx *ctx, int n, int count, const float2 *Q, float2 *P);
-// Y[t] += X[t]  (n complex elements per problem, contiguous over the batch)
-int launch_add(jstsp_ctx *ctx, long long n_total, float2 *Y, const float2 *X);
 int launch_ce_ratio(jstsp_ctx *ctx, int batch, const float *lamV1, const float *lamV2,
                     const float *lamX, double *ce, int Imax, int it);
 
