@@ -99,6 +99,8 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *   JSTSP_OVERLAP=0|1     side streams between the kernels of an iteration (default: on with the one-pass kernel)
  *   JSTSP_SVT_SKIP=1      opt-in: a trial whose svt threshold is below 2^-27 max|Z| skips its eigen-decomposition (Y = Z is
  *                         then the fp32 answer); never used for a reported number
+ *   JSTSP_HOST_PIPELINE=0 a JSTSP_HOST proposed_algorithm call of 128 or more problems as ONE staged solve (default: its two halves on
+ *                         two internal contexts, the upload of the second overlapping the solve of the first)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_EIG128=0        general Jacobi kernel (basis in HBM) for Gram orders 65..128
  *   JSTSP_OMP_GRAM=0      jstsp_omp_kron: measurement-space OMP instead of the coefficient-domain kernel

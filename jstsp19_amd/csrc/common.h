@@ -75,6 +75,7 @@ struct Tuning {
                             // f16 pipe in one launch (hsmall.hip) instead of fp32-MFMA products; measured: more accurate products,
                             // +2 % channel-estimates/s, but WORSE parity (rms |dNMSE| 2.18e-7 against 1.73e-7, a +5e-8 bias): off
     int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
+    int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
     int bj_trace = 0;       // JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
 };
@@ -141,6 +142,7 @@ struct jstsp_ctx {
     uint32_t *diag = nullptr;
     int last_dict_block = 0;     // block height of the block-Toeplitz structure the last fused solve found in its dictionary (0: none)
     int fused_fallbacks = 0;     // trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass
+    jstsp_ctx *helper = nullptr; // second context of the same device (own stream, own workspace): the other half of a pipelined JSTSP_HOST solve (proposed.hip)
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };

@@ -130,6 +130,25 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
 
 using namespace jstsp;
 
+// A JSTSP_HOST solve whose device work has been enqueued but whose results are still in the context's workspace: the halves of
+// a pipelined host call (jstsp_proposed_algorithm_c32 below).  proposed_finish copies them out, reads the overflow flags and
+// re-solves flagged trials.
+static bool tune_host_pipeline()
+{
+    load_tuning();
+    return tune().host_pipeline != 0;
+}
+
+struct PendingSolve {
+    bool active = false, fused = false, want_ce = false;
+    int batch = 0;
+    size_t g = 0, nm = 0;
+    int Imax = 0;
+    const float2 *dS = nullptr, *dY = nullptr;
+    const double *dce = nullptr;
+    const uint32_t *ovf = nullptr;
+};
+
 // One batched solve.  allow_fused = false: never the fused pass (the re-solve of trials whose predicted k scale
 // overflowed in it).  overflowed != NULL: receives the indices of such trials (their outputs are not to be used); reading
 // the per-trial flags costs ONE stream synchronisation at the end of a solve that used the fused pass.
@@ -139,7 +158,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
                          long long strideB, int Imax, const double *tau_Y,
                          const double *tau_S, const double *rho, int type,
                          const int32_t *indx_S_, jstsp_c32 *S_out, jstsp_c32 *Y_out,
-                         double *ce_out, int memspace, bool allow_fused, std::vector<int> *overflowed)
+                         double *ce_out, int memspace, bool allow_fused, std::vector<int> *overflowed, PendingSolve *defer = nullptr)
 {
     JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
     JSTSP_REQUIRE(subY_ && Omega_ && A_ && B_ && tau_Y && tau_S && rho && S_out, JSTSP_E_NULL,
@@ -670,6 +689,11 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         }
     }
     if (want_ce && Imax > 0) JSTSP_HIP(hipStreamWaitEvent(sm, ev_ce, 0));
+    if (defer) {        // results stay in the workspace; copies, flags and recovery happen in proposed_finish
+        defer->active = true; defer->fused = fusedp; defer->want_ce = want_ce && Imax > 0; defer->batch = batch; defer->g = g; defer->nm = nm;
+        defer->Imax = Imax; defer->dS = w.S; defer->dY = w.Y; defer->dce = w.ce; defer->ovf = fusedp ? fw.ovf : nullptr;
+        return 0;
+    }
 
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), w.S, batch * g, memspace));
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), w.Y, batch * nm, memspace));
@@ -690,6 +714,44 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     return 0;
 }
 
+// Recovery: runs of consecutive flagged trials are solved again by the three-kernel iteration (every operand scale
+// there is the exact maximum of data that already exists: it cannot overflow), straight into the caller's arrays -
+// per-trial arrays are contiguous with the trial index slowest, so a sub-batch is a pointer offset in either memspace.
+static int resolve_overflowed(jstsp_ctx *ctx, const std::vector<int> &ovf, int N, int M, int Gr, int G2, const jstsp_c32 *subY,
+                              const float *Omega, const jstsp_c32 *A, long long strideA, const jstsp_c32 *B, long long strideB,
+                              int Imax, const double *tau_Y, const double *tau_S, const double *rho, int type,
+                              const int32_t *indx_S, jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out, int memspace, int *count)
+{
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2;
+    for (size_t i = 0; i < ovf.size();) {
+        size_t j = i + 1;
+        while (j < ovf.size() && ovf[j] == ovf[j - 1] + 1) ++j;
+        const int t0 = ovf[i], cnt = (int)(j - i);
+        JSTSP_TRY(proposed_impl(ctx, N, M, Gr, G2, cnt, subY + t0 * nm, Omega + t0 * nm, A + (size_t)t0 * strideA, strideA,
+                                B + (size_t)t0 * strideB, strideB, Imax, tau_Y + t0, tau_S + t0, rho + t0, type,
+                                indx_S ? indx_S + t0 * g : nullptr, S_out + t0 * g, Y_out ? Y_out + t0 * nm : nullptr,
+                                ce_out ? ce_out + (size_t)t0 * 3 * Imax : nullptr, memspace, false, nullptr));
+        *count += cnt;
+        i = j;
+    }
+    return 0;
+}
+
+// Second phase of a deferred JSTSP_HOST solve: device -> host copies of the outputs, the overflow flags, one synchronisation.
+static int proposed_finish(jstsp_ctx *ctx, const PendingSolve &p, jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out, std::vector<int> *ovf)
+{
+    JSTSP_ENTER(ctx);
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), p.dS, p.batch * p.g, JSTSP_HOST));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), p.dY, p.batch * p.nm, JSTSP_HOST));
+    if (p.want_ce) JSTSP_TRY(stage_out(ctx, ce_out, p.dce, (size_t)p.batch * 3 * p.Imax, JSTSP_HOST));
+    std::vector<uint32_t> flags(p.ovf ? p.batch : 0);
+    if (p.ovf) JSTSP_HIP(hipMemcpyAsync(flags.data(), p.ovf, (size_t)p.batch * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < (int)flags.size(); ++t)
+        if (flags[t]) ovf->push_back(t);
+    return 0;
+}
+
 extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
                                             const jstsp_c32 *subY, const float *Omega,
                                             const jstsp_c32 *A, long long strideA, const jstsp_c32 *B,
@@ -700,23 +762,47 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
 {
     std::vector<int> ovf;
     if (ctx) { ctx->fused_fallbacks = 0; ctx->last_dict_block = 0; }
+    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2;
+    // JSTSP_HOST with a large batch: the two halves of the batch on two contexts of the device, so that the upload of the second
+    // half (4.75 GiB per 256 trials at BASELINE configs[1], 57 GB/s) runs while the first half is being solved, and the download
+    // of the first half while the second is.  A trial's result does not depend on what else is in its batch (tests), so the
+    // outputs are those of the one-call form.  Measured at configs[1] (tools/host_path_rate.py): 256 trials 544 -> 594
+    // channel-estimates/s, 128 trials 514 -> 540, 64 trials 466 -> 391 (a 32-trial solve no longer fills the chip): from 128 on.
+    const size_t in_bytes = (size_t)batch * (nm * 12 + (strideB ? (size_t)G2 * M * 8 : 0));
+    const bool pipeline = ctx && memspace == JSTSP_HOST && type == JSTSP_TYPE_APPROXIMATE && batch >= 128 && Imax > 1 && Y_out &&
+                          in_bytes >= ((size_t)256 << 20) && subY && Omega && A && B && tau_Y && tau_S && rho && S_out &&
+                          tune_host_pipeline();
+    if (pipeline) {
+        if (!ctx->helper) JSTSP_TRY(jstsp_create(ctx->device, &ctx->helper));
+        jstsp_ctx *cx[2] = {ctx, ctx->helper};
+        const int h = ((batch / 2 + 7) / 8) * 8, cnt[2] = {h, batch - h}, t0[2] = {0, h};
+        PendingSolve pend[2];
+        for (int k = 0; k < 2; ++k) {
+            cx[k]->fused_fallbacks = 0; cx[k]->last_dict_block = 0;
+            JSTSP_TRY(proposed_impl(cx[k], N, M, Gr, G2, cnt[k], subY + t0[k] * nm, Omega + t0[k] * nm, A + (size_t)t0[k] * strideA, strideA,
+                                    B + (size_t)t0[k] * strideB, strideB, Imax, tau_Y + t0[k], tau_S + t0[k], rho + t0[k], type,
+                                    indx_S ? indx_S + t0[k] * g : nullptr, S_out + t0[k] * g, Y_out + t0[k] * nm,
+                                    ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, JSTSP_HOST, true, nullptr, &pend[k]));
+        }
+        int fallbacks = 0;
+        for (int k = 0; k < 2; ++k) {
+            std::vector<int> o;
+            JSTSP_TRY(proposed_finish(cx[k], pend[k], S_out + t0[k] * g, Y_out + t0[k] * nm, ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, &o));
+            JSTSP_TRY(resolve_overflowed(cx[k], o, N, M, Gr, G2, subY + t0[k] * nm, Omega + t0[k] * nm, A + (size_t)t0[k] * strideA, strideA,
+                                         B + (size_t)t0[k] * strideB, strideB, Imax, tau_Y + t0[k], tau_S + t0[k], rho + t0[k], type,
+                                         indx_S ? indx_S + t0[k] * g : nullptr, S_out + t0[k] * g, Y_out + t0[k] * nm,
+                                         ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, JSTSP_HOST, &fallbacks));
+        }
+        ctx->fused_fallbacks = fallbacks;
+        ctx->last_dict_block = (cx[0]->last_dict_block == cx[1]->last_dict_block) ? cx[0]->last_dict_block : 0;
+        return 0;
+    }
     JSTSP_TRY(proposed_impl(ctx, N, M, Gr, G2, batch, subY, Omega, A, strideA, B, strideB, Imax, tau_Y, tau_S, rho, type,
                             indx_S, S_out, Y_out, ce_out, memspace, true, &ovf));
-    // Recovery: runs of consecutive flagged trials are solved again by the three-kernel iteration (every operand scale
-    // there is the exact maximum of data that already exists: it cannot overflow), straight into the caller's arrays -
-    // per-trial arrays are contiguous with the trial index slowest, so a sub-batch is a pointer offset in either memspace.
-    const size_t nm = (size_t)N * M, g = (size_t)Gr * G2;
-    for (size_t i = 0; i < ovf.size();) {
-        size_t j = i + 1;
-        while (j < ovf.size() && ovf[j] == ovf[j - 1] + 1) ++j;
-        const int t0 = ovf[i], cnt = (int)(j - i);
-        JSTSP_TRY(proposed_impl(ctx, N, M, Gr, G2, cnt, subY + t0 * nm, Omega + t0 * nm, A + (size_t)t0 * strideA, strideA,
-                                B + (size_t)t0 * strideB, strideB, Imax, tau_Y + t0, tau_S + t0, rho + t0, type,
-                                indx_S ? indx_S + t0 * g : nullptr, S_out + t0 * g, Y_out ? Y_out + t0 * nm : nullptr,
-                                ce_out ? ce_out + (size_t)t0 * 3 * Imax : nullptr, memspace, false, nullptr));
-        ctx->fused_fallbacks += cnt;
-        i = j;
-    }
+    int fallbacks = 0;
+    JSTSP_TRY(resolve_overflowed(ctx, ovf, N, M, Gr, G2, subY, Omega, A, strideA, B, strideB, Imax, tau_Y, tau_S, rho, type, indx_S, S_out,
+                                 Y_out, ce_out, memspace, &fallbacks));
+    ctx->fused_fallbacks += fallbacks;
     return 0;
 }
 

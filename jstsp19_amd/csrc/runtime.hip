@@ -36,6 +36,7 @@ void load_tuning()
     t.omp_gram = env_int("JSTSP_OMP_GRAM", t.omp_gram);
     t.bj_trace = env_int("JSTSP_BJ_TRACE", t.bj_trace);
     t.gram_refine = env_int("JSTSP_GRAM_REFINE", t.gram_refine);
+    t.host_pipeline = env_int("JSTSP_HOST_PIPELINE", t.host_pipeline);
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     g_tune = t;
@@ -448,6 +449,7 @@ int jstsp_create(int device_id, jstsp_ctx **out)
 int jstsp_destroy(jstsp_ctx *ctx)
 {
     if (!ctx) return 0;
+    if (ctx->helper) { (void)jstsp_destroy(ctx->helper); ctx->helper = nullptr; }
     DeviceScope dev_scope_(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     prof_collect(ctx);

@@ -111,3 +111,39 @@ def test_one_trial_whose_k_jumps_is_re_solved_alone_and_matches_the_oracle():
     # two outputs only (no three-Gram pass): same recovery
     (S3, _, _), n3 = _solve(inp, IM, Omega=Om, want_ce=False)
     assert n3 == 1 and _rel(S3, S1) < 1e-5
+
+
+def test_pipelined_host_call_equals_the_staged_one_and_recovers_per_half():
+    """A JSTSP_HOST call of >= 128 problems runs as two halves on two internal contexts (proposed.hip): bit for bit the outputs of
+    the single staged call, also when trials in BOTH halves overflow their predicted scale and are solved again."""
+    import os
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=5.0)
+    inp = build_trials(p, 0, 128, seed=11)
+    h = {k: inp[k].cpu().numpy() for k in ("subY", "Omega", "B")}
+    A = inp["A"].cpu().numpy()
+    hyp = [inp[k].numpy() for k in ("tau_Y", "tau_Z", "rho")]
+
+    def run(env, Imax=12):
+        os.environ.update(env)
+        try:
+            r = J.proposed_algorithm(h["subY"], h["Omega"], A, h["B"], Imax, *hyp, "approximate")
+            n = J.default_context(0).last_fused_fallbacks()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return [np.asarray(x) for x in r], n
+
+    one, n1 = run({"JSTSP_HOST_PIPELINE": "0"})
+    two, n2 = run({})
+    assert n1 == 0 and n2 == 0
+    for a, b in zip(one, two):
+        assert a.tobytes() == b.tobytes()
+    # every trial forced through the recovery: both halves re-solve theirs with the three-kernel iteration
+    ref, _ = run({"JSTSP_FUSED": "0", "JSTSP_HOST_PIPELINE": "0"})
+    rec, nrec = run({"JSTSP_FUSED_KBACK": "-20"})
+    assert nrec == 128
+    for a, b in zip(ref, rec):
+        assert a.tobytes() == b.tobytes()
