@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     const int tm = rem % tiles_m;
     const int tn = rem / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
+    if (d.herm_upper && n0 + BN <= m0) return;          // entirely below the diagonal: mirrored by the caller
 
     const int kchunk = ((d.k + d.splitk - 1) / d.splitk + BK - 1) / BK * BK;
     const int kbeg = split * kchunk;

@@ -179,6 +179,8 @@ struct GemmDesc {
     // it (C_lo, same layout as C; alpha = 1, no D): C + C_lo carries the product to about 1e-9 relative
     int force_m64;
     float2 *C_lo;
+    int herm_upper;                         // the product is Hermitian (a Gram): tiles entirely below the diagonal are skipped, the caller
+                                            // mirrors them (hermitian_fill_lower)
 };
 // The N x M array C of the reference is never stored: with cc = rho/(rho+1), D = X - Xs,
 //   C   = cc (D - V2/rho)                       (proposed_algorithm.m:61)
