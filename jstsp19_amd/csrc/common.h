@@ -266,7 +266,8 @@ int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gp
                     float2 *Uwarm, int warm, const uint32_t *skip_amax = nullptr);
 // Orders 65..128 (eig3.hip): G in LDS, eigenvector basis in registers as a systolic array; SVT projector only.
 int launch_eig128(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
-                  const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm = nullptr, int warm = 0);
+                  const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm = nullptr, int warm = 0,
+                  int max_sweeps = 16);
 int eig_fast_ne(int n);           // padded order (32 or 64) of the warm-start basis
 int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
                 float *lam_out, bool lanczos = false);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)

@@ -261,13 +261,13 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
 // Uwarm: nullptr, or batch * n*n float2 that receives the eigenvector basis; warm != 0: Uwarm holds the basis of the
 // previous call AND the caller has already transformed the Gram to that basis (G <- Uw^H G Uw).
 int launch_eig128(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
-                  const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm, int warm)
+                  const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm, int warm, int max_sweeps)
 {
     JSTSP_REQUIRE(n > 64 && n <= 128, JSTSP_E_UNSUPPORTED, "launch_eig128: n = %d outside (64, 128]", n);
     const size_t sh = (size_t)NE * LD * sizeof(float2) + (size_t)(4 * H + 24 + NE) * sizeof(float);
     JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     const float tol = 1e-4f;
-    const int maxsw = 16;
+    const int maxsw = max_sweeps < 1 ? 1 : (max_sweeps > 16 ? 16 : max_sweeps);
     hipLaunchKernelGGL(jacobi128_kernel, dim3(batch), dim3(NT), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs, prm, tau, Q,
                        tol, maxsw, (int *)nullptr, Uwarm, warm);
     JSTSP_HIP(hipGetLastError());
