@@ -104,6 +104,7 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_EIG128=0        general Jacobi kernel (basis in HBM) for Gram orders 65..128
  *   JSTSP_OMP_GRAM=0      jstsp_omp_kron: measurement-space OMP instead of the coefficient-domain kernel
+ *   JSTSP_BJ_MASK=0       block Jacobi (orders above 128) without streams restricted to a subset of the compute units
  *   JSTSP_BJ_TRACE=1      print the block Jacobi's convergence (orders above 128) per sweep to stderr
  * (JSTSP_DEVICE=<id> is read by the MEX gateway, not by the library.) */
 

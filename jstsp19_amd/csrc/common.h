@@ -77,6 +77,7 @@ struct Tuning {
     int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
+    int bj_mask = 1;        // JSTSP_BJ_MASK: 0 the block Jacobi above order 128 without compute-unit masks (its sub-problems then compete with the panel products for units)
     int bj_trace = 0;       // JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
 };
 const Tuning &tune();       // the calling thread's setting, as parsed by the API call in progress
@@ -144,6 +145,10 @@ struct jstsp_ctx {
     int fused_fallbacks = 0;     // trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass
     jstsp_ctx *helper = nullptr; // second context of the same device (own stream, own workspace): the other half of a pipelined JSTSP_HOST solve (proposed.hip)
     hipStream_t side[2] = {nullptr, nullptr};
+    // streams with a compute-unit mask (runtime.hip: ensure_cu_streams): [0..2] everything but 32 reserved units, [3] the
+    // reserved units only - the block Jacobi's chain of sub-problems runs there beside panel products that fill the rest
+    hipStream_t cu_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    int cu_state = 0;            // 0 not tried, 1 available, -1 the runtime refused
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

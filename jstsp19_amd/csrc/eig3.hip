@@ -44,6 +44,9 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
     float *red = rot + 4 * H;                                   // [24]
     float *qv = red + 24;                                       // [NE]
     const int t = blockIdx.x, tid = threadIdx.x;
+    // (latency-bound: when the block Jacobi of eig_large.hip runs its panel products beside this kernel, their waves must not
+    //  take issue slots from it)
+    __builtin_amdgcn_s_setprio(3);
 
     for (int e = tid; e < NE * NE; e += NT) {
         const int i = e % NE, j = e / NE;
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
         if (G[i + LD * i].x != 0.f) red[2] = 1.f;
     __syncthreads();
     if (red[2] == 0.f) {
-        for (int e = tid; e < n * n; e += NT) Q[(size_t)t * n * n + e] = make_float2((e % n == e / n) ? 1.f : 0.f, 0.f);
+        if (Q) for (int e = tid; e < n * n; e += NT) Q[(size_t)t * n * n + e] = make_float2((e % n == e / n) ? 1.f : 0.f, 0.f);
         if (Uwarm && !warm)                                     // the caller treats the basis as valid from now on
             for (int e = tid; e < n * n; e += NT)
                 Uwarm[(size_t)t * n * n + e] = make_float2((e % n == e / n) ? 1.f : 0.f, 0.f);
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
     __syncthreads();
     if (Uw)                                                     // keep the basis for the next call of the sequence
         for (int e = tid; e < n * n; e += NT) Uw[e] = U[(e % n) + NE * (e / n)];
+    if (!Q) return;                                             // (basis only: the block Jacobi of eig_large.hip)
     // Q[i][j] = sum_k q_k U[i][k] conj(U[j][k]): 16 blocks of 32 x 32, one per wave; MFMA fed (A-op = conj(U_j), B-op = q U_i)
     {
         const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -258,12 +262,13 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
 }  // namespace
 
 // SVT projector Q[t] = U diag(min(1, tau_t / sigma_i)) U^H of the n x n Gram sum_s Gpart[t][s], 64 < n <= 128.
-// Uwarm: nullptr, or batch * n*n float2 that receives the eigenvector basis; warm != 0: Uwarm holds the basis of the
+// Q: nullptr = basis only (Uwarm required).  Uwarm: nullptr, or batch * n*n float2 that receives the eigenvector basis; warm != 0: Uwarm holds the basis of the
 // previous call AND the caller has already transformed the Gram to that basis (G <- Uw^H G Uw).
 int launch_eig128(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
                   const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm, int warm, int max_sweeps)
 {
     JSTSP_REQUIRE(n > 64 && n <= 128, JSTSP_E_UNSUPPORTED, "launch_eig128: n = %d outside (64, 128]", n);
+    JSTSP_REQUIRE(Q || Uwarm, JSTSP_E_ARG, "launch_eig128: neither a projector nor a basis requested");
     const size_t sh = (size_t)NE * LD * sizeof(float2) + (size_t)(4 * H + 24 + NE) * sizeof(float);
     JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     const float tol = 1e-4f;

@@ -193,14 +193,80 @@ __global__ void scale_cols_kernel(int n, const float2 *U, const float *lam, cons
     }
 }
 
+// Look-ahead of the block Jacobi (launch_eig_large): Wc = the permuted matrix of this round (pair k = rows / columns
+// 128 k .. 128 k + 127), J = this round's rotations.  After W' = J^H Wc J the next round pairs the blocks
+// (src[2 k'], src[2 k' + 1]) (block numbers of THIS round's order); block (u, v) of that pair's sub-matrix is
+//      W'[bu, bv] = J_p(:, 64 hu ..)^H  Wc[128 p .., 128 q ..]  J_q(:, 64 hv ..),     bu = 2 p + hu, bv = 2 q + hv.
+// One workgroup of 256 threads per 16 columns of a block (blockIdx.x = 8 u + 4 v + column slice): T = Wc[p, q] J_q(:, slice)
+// (128 x 16: 4 x 2 outputs per thread, operands straight from memory - the rotation entries are wave-uniform), then
+// J_p(:, half)^H T (64 x 16, 4 per thread; T from LDS, the rotation half through LDS in chunks of 16 rows).  24 KiB of LDS: the
+// kernel has to find room on compute units that the panel products of the main stream are filling.  fp32 FMA chains of 128
+// terms, like the panel products themselves.
+__global__ __launch_bounds__(256) void lookahead_kernel(int np, int m, const int *src, const float2 *W, const float2 *J, float2 *S)
+{
+    __shared__ __attribute__((aligned(16))) float2 T[128 * 16];        // T[k][c]
+    __shared__ __attribute__((aligned(16))) float2 Jc[16 * 64];        // Jc[k - k0][i] = J_p(k, 64 hu + i)
+    __builtin_amdgcn_s_setprio(3);         // (on the critical chain, beside panel products that fill the chip)
+    const int u = blockIdx.x >> 3, v = (blockIdx.x >> 2) & 1, sl = blockIdx.x & 3;
+    const int b = blockIdx.y, t = b / m, kn = b % m, tid = threadIdx.x;
+    const int bu = src[2 * kn + u], bv = src[2 * kn + v];
+    const int p = bu >> 1, hu = bu & 1, q = bv >> 1, hv = bv & 1;
+    const float2 *w = W + (size_t)t * np * np + (size_t)(128 * q) * np + 128 * p;                   // Wc[128 p + i, 128 q + j]
+    const float2 *jq = J + ((size_t)t * m + q) * 128 * 128 + (size_t)(64 * hv + 16 * sl) * 128;     // J_q(k, 64 hv + 16 sl + c) = jq[k + 128 c]
+    const float2 *jp = J + ((size_t)t * m + p) * 128 * 128 + (size_t)(64 * hu) * 128;
+    {
+        const int rg = tid & 31, cg = __builtin_amdgcn_readfirstlane(tid >> 6) * 2 + ((tid >> 5) & 1);     // rows 4 rg .., columns 2 cg ..
+        float2 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = make_float2(0.f, 0.f); acc[i][1] = make_float2(0.f, 0.f); }
+#pragma unroll 8
+        for (int k = 0; k < 128; ++k) {
+            const float4 w01 = *reinterpret_cast<const float4 *>(&w[4 * rg + (size_t)np * k]);
+            const float4 w23 = *reinterpret_cast<const float4 *>(&w[4 * rg + 2 + (size_t)np * k]);
+            const float2 a[4] = {make_float2(w01.x, w01.y), make_float2(w01.z, w01.w), make_float2(w23.x, w23.y), make_float2(w23.z, w23.w)};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float2 x = jq[k + 128 * (2 * cg + c)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][c].x = fmaf(a[i].x, x.x, fmaf(-a[i].y, x.y, acc[i][c].x));
+                    acc[i][c].y = fmaf(a[i].x, x.y, fmaf(a[i].y, x.x, acc[i][c].y));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { T[(4 * rg + i) * 16 + 2 * cg] = acc[i][0]; T[(4 * rg + i) * 16 + 2 * cg + 1] = acc[i][1]; }
+    }
+    const int i = tid & 63, jg = tid >> 6;                  // row i, columns 4 jg ..
+    float2 o[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    for (int k0 = 0; k0 < 128; k0 += 16) {
+        __syncthreads();                                    // (T complete / the previous chunk consumed)
+        for (int e = tid; e < 16 * 64; e += 256) Jc[(e & 15) * 64 + (e >> 4)] = jp[k0 + (e & 15) + 128 * (e >> 4)];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float2 a = Jc[kk * 64 + i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                   // conj(a) x
+                const float2 x = T[(k0 + kk) * 16 + 4 * jg + c];
+                o[c].x = fmaf(a.x, x.x, fmaf(a.y, x.y, o[c].x));
+                o[c].y = fmaf(a.x, x.y, fmaf(-a.y, x.x, o[c].y));
+            }
+        }
+    }
+    float2 *s = S + (size_t)b * 128 * 128;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[(64 * u + i) + 128 * (64 * v + 16 * sl + 4 * jg + c)] = o[c];
+}
+
 // stream-ordered temporaries outside the context's arena (the callers sized that for the small kernels), freed on every path
 struct Temps {
-    hipStream_t st, also = nullptr;        // `also`: a second stream that works on these buffers (drained before they are freed)
+    hipStream_t st, also[4] = {nullptr, nullptr, nullptr, nullptr};      // `also`: further streams that work on these buffers (drained before they are freed)
     std::vector<void *> p;
     explicit Temps(hipStream_t s) : st(s) {}
     ~Temps()
     {
-        if (also) (void)hipStreamSynchronize(also);
+        for (hipStream_t a : also) if (a) (void)hipStreamSynchronize(a);
         for (void *q : p) (void)hipFreeAsync(q, st);
     }
     template <class T> T *get(size_t n)
@@ -229,11 +295,11 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
     Temps tmp(st);
     float2 *W = tmp.get<float2>(batch * nn), *Wp = tmp.get<float2>(batch * nn);
     float2 *U = vecs ? tmp.get<float2>(batch * nn) : nullptr, *Up = vecs ? tmp.get<float2>(batch * nn) : nullptr;
-    float2 *S = tmp.get<float2>(cnt * sub * sub), *J = tmp.get<float2>(2 * cnt * sub * sub), *Vg = tmp.get<float2>(cnt * sub * sub);
+    float2 *S = tmp.get<float2>(cnt * sub * sub), *J = tmp.get<float2>(2 * cnt * sub * sub);
     float *lamJ = tmp.get<float>(cnt * sub), *dscale = tmp.get<float>(batch), *lam = tmp.get<float>((size_t)batch * n);
     double *stat = tmp.get<double>(2 * (size_t)batch);
     int *idx = tmp.get<int>(np), *lgd = tmp.get<int>(np);
-    JSTSP_REQUIRE(W && Wp && (!vecs || (U && Up)) && S && J && Vg && lamJ && dscale && lam && stat && idx && lgd, JSTSP_E_NOMEM,
+    JSTSP_REQUIRE(W && Wp && (!vecs || (U && Up)) && S && J && lamJ && dscale && lam && stat && idx && lgd, JSTSP_E_NOMEM,
                   "eig (order %d, %d matrices): out of device memory", n, batch);
     const dim3 grid((unsigned)std::min<size_t>((nn + 255) / 256, 4096), (unsigned)batch);
     hipLaunchKernelGGL(dscale_kernel, dim3(batch), dim3(256), 0, st, n, Gpart, sGt, nsplit, sGs, dscale);
@@ -251,9 +317,11 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
     }
     for (int i = 0; i < np; ++i) { hidx[i] = src[i / BS] * BS + i % BS; lg[i] = i; }
     JSTSP_TRY(upload(ctx, idx, hidx.data(), np * sizeof(int)));
+    int *srcd = tmp.get<int>(nb);
+    JSTSP_REQUIRE(srcd, JSTSP_E_NOMEM, "eig (order %d): out of device memory", n);
+    JSTSP_TRY(upload(ctx, srcd, src.data(), nb * sizeof(int)));
 
     const int max_sweeps = 18;
-    const bool sub_fast = true;         // the register-resident order-128 kernel for the pair sub-problems (eig3.hip)
     // ONE sweep of the scalar method inside each pair sub-problem per round: the unitary it returns is applied whatever it
     // achieved, so the outer iteration is a similarity transformation all the same - and it converges in the same number of
     // outer sweeps as with exactly solved sub-problems (order 4096: off/diag after each sweep equal to two digits, 12 sweeps
@@ -264,76 +332,104 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
     double last_worst = 0.0;
     const long long sPanel = (long long)sub * np, sSub = (long long)sub * sub;
     double prev = -1.0;
-    // The basis is not read until the iteration ends (or restarts): its update U <- U J runs on a side stream and is held back
-    // until the sub-problem kernel of the NEXT round starts - that kernel holds nb / 2 compute units only, the panel products
-    // of the main stream hold all of them.  The rotations alternate between two buffers so that a round's sub-problems never
-    // overwrite what the pending basis update reads.
-    const bool side_u = vecs && m > 1;
-    hipStream_t su = st;
-    hipEvent_t ev_j = nullptr, ev_u[2] = {nullptr, nullptr};
-    if (side_u) {
+    // Three streams (nb > 2).  The sub-problem kernel holds nb / 2 compute units only and the panel products all of them, so
+    // the chain of sub-problems is taken off the main stream:
+    //   main : permutation of W, the two panel products W <- J^H W J
+    //   sj   : sub-problems of round r, then the LOOK-AHEAD: the diagonal blocks of the NEXT round's pairs formed directly
+    //          from the (permuted) W of this round and its rotations (lookahead_kernel: 2 x 2 blocks of 64 x 64, each
+    //          J_p(:, half)^H W[p, q] J_q(:, half) - a few small products), so that the sub-problems of round r + 1 run beside
+    //          the panel products of round r
+    //   su   : the basis update U <- U J (not read until the iteration ends or restarts)
+    // The rotations alternate between two buffers: round r + 2 overwrites J[r & 1] only after the panel products (main, implied
+    // by the permutation the look-ahead waits for) and the basis update (ev_u) of round r have read it.
+    const bool piped = m > 1;
+    // With compute-unit masks (runtime.hip: ensure_cu_streams) the sub-problems own 32 units and everything else - the panel
+    // products included, which is why the "main" work leaves the caller's stream for the length of the iteration - is kept off
+    // them: a 1024-thread workgroup with 140 KiB of LDS otherwise waits for a unit that the panel products have drained by chance.
+    float2 *Tm = (np > 1024 && vecs) ? tmp.get<float2>(batch * nn) : nullptr;       // (the restart's intermediate product)
+    JSTSP_REQUIRE(!(np > 1024 && vecs) || Tm, JSTSP_E_NOMEM, "eig (order %d): out of device memory", n);
+    hipStream_t sp = st, su = st, sj = st, sl = st;
+    hipEvent_t ev_j = nullptr, ev_u[2] = {nullptr, nullptr}, ev_perm = nullptr, ev_la = nullptr, ev_io = nullptr;
+    if (piped) {
         JSTSP_TRY(ensure_side_streams(ctx));
-        su = ctx->side[0]; tmp.also = su; ev_j = ctx->ev[0]; ev_u[0] = ctx->ev[1]; ev_u[1] = ctx->ev[2];
+        // (only when the sub-problems of a round fit the reserved units one each; more of them want the whole chip)
+        if (tune().bj_mask && cnt <= 32 && ensure_cu_streams(ctx)) { sp = ctx->cu_stream[0]; su = ctx->cu_stream[1]; sl = ctx->cu_stream[2]; sj = ctx->cu_stream[3]; }
+        else { su = ctx->side[0]; sj = sl = ctx->side[1]; }
+        tmp.also[0] = su; tmp.also[1] = sj; tmp.also[2] = sl; tmp.also[3] = sp != st ? sp : nullptr;
+        ev_j = ctx->ev[0]; ev_u[0] = ctx->ev[1]; ev_u[1] = ctx->ev[2]; ev_perm = ctx->ev[3]; ev_la = ctx->ev[4]; ev_io = ctx->ev[5];
+        if (sp != st) { JSTSP_HIP(hipEventRecord(ev_io, st)); JSTSP_HIP(hipStreamWaitEvent(sp, ev_io, 0)); }
     }
+    StreamScope main_sc(ctx, sp);
     long long round_no = 0;
-    bool u_pending = false;                 // the basis update of round round_no - 1 has not been issued yet
-    auto issue_u = [&]() -> int {           // ... issue it behind everything the main stream has been given so far
-        if (!u_pending) return 0;
-        u_pending = false;
-        const long long r = round_no - 1;
-        JSTSP_HIP(hipEventRecord(ev_j, st));
-        JSTSP_HIP(hipStreamWaitEvent(su, ev_j, 0));
-        StreamScope sc(ctx, su);
-        hipLaunchKernelGGL(permute_kernel, grid, dim3(256), 0, su, np, idx, (const float2 *)nullptr, (float2 *)nullptr, U, Up);
-        JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Up, sPanel, np}, Mat{J + (size_t)(r & 1) * cnt * sub * sub, sSub, sub},
-                       U, sPanel, np));                                                                                   // U' = U J
-        JSTSP_HIP(hipEventRecord(ev_u[r & 1], su));
-        return 0;
-    };
+    bool la_valid = false;                  // S holds the next round's diagonal blocks (look-ahead of the previous round)
     auto join_u = [&]() -> int {            // the main stream continues behind the last basis update
-        JSTSP_TRY(issue_u());
-        if (side_u && round_no > 0) JSTSP_HIP(hipStreamWaitEvent(st, ev_u[(round_no - 1) & 1], 0));
+        if (piped && vecs && round_no > 0) JSTSP_HIP(hipStreamWaitEvent(sp, ev_u[(round_no - 1) & 1], 0));
         return 0;
     };
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         for (int r = 0; r < std::max(1, nb - 1); ++r) {
-            const float2 *Wc = W, *Uc = U;
-            float2 *Jr = J + (side_u ? (size_t)(round_no & 1) * cnt * sub * sub : 0);
-            if (m > 1) {                            // partners of this round side by side
-                hipLaunchKernelGGL(permute_kernel, grid, dim3(256), 0, st, np, idx, W, Wp, side_u ? (const float2 *)nullptr : U, Up);
-                for (int i = 0; i < np; ++i) lg2[i] = lg[hidx[i]];
-                lg.swap(lg2);
-                Wc = Wp; Uc = Up;
+            if (!piped) {                           // two blocks: one sub-problem, nothing to overlap
+                hipLaunchKernelGGL(gather_diag_kernel, dim3((unsigned)cnt), dim3(256), 0, sp, np, m, W, S);
+                JSTSP_TRY(launch_eig128(ctx, sub, (int)cnt, S, sSub, 1, 0, nullptr, lamJ /* tau = 0 */, nullptr, J, 0, inner_sweeps));
+                const Mat Jm{J, sSub, sub};
+                JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{W, sPanel, np}, Jm, Wp, sPanel, np));           // X = W J
+                hipLaunchKernelGGL(conj_transpose_kernel, dim3(np / 32, np / 32, batch), dim3(32, 8), 0, sp, np, Wp, W);
+                JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{W, sPanel, np}, Jm, Wp, sPanel, np));           // W' = X^H J
+                std::swap(W, Wp);
+                if (vecs) {
+                    JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{U, sPanel, np}, Jm, Up, sPanel, np));       // U' = U J
+                    std::swap(U, Up);
+                }
+                ++round_no;
+                continue;
             }
-            hipLaunchKernelGGL(gather_diag_kernel, dim3((unsigned)cnt), dim3(256), 0, st, np, m, Wc, S);
-            JSTSP_HIP(hipGetLastError());
-            // every pair's 128 x 128 sub-problem, exactly: eigenvectors J (columns).  eig3.hip's register-resident kernel
-            // (1024 threads per matrix; its by-product, a projector for tau = 0, goes to a scratch buffer) or eig.hip's general one
-            JSTSP_TRY(issue_u());           // (the previous round's basis update: beside this round's sub-problems)
-            if (side_u && round_no >= 2) JSTSP_HIP(hipStreamWaitEvent(st, ev_u[round_no & 1], 0));
-            if (sub_fast) JSTSP_TRY(launch_eig128(ctx, sub, (int)cnt, S, sSub, 1, 0, nullptr, lamJ /* tau = 0 */, Vg, Jr, 0, inner_sweeps));
-            else JSTSP_TRY(launch_eig(ctx, EIG_VECS, sub, (int)cnt, S, sSub, 1, 0, nullptr, nullptr, Jr, lamJ, Vg));
+            float2 *Jr = J + (size_t)(round_no & 1) * cnt * sub * sub;
             const Mat Jm{Jr, sSub, sub};
-            u_pending = side_u;
-            float2 *X = (m > 1) ? W : Wp;           // (the buffer that does not hold Wc)
-            float2 *Xh = (m > 1) ? Wp : W;
-            JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Wc, sPanel, np}, Jm, X, sPanel, np));          // X = W J
-            hipLaunchKernelGGL(conj_transpose_kernel, dim3(np / 32, np / 32, batch), dim3(32, 8), 0, st, np, X, Xh);
-            JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Xh, sPanel, np}, Jm, X, sPanel, np));          // W' = X^H J
-            if (vecs && !side_u) {
-                float2 *Un = (m > 1) ? U : Up;
-                JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Uc, sPanel, np}, Jm, Un, sPanel, np));      // U' = U J
-                if (m == 1) std::swap(U, Up);
+            // main: partners of this round side by side
+            hipLaunchKernelGGL(permute_kernel, grid, dim3(256), 0, sp, np, idx, W, Wp, (const float2 *)nullptr, (float2 *)nullptr);
+            for (int i = 0; i < np; ++i) lg2[i] = lg[hidx[i]];
+            lg.swap(lg2);
+            JSTSP_HIP(hipEventRecord(ev_perm, sp));
+            {   // sj: every pair's 128 x 128 sub-problem (eig3.hip's register-resident kernel, 1024 threads per matrix, basis only):
+                // rotations J (columns); then the look-ahead
+                StreamScope sc(ctx, sj);
+                const bool gather = !la_valid;      // (first round, or the matrix has just been replaced)
+                if (gather) {
+                    JSTSP_HIP(hipStreamWaitEvent(sj, ev_perm, 0));
+                    hipLaunchKernelGGL(gather_diag_kernel, dim3((unsigned)cnt), dim3(256), 0, sj, np, m, Wp, S);
+                }
+                if (vecs && round_no >= 2) JSTSP_HIP(hipStreamWaitEvent(sj, ev_u[round_no & 1], 0));
+                JSTSP_TRY(launch_eig128(ctx, sub, (int)cnt, S, sSub, 1, 0, nullptr, lamJ /* tau = 0 */, nullptr, Jr, 0, inner_sweeps));
+                JSTSP_HIP(hipEventRecord(ev_j, sj));
+                if (sl != sj) JSTSP_HIP(hipStreamWaitEvent(sl, ev_j, 0));
+                if (!gather || sl != sj) JSTSP_HIP(hipStreamWaitEvent(sl, ev_perm, 0));   // (the look-ahead reads this round's permuted W)
+                hipLaunchKernelGGL(lookahead_kernel, dim3(16, (unsigned)cnt), dim3(256), 0, sl, np, m, srcd, Wp, Jr, S);
+                JSTSP_HIP(hipEventRecord(ev_la, sl));
+                if (sl != sj) JSTSP_HIP(hipStreamWaitEvent(sj, ev_la, 0));            // (the next sub-problems read S)
+                la_valid = true;
             }
-            if (m == 1) std::swap(W, Wp);           // (results always end in W / U)
+            if (vecs) {                             // su: U' = U J
+                StreamScope sc(ctx, su);
+                JSTSP_HIP(hipStreamWaitEvent(su, ev_j, 0));
+                hipLaunchKernelGGL(permute_kernel, grid, dim3(256), 0, su, np, idx, (const float2 *)nullptr, (float2 *)nullptr, U, Up);
+                JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Up, sPanel, np}, Jm, U, sPanel, np));
+                JSTSP_HIP(hipEventRecord(ev_u[round_no & 1], su));
+            }
+            // main: W' = J^H W J (the conjugate transposition overwrites the permuted W the look-ahead reads)
+            JSTSP_HIP(hipStreamWaitEvent(sp, ev_j, 0));
+            JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Wp, sPanel, np}, Jm, W, sPanel, np));               // X = W J
+            JSTSP_HIP(hipStreamWaitEvent(sp, ev_la, 0));
+            hipLaunchKernelGGL(conj_transpose_kernel, dim3(np / 32, np / 32, batch), dim3(32, 8), 0, sp, np, W, Wp);
+            JSTSP_TRY(gemm(ctx, 'N', 'N', np, sub, sub, (int)cnt, Mat{Wp, sPanel, np}, Jm, W, sPanel, np));               // W' = X^H J
+            JSTSP_HIP(hipGetLastError());
             ++round_no;
         }
         // stop when the off-diagonal mass is at the fp32 level of the matrix, or no longer shrinking
-        JSTSP_HIP(hipMemsetAsync(stat, 0, 2 * (size_t)batch * sizeof(double), st));
-        hipLaunchKernelGGL(offnorm_kernel, grid, dim3(256), 0, st, np, W, stat);
+        JSTSP_HIP(hipMemsetAsync(stat, 0, 2 * (size_t)batch * sizeof(double), sp));
+        hipLaunchKernelGGL(offnorm_kernel, grid, dim3(256), 0, sp, np, W, stat);
         std::vector<double> hs(2 * (size_t)batch);
-        JSTSP_HIP(hipMemcpyAsync(hs.data(), stat, hs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-        JSTSP_HIP(hipStreamSynchronize(st));
+        JSTSP_HIP(hipMemcpyAsync(hs.data(), stat, hs.size() * sizeof(double), hipMemcpyDeviceToHost, sp));
+        JSTSP_HIP(hipStreamSynchronize(sp));
         double worst = 0.0;
         for (int t = 0; t < batch; ++t) worst = std::max(worst, hs[2 * t + 1] > 0 ? std::sqrt(hs[2 * t] / hs[2 * t + 1]) : 0.0);
         last_worst = worst;
@@ -349,9 +445,9 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
                 if (restarted || !vecs) { converged = true; break; }
                 restarted = true;
                 JSTSP_TRY(join_u());
-                float2 *Gp = Wp, *Tm = tmp.get<float2>(batch * nn);
-                JSTSP_REQUIRE(Tm, JSTSP_E_NOMEM, "eig (order %d): out of device memory", n);
-                hipLaunchKernelGGL(init_kernel, grid, dim3(256), 0, st, n, np, Gpart, sGt, nsplit, sGs, Gp, (float2 *)nullptr, dscale);
+                la_valid = false;                   // (the blocks formed ahead belong to the matrix that is being replaced)
+                float2 *Gp = Wp;
+                hipLaunchKernelGGL(init_kernel, grid, dim3(256), 0, sp, n, np, Gpart, sGt, nsplit, sGs, Gp, (float2 *)nullptr, dscale);
                 JSTSP_TRY(gemm(ctx, 'N', 'N', np, np, np, batch, Mat{Gp, (long long)nn, np}, Mat{U, (long long)nn, np}, Tm, (long long)nn, np));
                 JSTSP_TRY(gemm(ctx, 'C', 'N', np, np, np, batch, Mat{U, (long long)nn, np}, Mat{Tm, (long long)nn, np}, W, (long long)nn, np));
                 prev = -1.0;
@@ -367,6 +463,11 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
     // refinement below repairs eigenvalues, not eigenvectors).  A run that ends within 1e-4 of its diagonal without having met
     // the stop rule is accepted - the rule asks for the fp32 floor.
     JSTSP_TRY(join_u());
+    if (sp != st) {                          // back on the caller's stream
+        JSTSP_HIP(hipEventRecord(ev_io, sp));
+        JSTSP_HIP(hipStreamWaitEvent(st, ev_io, 0));
+        ctx->stream = st;
+    }
     JSTSP_REQUIRE(converged || last_worst < 1e-4, JSTSP_E_ILLCOND,
                   "eig (order %d, %d matrices): block Jacobi did not converge in %d sweeps (off-diagonal / diagonal mass %.2e)", n,
                   batch, max_sweeps, last_worst);

@@ -35,6 +35,7 @@ void load_tuning()
     t.eig128 = env_int("JSTSP_EIG128", t.eig128);
     t.omp_gram = env_int("JSTSP_OMP_GRAM", t.omp_gram);
     t.bj_trace = env_int("JSTSP_BJ_TRACE", t.bj_trace);
+    t.bj_mask = env_int("JSTSP_BJ_MASK", t.bj_mask);
     t.gram_refine = env_int("JSTSP_GRAM_REFINE", t.gram_refine);
     t.host_pipeline = env_int("JSTSP_HOST_PIPELINE", t.host_pipeline);
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
@@ -324,6 +325,34 @@ int ensure_side_streams(jstsp_ctx *ctx)
     return 0;
 }
 
+// Compute-unit masks: 32 of the units are set aside (4 per XCD whichever way the mask bits are dealt over the XCDs: bit
+// 32 x + 8 y + (x + y) % 8 for x < 8, y < 4 lands in XCD x under "32 consecutive bits per XCD" and in XCD (x + y) % 8 under
+// "bits dealt round-robin"), the other streams get the complement.
+bool ensure_cu_streams(jstsp_ctx *ctx)
+{
+    if (ctx->cu_state) return ctx->cu_state > 0;
+    ctx->cu_state = -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess || prop.multiProcessorCount != 256) return false;
+    uint32_t keep[8], rest[8];
+    for (int w = 0; w < 8; ++w) { keep[w] = 0u; rest[w] = 0xffffffffu; }
+    for (int x = 0; x < 8; ++x)
+        for (int y = 0; y < 4; ++y) {
+            const int bit = 32 * x + 8 * y + (x + y) % 8;
+            keep[bit >> 5] |= 1u << (bit & 31);
+            rest[bit >> 5] &= ~(1u << (bit & 31));
+        }
+    for (int i = 0; i < 4; ++i)
+        if (hipExtStreamCreateWithCUMask(&ctx->cu_stream[i], 8, i == 3 ? keep : rest) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j < i; ++j) { (void)hipStreamDestroy(ctx->cu_stream[j]); ctx->cu_stream[j] = nullptr; }
+            ctx->cu_stream[i] = nullptr;
+            return false;
+        }
+    ctx->cu_state = 1;
+    return true;
+}
+
 // ---- conditioning record ------------------------------------------------------------------------
 static const uint32_t DIAG_INIT[3] = {0x7f800000u /* +inf: no pinv yet */, 0u, 0x7f800000u /* no Gram inverse yet */};
 
@@ -456,6 +485,7 @@ int jstsp_destroy(jstsp_ctx *ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned_done) (void)hipEventDestroy(ctx->pinned_done);
     for (int i = 0; i < 2; ++i) if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
+    for (int i = 0; i < 4; ++i) if (ctx->cu_stream[i]) { (void)hipStreamSynchronize(ctx->cu_stream[i]); (void)hipStreamDestroy(ctx->cu_stream[i]); }
     for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->diag) (void)hipFree(ctx->diag);

@@ -115,10 +115,14 @@ def test_library_has_no_vendor_lapack_dependency():
             assert "dlopen" not in open(os.path.join(src, f)).read(), f
 
 
-def test_eigen_decomposition_of_order_1024_through_the_kronecker_vamp():
+@pytest.mark.parametrize("cu_mask", ["1", "0"])
+def test_eigen_decomposition_of_order_1024_through_the_kronecker_vamp(cu_mask, monkeypatch):
     """A delay factor of order 1024 (16 blocks of 64): first VAMP iterations against the float64 oracle - they use the
-    eigenvectors and eigenvalues of Gb directly (U^H (.) U, d = la x lb^2)."""
+    eigenvectors and eigenvalues of Gb directly (U^H (.) U, d = la x lb^2).  Both schedules of the block Jacobi: its chain of
+    sub-problems on 32 reserved compute units beside the panel products (streams with a compute-unit mask; the default when a
+    round has at most 32 sub-problems), and on plain side streams (JSTSP_BJ_MASK=0; what a runtime without masks gets)."""
     from oracle import vamp as V
+    monkeypatch.setenv("JSTSP_BJ_MASK", cu_mask)
     rng = np.random.default_rng(16)
     Na, Gr, G2, T = 16, 16, 1024, 1400
     Af = (rng.standard_normal((Na, Gr)) + 1j * rng.standard_normal((Na, Gr))) / np.sqrt(2 * Na)
