@@ -103,6 +103,16 @@ struct Conv {
         if (t) outs.push_back({dst, t, n * sizeof(T), false});
         return t;
     }
+    // fp32 device array -> the caller's doubles (host memspace), enqueued on the context's stream
+    int deliver(const float *dev, double *dst, size_t n)
+    {
+        if (!dst) return 0;
+        double *d64 = (double *)dmalloc(n * sizeof(double));
+        if (!d64) return rc;
+        widen_kernel<<<conv_grid(n), 256, 0, ctx->stream>>>(dev, d64, n);
+        JSTSP_HIP(hipMemcpyAsync(dst, d64, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        return 0;
+    }
     int finish()
     {
         for (const Out &o : outs) {
@@ -183,6 +193,64 @@ int jstsp_proposed_algorithm_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
               "proposed_algorithm");
     JSTSP_REQUIRE(subY && Omega && A && B && tau_Y && tau_S && rho && S_out, JSTSP_E_NULL,
                   "proposed_algorithm: NULL argument");
+    // JSTSP_HOST with a large batch: two halves on two contexts, as the _c32 entry does (proposed.hip) - the upload and narrowing
+    // of the second half (doubles: 9.5 GiB per 256 trials at BASELINE configs[1]) run while the first half is being solved.
+    const size_t in_bytes = (size_t)batch * ((size_t)N * M * 24 + (strideB ? (size_t)G2 * M * 16 : 0));
+    if (memspace == JSTSP_HOST && type == JSTSP_TYPE_APPROXIMATE && batch >= 128 && Imax > 1 && Y_out && tune().host_pipeline &&
+        in_bytes >= ((size_t)512 << 20)) {
+        if (!ctx->helper) JSTSP_TRY(jstsp_create(ctx->device, &ctx->helper));
+        jstsp_ctx *cx[2] = {ctx, ctx->helper};
+        const size_t nm1 = (size_t)N * M, g1 = (size_t)Gr * G2;
+        const int h = ((batch / 2 + 7) / 8) * 8, cnt[2] = {h, batch - h}, t0[2] = {0, h};
+        Conv half0(cx[0], JSTSP_HOST), half1(cx[1], JSTSP_HOST);
+        Conv *cvk[2] = {&half0, &half1};
+        PendingSolve pend[2];
+        const jstsp_c32 *yk[2], *ak[2], *bk[2];
+        const float *ok[2];
+        const int32_t *ik[2];
+        for (int k = 0; k < 2; ++k) {
+            Conv &c = *cvk[k];
+            yk[k] = c.in(subY + t0[k] * nm1, cnt[k] * nm1);
+            ok[k] = c.in_real(Omega + t0[k] * nm1, cnt[k] * nm1);
+            ak[k] = c.in_dict(A + (size_t)t0[k] * strideA, (size_t)N * Gr, strideA, cnt[k]);
+            bk[k] = c.in_dict(B + (size_t)t0[k] * strideB, (size_t)G2 * M, strideB, cnt[k]);
+            ik[k] = c.in_raw(indx_S ? indx_S + t0[k] * g1 : nullptr, cnt[k] * g1);
+            JSTSP_TRY(c.rc);
+            JSTSP_TRY(proposed_enqueue_device(cx[k], N, M, Gr, G2, cnt[k], yk[k], ok[k], ak[k], strideA, bk[k], strideB, Imax, tau_Y + t0[k],
+                                              tau_S + t0[k], rho + t0[k], type, ik[k], ce_out != nullptr, &pend[k]));
+        }
+        int fallbacks = 0;
+        for (int k = 0; k < 2; ++k) {
+            Conv &c = *cvk[k];
+            const PendingSolve &p = pend[k];
+            JSTSP_TRY(c.deliver(reinterpret_cast<const float *>(p.dS), reinterpret_cast<double *>(S_out + t0[k] * g1), 2 * cnt[k] * g1));
+            JSTSP_TRY(c.deliver(reinterpret_cast<const float *>(p.dY), reinterpret_cast<double *>(Y_out + t0[k] * nm1), 2 * cnt[k] * nm1));
+            if (p.want_ce)
+                JSTSP_HIP(hipMemcpyAsync(ce_out + (size_t)t0[k] * 3 * Imax, p.dce, (size_t)cnt[k] * 3 * Imax * sizeof(double),
+                                         hipMemcpyDeviceToHost, cx[k]->stream));
+            JSTSP_TRY(c.rc);
+            std::vector<int> o;
+            JSTSP_TRY(proposed_pending_flags(cx[k], p, &o));
+            for (size_t i = 0; i < o.size();) {            // runs of flagged trials again, without the fused pass
+                size_t j = i + 1;
+                while (j < o.size() && o[j] == o[j - 1] + 1) ++j;
+                const int r0 = o[i], nrun = (int)(j - i), tg = t0[k] + r0;
+                Conv cr(cx[k], JSTSP_HOST);
+                jstsp_c32 *s = cr.out(S_out + tg * g1, nrun * g1), *yo = cr.out(Y_out + tg * nm1, nrun * nm1);
+                double *ce = cr.out_raw(ce_out ? ce_out + (size_t)tg * 3 * Imax : nullptr, (size_t)nrun * 3 * Imax);
+                JSTSP_TRY(cr.rc);
+                JSTSP_TRY(proposed_resolve_device(cx[k], N, M, Gr, G2, nrun, yk[k] + r0 * nm1, ok[k] + r0 * nm1, ak[k] + (size_t)r0 * strideA,
+                                                  strideA, bk[k] + (size_t)r0 * strideB, strideB, Imax, tau_Y + tg, tau_S + tg, rho + tg,
+                                                  type, ik[k] ? ik[k] + r0 * g1 : nullptr, s, yo, ce));
+                JSTSP_TRY(cr.finish());
+                fallbacks += nrun;
+                i = j;
+            }
+        }
+        ctx->fused_fallbacks = fallbacks;
+        ctx->last_dict_block = (cx[0]->last_dict_block == cx[1]->last_dict_block) ? cx[0]->last_dict_block : 0;
+        return 0;
+    }
     const size_t nm = (size_t)N * M * batch;
     const jstsp_c32 *y = cv.in(subY, nm), *a = cv.in_dict(A, (size_t)N * Gr, strideA, batch),
                     *b = cv.in_dict(B, (size_t)G2 * M, strideB, batch);

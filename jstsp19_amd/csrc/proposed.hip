@@ -139,16 +139,6 @@ static bool tune_host_pipeline()
     return tune().host_pipeline != 0;
 }
 
-struct PendingSolve {
-    bool active = false, fused = false, want_ce = false;
-    int batch = 0;
-    size_t g = 0, nm = 0;
-    int Imax = 0;
-    const float2 *dS = nullptr, *dY = nullptr;
-    const double *dce = nullptr;
-    const uint32_t *ovf = nullptr;
-};
-
 // One batched solve.  allow_fused = false: never the fused pass (the re-solve of trials whose predicted k scale
 // overflowed in it).  overflowed != NULL: receives the indices of such trials (their outputs are not to be used); reading
 // the per-trial flags costs ONE stream synchronisation at the end of a solve that used the fused pass.
@@ -806,6 +796,39 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     ctx->fused_fallbacks += fallbacks;
     return 0;
 }
+
+namespace jstsp {
+// (solver_common.h: the phases of a pipelined host call for c64.hip, which stages - and narrows - its inputs itself)
+int proposed_enqueue_device(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *subY, const float *Omega,
+                            const jstsp_c32 *A, long long strideA, const jstsp_c32 *B, long long strideB, int Imax,
+                            const double *tau_Y, const double *tau_S, const double *rho, int type, const int32_t *indx_S,
+                            bool want_ce, PendingSolve *out)
+{
+    static jstsp_c32 sink_c;            // (a deferred solve never writes its output arguments; they only say what is wanted)
+    static double sink_d;
+    if (ctx) { ctx->fused_fallbacks = 0; ctx->last_dict_block = 0; }
+    return proposed_impl(ctx, N, M, Gr, G2, batch, subY, Omega, A, strideA, B, strideB, Imax, tau_Y, tau_S, rho, type, indx_S, &sink_c,
+                         &sink_c, want_ce ? &sink_d : nullptr, JSTSP_DEVICE, true, nullptr, out);
+}
+int proposed_pending_flags(jstsp_ctx *ctx, const PendingSolve &p, std::vector<int> *ovf)
+{
+    JSTSP_ENTER(ctx);
+    std::vector<uint32_t> flags(p.ovf ? p.batch : 0);
+    if (p.ovf) JSTSP_HIP(hipMemcpyAsync(flags.data(), p.ovf, (size_t)p.batch * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < (int)flags.size(); ++t)
+        if (flags[t]) ovf->push_back(t);
+    return 0;
+}
+int proposed_resolve_device(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *subY, const float *Omega,
+                            const jstsp_c32 *A, long long strideA, const jstsp_c32 *B, long long strideB, int Imax,
+                            const double *tau_Y, const double *tau_S, const double *rho, int type, const int32_t *indx_S,
+                            jstsp_c32 *S_dev, jstsp_c32 *Y_dev, double *ce_dev)
+{
+    return proposed_impl(ctx, N, M, Gr, G2, batch, subY, Omega, A, strideA, B, strideB, Imax, tau_Y, tau_S, rho, type, indx_S, S_dev,
+                         Y_dev, ce_dev, JSTSP_DEVICE, false, nullptr);
+}
+}  // namespace jstsp
 
 /* Trials of the last jstsp_proposed_algorithm_* call on this context that were solved a second time by the three-kernel
  * iteration because the fused pass's predicted operand scale overflowed for them (0 in all but pathological inputs). */

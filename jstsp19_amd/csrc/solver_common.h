@@ -2,6 +2,7 @@
 // spectral norms, host<->device staging.
 #pragma once
 #include "common.h"
+#include <vector>
 
 namespace jstsp {
 
@@ -98,6 +99,31 @@ int ensure_diag(jstsp_ctx *ctx);
 int diag_reset(jstsp_ctx *ctx);
 // After the stream has been synchronised: JSTSP_E_ILLCOND when a Gram inverse of the call lost all its fp32 digits.
 int diag_check_host(jstsp_ctx *ctx, const char *what);
+
+// A proposed_algorithm solve whose device work has been enqueued but whose results are still in the context's workspace
+// (proposed.hip): the halves of a pipelined JSTSP_HOST call.  Valid until the next solve on that context.
+struct PendingSolve {
+    bool active = false, fused = false, want_ce = false;
+    int batch = 0;
+    size_t g = 0, nm = 0;
+    int Imax = 0;
+    const float2 *dS = nullptr, *dY = nullptr;
+    const double *dce = nullptr;
+    const uint32_t *ovf = nullptr;
+};
+// The two phases for a caller that stages its own inputs (c64.hip): every array argument in device memory (tau_Y, tau_S, rho on
+// the host as always).  enqueue: the whole solve without its final copies and flag read; flags: the trials whose predicted k
+// scale overflowed in the fused pass (one stream synchronisation); resolve: such a run of trials again by the three-kernel
+// iteration, outputs to device arrays.
+int proposed_enqueue_device(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *subY, const float *Omega,
+                            const jstsp_c32 *A, long long strideA, const jstsp_c32 *B, long long strideB, int Imax,
+                            const double *tau_Y, const double *tau_S, const double *rho, int type, const int32_t *indx_S,
+                            bool want_ce, PendingSolve *out);
+int proposed_pending_flags(jstsp_ctx *ctx, const PendingSolve &p, std::vector<int> *ovf);
+int proposed_resolve_device(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *subY, const float *Omega,
+                            const jstsp_c32 *A, long long strideA, const jstsp_c32 *B, long long strideB, int Imax,
+                            const double *tau_Y, const double *tau_S, const double *rho, int type, const int32_t *indx_S,
+                            jstsp_c32 *S_dev, jstsp_c32 *Y_dev, double *ce_dev);
 
 // Host -> device scalar block.
 int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes);

@@ -147,3 +147,48 @@ def test_pipelined_host_call_equals_the_staged_one_and_recovers_per_half():
     assert nrec == 128
     for a, b in zip(ref, rec):
         assert a.tobytes() == b.tobytes()
+
+
+def test_pipelined_complex_double_host_call_equals_the_staged_one_and_recovers_per_half():
+    """The MEX gateway's route (interleaved complex DOUBLES in host memory, jstsp_proposed_algorithm_c64) is pipelined the same
+    way (c64.hip: each half uploaded and narrowed on its own context): bit for bit the staged call, with and without recovery."""
+    import ctypes as C
+    import os
+    import jstsp19_amd as J
+    from jstsp19_amd import _lib
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=5.0)
+    batch, Imax = 128, 12
+    inp = build_trials(p, 0, batch, seed=11)
+    lib, ctx = _lib.load(), J.default_context(0)
+    colm = lambda a, dt: np.ascontiguousarray(np.swapaxes(a.cpu().numpy(), -1, -2).astype(dt))
+    sy, om, b, a64 = colm(inp["subY"], np.complex128), colm(inp["Omega"], np.float64), colm(inp["B"], np.complex128), colm(inp["A"], np.complex128)
+    N, M = inp["subY"].shape[1:]
+    Gr, G2 = inp["A"].shape[1], inp["B"].shape[1]
+    ty, ts, rh = (np.ascontiguousarray(inp[k].numpy(), dtype=np.float64) for k in ("tau_Y", "tau_Z", "rho"))
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    dp = lambda x: x.ctypes.data_as(C.POINTER(C.c_double))
+
+    def run(env):
+        S = np.empty(batch * Gr * G2, np.complex128); Y = np.empty(batch * N * M, np.complex128); ce = np.empty(batch * 3 * Imax, np.float64)
+        os.environ.update(env)
+        try:
+            _lib.check(lib.jstsp_proposed_algorithm_c64(ctx.handle, N, M, Gr, G2, batch, vp(sy), vp(om), vp(a64), 0, vp(b), G2 * M, Imax, dp(ty),
+                                                        dp(ts), dp(rh), 0, None, vp(S), vp(Y), vp(ce), 0), "proposed_algorithm_c64")
+            n = ctx.last_fused_fallbacks()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        return (S, Y, ce), n
+
+    one, n1 = run({"JSTSP_HOST_PIPELINE": "0"})
+    two, n2 = run({})
+    assert n1 == 0 and n2 == 0
+    for x, y in zip(one, two):
+        assert x.tobytes() == y.tobytes()
+    assert np.isfinite(one[0]).all() and np.count_nonzero(one[0]) > 0
+    ref, _ = run({"JSTSP_FUSED": "0", "JSTSP_HOST_PIPELINE": "0"})
+    rec, nrec = run({"JSTSP_FUSED_KBACK": "-20"})
+    assert nrec == batch
+    for x, y in zip(ref, rec):
+        assert x.tobytes() == y.tobytes()
