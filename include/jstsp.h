@@ -194,8 +194,9 @@ int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count);
  * dictionaries of the reference's drivers stack L delayed copies of one pilot frame under the transmit steering vectors
  * (errorVSsnr.m:36-47), which makes them block-Toeplitz: B(ld*Gt + g, m) == B(g, m - ld) for m >= ld, G2 = L*Gt.  The
  * library PROBES that (exact comparison of every entry, once per call) and, where it holds, streams only the first block
- * in each iteration.  *gt = the block height used, 0 = none found (any B is accepted; an unstructured one just costs the
- * full read).  JSTSP_TOEPLITZ=0 in the environment skips the probe.
+ * in each iteration and forms G_B = B B^H from its first block row (1 / L of the product; that also for shapes the one-pass
+ * iteration does not take).  *gt = the block height used, 0 = none found (any B is accepted; an unstructured one just costs
+ * the full read).  JSTSP_TOEPLITZ=0 in the environment skips the probe.
  * What the structure changes in the results: with JSTSP_TOEPLITZ=1 (compact image, same kernel, same products) NOTHING -
  * bit-identical to the unstructured path.  With the default (2), block height 64 takes the window kernel, which applies the
  * leading columns of each delayed block as separate fp32 terms: fp32-EQUIVALENT to the unstructured path (same accuracy

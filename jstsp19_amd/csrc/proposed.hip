@@ -299,6 +299,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             dg.force_m64 = 1; dg.C_lo = G0lo;
             JSTSP_TRY(launch_cgemm(ctx, dg, GEMM_MISC));
             JSTSP_TRY(toeplitz_gram_assemble(ctx, B, strideB, G2, M, toep_gt, nB, G0, G0lo, w.GB, nullptr));
+            ctx->last_dict_block = toep_gt;        // (the structure has been used, whether or not the fused pass takes this shape)
         } else {
             GemmDesc dg = make_gemm('N', 'C', G2, G2, M, nB, Bm, Bm, w.GB, (long long)G2 * G2, G2);
             dg.force_m64 = 1; dg.herm_upper = 1;

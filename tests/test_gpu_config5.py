@@ -36,6 +36,9 @@ def test_cfg5_small_frame_proposed_and_angles_against_the_oracle():
     inp = build_trials(p, 0, nb, seed=77)
     ty, tz, rho = inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy()
     S, Y, ce = J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], Imax, ty, tz, rho, "approximate")
+    # the builder's pilots are the drivers': block-Toeplitz with block height Gt = 256 - found, and used for G_B = B B^H (its
+    # first block row only) although the one-pass iteration does not take G2 = 4096
+    assert J.default_context(0).last_dictionary_block() == 256
     Sa, Ya, cea = J.proposed_algorithm_angles(inp["subY"], inp["Omega"], inp["indx_S"], inp["A"], inp["B"], Imax, ty, tz,
                                               rho, "approximate", None)
     torch.cuda.synchronize()
