@@ -944,7 +944,9 @@ size_t hgemm_pack_bytes(int Kd, int J, int count)
 int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax)
 {
     JSTSP_HIP(hipMemsetAsync(amax, 0, (size_t)count * sizeof(uint32_t), ctx->stream));
-    const int gx = (int)std::max<long long>(1, std::min<long long>(2 * n / 4 / 256 / 16, 16));
+    // (16 blocks per problem fill the chip when there are hundreds of problems; ONE shared 2-GiB dictionary - BASELINE configs[4] -
+    //  was read by 16 workgroups at 0.27 TB/s: 7.8 ms per call)
+    const int gx = (int)std::max<long long>(1, std::min<long long>(2 * n / 4 / 256 / 16, std::max(16, 4096 / std::max(count, 1))));
     absmax_kernel<<<dim3(gx, count), 256, 0, ctx->stream>>>(2 * n, reinterpret_cast<const float *>(X), 2 * sXt, amax);
     JSTSP_HIP(hipGetLastError());
     return 0;
