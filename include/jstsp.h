@@ -94,6 +94,8 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         both Grams in float64, kept as two floats, the low-order parts applied whenever R*v is recomputed
  *   JSTSP_RV_REFRESH=n    proposed_algorithm 'approximate': R*v recomputed from v every n iterations (default 4; 1 = always);
  *   JSTSP_RV_ALWAYS=n     ... and in each of the first n iterations (default 0)
+ *   JSTSP_RV_COMP=1       opt-in: v and R*v carried as two floats each (compensated accumulation); with JSTSP_RV_REFRESH=1000 (R*v
+ *                         never recomputed) +4 % at rms |dNMSE| 2.0e-7, but one bench trial at 1.2e-6: outside the accuracy statement
  *   JSTSP_GRAD_HEAD=3     opt-in: the 64-term products of the gradient step on the f16 pipe in one launch (jstsp_gradient_head_c32);
  *                         faster (+2 %) and individually more accurate, but measured WORSE against float64 (rms 2.2e-7 vs 1.7e-7)
  *   JSTSP_OVERLAP=0|1     side streams between the kernels of an iteration (default: on with the one-pass kernel)

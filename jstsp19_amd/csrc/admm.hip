@@ -179,8 +179,12 @@ template <int NT>
 __global__ __launch_bounds__(NT) void step_v_kernel(int g, const float2 *Res, const float2 *RRes,
                                                     float2 *V, float2 *S, const int32_t *rank,
                                                     int cnt, const TrialParams *prm, double *ce3,
-                                                    int Imax, int it, float2 *RV)
+                                                    int Imax, int it, float2 *RV, float2 *Vlo, float2 *RVlo, int vlo_reset)
 {
+    // Vlo / RVlo != NULL: v and R v are carried as two floats each (hi in V / RV): the sums of alpha res and alpha R res are
+    // accumulated to about 48 bits (in float64 here, split again on the way out), so that R v stays R times THE v that was
+    // accumulated instead of drifting from it by one fp32 rounding of each per iteration.  s = soft(v) sees the leading part.
+    // vlo_reset: R v has just been recomputed from the leading part of v - the stored low-order part of v is dropped.
     __shared__ double sh[NT / 64];
     const int t = blockIdx.x;
     const long long base = (long long)t * g;
@@ -204,6 +208,20 @@ __global__ __launch_bounds__(NT) void step_v_kernel(int g, const float2 *Res, co
     for (int i = threadIdx.x; i < g; i += NT) {
         const float2 r = Res[base + i];
         float2 v = V[base + i];
+        if (Vlo) {
+            const float2 vl = vlo_reset ? make_float2(0.f, 0.f) : Vlo[base + i];
+            const double sx = ((double)v.x + (double)vl.x) + ((double)ax * r.x - (double)ay * r.y);
+            const double sy = ((double)v.y + (double)vl.y) + ((double)ax * r.y + (double)ay * r.x);
+            v = make_float2((float)sx, (float)sy);
+            Vlo[base + i] = make_float2((float)(sx - (double)v.x), (float)(sy - (double)v.y));
+            const float2 rr = RRes[base + i], rv = RV[base + i], rl = RVlo[base + i];
+            const double tx = ((double)rv.x + (double)rl.x) + ((double)ax * rr.x - (double)ay * rr.y);
+            const double ty = ((double)rv.y + (double)rl.y) + ((double)ax * rr.y + (double)ay * rr.x);
+            const float2 rn = make_float2((float)tx, (float)ty);
+            RV[base + i] = rn;
+            RVlo[base + i] = make_float2((float)(tx - (double)rn.x), (float)(ty - (double)rn.y));
+            V[base + i] = v;
+        } else {
         v.x += ax * r.x - ay * r.y;
         v.y += ax * r.y + ay * r.x;
         V[base + i] = v;
@@ -213,6 +231,7 @@ __global__ __launch_bounds__(NT) void step_v_kernel(int g, const float2 *Res, co
             rv.x += ax * rr.x - ay * rr.y;
             rv.y += ax * rr.y + ay * rr.x;
             RV[base + i] = rv;
+        }
         }
         float2 s = make_float2(soft1(v.x, thr), soft1(v.y, thr));
         if (rank && rank[base + i] >= cnt) s = make_float2(0.f, 0.f);
@@ -303,19 +322,19 @@ int launch_update_c(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, co
 }
 int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const float2 *RRes, float2 *V,
                   float2 *S, const int32_t *rank, int cnt, const TrialParams *prm, double *ce3,
-                  int Imax, int it, float2 *RV, int waves8)
+                  int Imax, int it, float2 *RV, int waves8, float2 *Vlo, float2 *RVlo, int vlo_reset)
 {
     // waves8 (the caller runs an eigen-decomposition beside this kernel): eight waves per problem - a workgroup that fits on a
     // CU beside a resident Jacobi, 16 waves x 106 registers do not; alone, the 16-wave form is 25 % faster
     if (g >= 8192 && waves8)
         hipLaunchKernelGGL(step_v_kernel<512>, dim3(batch), dim3(512), 0, ctx->stream, g, Res, RRes, V, S, rank,
-                           cnt, prm, ce3, Imax, it, RV);
+                           cnt, prm, ce3, Imax, it, RV, Vlo, RVlo, vlo_reset);
     else if (g >= 8192)
         hipLaunchKernelGGL(step_v_kernel<1024>, dim3(batch), dim3(1024), 0, ctx->stream, g, Res, RRes, V, S, rank,
-                           cnt, prm, ce3, Imax, it, RV);
+                           cnt, prm, ce3, Imax, it, RV, Vlo, RVlo, vlo_reset);
     else
         hipLaunchKernelGGL(step_v_kernel<256>, dim3(batch), dim3(256), 0, ctx->stream, g, Res, RRes, V, S, rank,
-                           cnt, prm, ce3, Imax, it, RV);
+                           cnt, prm, ce3, Imax, it, RV, Vlo, RVlo, vlo_reset);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

@@ -367,6 +367,11 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                         const float2 dv = Dp[gi + (long long)gj * d.ldd];
                         o.x += d.beta * dv.x;
                         o.y += d.beta * dv.y;
+                        if (d.D_lo) {       // (after the leading part: o - D is where the cancellation happens)
+                            const float2 dl = d.D_lo[(long long)t * d.sDt + gi + (long long)gj * d.ldd];
+                            o.x += d.beta * dl.x;
+                            o.y += d.beta * dl.y;
+                        }
                     }
                     const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
                     if (M64 && EPI == EPI_NONE && d.C_lo)       // what the fp32 result leaves of the float64 sum

@@ -74,6 +74,7 @@ struct Tuning {
     int grad_head = 0;      // JSTSP_GRAD_HEAD: bit 0 - Res / P1 of the gradient step, bit 1 - the first factor of a recomputed R v, on the
                             // f16 pipe in one launch (hsmall.hip) instead of fp32-MFMA products; measured: more accurate products,
                             // +2 % channel-estimates/s, but WORSE parity (rms |dNMSE| 2.18e-7 against 1.73e-7, a +5e-8 bias): off
+    int rv_comp = 0;        // JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
     int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
@@ -184,6 +185,7 @@ struct GemmDesc {
     // it (C_lo, same layout as C; alpha = 1, no D): C + C_lo carries the product to about 1e-9 relative
     int force_m64;
     float2 *C_lo;
+    const float2 *D_lo;                     // low-order part of D (same layout): C = alpha acc + beta (D + D_lo); NULL = none
     int herm_upper;                         // the product is Hermitian (a Gram): tiles entirely below the diagonal are skipped, the caller
                                             // mirrors them (hermitian_fill_lower)
 };
@@ -287,7 +289,8 @@ int launch_update_c(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, co
                     float2 *V2, float2 *C, const TrialParams *prm);
 int launch_step_v(jstsp_ctx *ctx, int g, int batch, const float2 *Res, const float2 *RRes,
                   float2 *V, float2 *S, const int32_t *rank, int cnt, const TrialParams *prm,
-                  double *ce3, int Imax, int it, float2 *RV = nullptr, int waves8 = 0);    // RV != nullptr: RV += alpha * RRes as well
+                  double *ce3, int Imax, int it, float2 *RV = nullptr, int waves8 = 0,      // RV != nullptr: RV += alpha * RRes as well
+                  float2 *Vlo = nullptr, float2 *RVlo = nullptr, int vlo_reset = 0);         // low-order parts: v and R v as two floats (admm.hip)
 int launch_soft(jstsp_ctx *ctx, int g, int batch, const float2 *V, float2 *S, const int32_t *rank,
                 int cnt, const TrialParams *prm);
 int launch_inv_d(jstsp_ctx *ctx, long long nm, int batch, const float *Omega, float scale2rho,

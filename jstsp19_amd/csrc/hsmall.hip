@@ -179,6 +179,7 @@ struct HeadDesc {
     const float2 *A; long long sA;                        // N x Gr = 64 x 64 (sA = 0: shared)
     const float2 *GA; long long sGA;                      // Gr x Gr Hermitian
     const float2 *RV;                                     // Gr x G2 per trial, or NULL (R v = 0)
+    const float2 *RVlo;                                   // its low-order part (R v carried as two floats), or NULL
     float2 *Tc;                                           // optional output: the summed Tc (N x G2), NULL = not stored
     float2 *Res, *P1;                                     // Gr x G2 per trial
     uint32_t *pmax;                                       // [batch] atomicMax of max(|re|, |im|) of P1 (float bits)
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void grad_head_kernel(HeadDesc d)
         const int g = wj * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         float2 v = acc_value(acc, r, al1);
         if (d.RV) { const float2 rv = d.RV[obase + 64ll * g]; v.x -= rv.x; v.y -= rv.y; }
+        if (d.RVlo) { const float2 rl = d.RVlo[obase + 64ll * g]; v.x -= rl.x; v.y -= rl.y; }
         res[r] = v;
         d.Res[obase + 64ll * g] = v;
         mr = fmaxf(mr, fmaxf(fabsf(v.x), fabsf(v.y)));
@@ -338,10 +340,10 @@ bool grad_head_shape_ok(int N, int Gr, int G2) { return N == 64 && Gr == 64 && G
 
 int launch_grad_head(jstsp_ctx *ctx, int G2, int batch, const float2 *P, long long sPt, long long sPp, int parts, const float2 *Kf,
                      const float2 *Bdl, long long sBdl, const float2 *A, long long sA, const float2 *GA, long long sGA,
-                     const float2 *RV, float2 *Tc, float2 *Res, float2 *P1, uint32_t *pmax)
+                     const float2 *RV, float2 *Tc, float2 *Res, float2 *P1, uint32_t *pmax, const float2 *RVlo)
 {
     JSTSP_REQUIRE((G2 & 63) == 0 && parts >= 1, JSTSP_E_SHAPE, "grad_head: G2 = %d, parts = %d", G2, parts);
-    HeadDesc d{P, sPt, sPp, parts, Kf, Bdl, sBdl, A, sA, GA, sGA, RV, Tc, Res, P1, pmax, G2};
+    HeadDesc d{P, sPt, sPp, parts, Kf, Bdl, sBdl, A, sA, GA, sGA, RV, RVlo, Tc, Res, P1, pmax, G2};
     hipLaunchKernelGGL(grad_head_kernel, dim3((unsigned)(batch * (G2 >> 6))), dim3(256), 0, ctx->stream, d);
     JSTSP_HIP(hipGetLastError());
     return 0;

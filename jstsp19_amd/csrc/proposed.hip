@@ -20,6 +20,7 @@ struct ProposedWS {
     float *invD;
     // Gr x G2 per problem
     float2 *V, *RV, *Res, *RRes, *S, *P1;
+    float2 *Vlo = nullptr, *RVlo = nullptr;     // low-order parts of v and R v (compensated accumulation: allocated by the solve when used)
     // N x G2 per problem
     float2 *Tc, *W;
     float2 *GA, *GB;
@@ -192,6 +193,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const bool want_fused = allow_fused && tn.fused != 0 && approx && Imax > 1 && fused_shape_ok(N, M, G2, fparts);
     if (want_fused) need += fused_bytes(M, G2, nB, batch, fparts);
     need += 1024;                                                                 // probe flags of the block-Toeplitz test
+    if (approx && tn.gram_refine && tn.rv_comp) need += 2 * rnd256((size_t)batch * g * sizeof(float2));     // low-order parts of v, R v
     if (approx && tn.gram_refine)      // low-order part of G_A, G_B's first block row (hi, lo)
         need += rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + 2 * rnd256((size_t)nB * (G2 / 2 + 1) * G2 * sizeof(float2));
     if (memspace == JSTSP_HOST) {
@@ -271,6 +273,22 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const bool refine = approx && tn.gram_refine != 0;
     // the 64-term products of the gradient step on the f16 pipe, fused into one launch (hsmall.hip)
     const bool use_head = refine && tn.grad_head != 0 && grad_head_shape_ok(N, Gr, G2);      // (bit 0: Res / P1; bit 1: first factor of R v)
+    // JSTSP_RV_COMP=1 (opt-in): v and R v as two floats each (admm.hip: step_v_kernel): the recurrence R v += alpha R res then
+    // tracks R times the v that was actually accumulated to about 48 bits, as the float64 reference's does; the low-order part of
+    // a recomputed R v comes out of the fp64-master product (C_lo), the gradient subtracts both parts (cgemm: D_lo).  Measured
+    // (2560 / 1280 fixture trials + the bench batch): with the default recomputation every 4th iteration max
+    // |dNMSE| 7.8e-7 instead of 8.7e-7 for -1.2 % (two more arrays through the step kernel); with NO recomputation at all
+    // (JSTSP_RV_REFRESH=1000) rms 2.04e-7, max 8.6e-7 over the 2560 sweep trials but 1.2e-6 on one trial of the bench batch, at
+    // 845 instead of 810 channel-estimates/s; recomputing only now and then (every 16th, or at 0, 4, 8, 16, 32, 64) is WORSE than
+    // never (1.5e-6, 2.0e-6): an exact R v is inconsistent with the operator the recurrence's split-f16 products realise, and
+    // every recomputation is a kick of that size.
+    const bool comp = refine && tn.rv_comp != 0 && Imax > 0;
+    float2 *rv_lo_out = nullptr;
+    if (comp) {
+        w.Vlo = ctx->arena.get<float2>((size_t)batch * g);
+        w.RVlo = ctx->arena.get<float2>((size_t)batch * g);
+        JSTSP_REQUIRE(w.Vlo && w.RVlo, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted (two-float accumulation)");
+    }
     float2 *GAlo = nullptr;
     if (refine) {
         GAlo = ctx->arena.get<float2>((size_t)nA * Gr * Gr);
@@ -375,6 +393,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // 1 / 4 / 8 / never: 514 / 529 / 533 / 536 channel-estimates/s, max |dNMSE| 2.4e-7 / 2.7e-7 / 2.7e-7 / 4.4e-7,
     // max |dS|/max|S| 2.5e-6 / 2.8e-6 / 3.2e-6 / 4.6e-6.  JSTSP_RV_REFRESH=1 recomputes every iteration.
     const int rv_refresh = std::max(1, tn.rv_refresh);
+    auto refresh_at = [&](int it) -> bool { return it < tn.rv_always || it % rv_refresh == 0; };      // R v recomputed at iteration `it`?
     // With the fused pass the work between two passes is three short independent chains (Gram + eigen-decomposition of
     // the next Z | partial sums -> gradient step -> A S | spectral norms): there the side streams are on by default
     // (4.35 -> 4.21 ms per iteration at configs[1]).
@@ -550,6 +569,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             if (exact || !w.h2g) {
                 GemmDesc dr = make_gemm('N', 'N', Gr, G2, G2, batch, Mat{w.P1, sg, Gr}, GBm, out, sg, Gr);
                 dr.force_m64 = exact ? 1 : 0;
+                if (exact) dr.C_lo = rv_lo_out;         // (R v itself: what the fp32 result leaves of the float64 sums)
                 return launch_cgemm(ctx, dr, GEMM_MISC);
             }
             HGemmDesc hg{w.P1, sg, Gr, pm, w.GBp.data, strideB ? w.GBp.st : 0, w.GBp.bmax, strideB ? 1 : 0,
@@ -573,7 +593,12 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         if (approx) {
             // R v: recomputed from v every `rv_refresh` iterations, carried by R v += alpha R res in between (both are
             // `R*v` of :47; the recurrence alone drifts in fp32)
-            if (it % rv_refresh == 0 || it < tn.rv_always) JSTSP_TRY(apply_R(w.V, w.RV, refine));
+            const bool refreshed = refresh_at(it);
+            if (refreshed) {
+                rv_lo_out = comp ? w.RVlo : nullptr;
+                JSTSP_TRY(apply_R(w.V, w.RV, refine));
+                rv_lo_out = nullptr;
+            }
             if (use_head && !(tn.grad_head & 1)) JSTSP_TRY(fused_reduce_if(passed));
             if (use_head && (tn.grad_head & 1)) {
                 // Res = A^H Tc - R v and P1 = G_A Res in one kernel on the f16 pipe, straight from the pass's partial sums
@@ -581,15 +606,16 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
                 if (passed)
                     JSTSP_TRY(launch_grad_head(ctx, G2, batch, fw.Ppart, (long long)fw.parts * sng, sng, fw.parts, fw.v2 ? fw.Kf : nullptr,
                                                fw.Bdl, fw.sBdl, A, strideA, w.GA, strideA ? (long long)Gr * Gr : 0, w.RV, nullptr, w.Res,
-                                               w.P1, pm));
+                                               w.P1, pm, comp ? w.RVlo : nullptr));
                 else
                     JSTSP_TRY(launch_grad_head(ctx, G2, batch, w.Tc, sng, 0, 1, nullptr, nullptr, 0, A, strideA, w.GA,
-                                               strideA ? (long long)Gr * Gr : 0, w.RV, nullptr, w.Res, w.P1, pm));
+                                               strideA ? (long long)Gr * Gr : 0, w.RV, nullptr, w.Res, w.P1, pm, comp ? w.RVlo : nullptr));
                 //    R*res for alpha = res'*res / (res'*R*res)                                (:48)
                 JSTSP_TRY(second_factor(w.RRes, pm, false));
             } else {
-                JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr,
-                               -1.f));
+                GemmDesc dres = make_gemm('C', 'N', Gr, G2, N, batch, Am, Mat{w.Tc, sng, N}, w.Res, sg, Gr, 1.f, w.RV, sg, Gr, -1.f);
+                dres.D_lo = comp ? w.RVlo : nullptr;
+                JSTSP_TRY(launch_cgemm(ctx, dres, GEMM_MISC));
                 //    R*res for alpha = res'*res / (res'*R*res)                                (:48)
                 JSTSP_TRY(apply_R(w.Res, w.RRes, false));
             }
@@ -600,7 +626,8 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             }
             //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
-                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr, svt_split));
+                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr, svt_split, comp ? w.Vlo : nullptr,
+                                    comp ? w.RVlo : nullptr, refreshed ? 1 : 0));
         } else {
             //    v = U\(L\k) = pinv(A) K pinv(B)   [ = G_A^-1 (A^H Tc) G_B^-1 on the Gram route: GA / GB hold the inverses ]  (:53)
             float2 *left = PB ? w.V : w.P1;        // result of the A side; the B side (if any) finishes into V

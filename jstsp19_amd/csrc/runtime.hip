@@ -40,6 +40,7 @@ void load_tuning()
     t.host_pipeline = env_int("JSTSP_HOST_PIPELINE", t.host_pipeline);
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
+    t.rv_comp = env_int("JSTSP_RV_COMP", t.rv_comp);
     g_tune = t;
 }
 
@@ -150,7 +151,7 @@ GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Ma
     d.splitk = splitk < 1 ? 1 : splitk; d.sCsplit = sCsplit;
     d.epi = EPI_NONE; d.prm = nullptr; d.e_rw0 = d.e_w1 = d.e_w2 = d.e_w3 = nullptr;
     d.e_r0 = d.e_r1 = d.e_r2 = d.e_r3 = nullptr; d.e_f0 = nullptr; d.epi_store_c = 1; d.amax_out = nullptr; d.amax_x = d.amax_v1 = d.amax_z = nullptr;
-    d.force_m64 = 0; d.C_lo = nullptr; d.herm_upper = 0;
+    d.force_m64 = 0; d.C_lo = nullptr; d.herm_upper = 0; d.D_lo = nullptr;
     return d;
 }
 

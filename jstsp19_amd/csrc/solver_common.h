@@ -29,7 +29,7 @@ int gram_f64(jstsp_ctx *ctx, char side, const float2 *X, long long sXt, int rows
 bool grad_head_shape_ok(int N, int Gr, int G2);
 int launch_grad_head(jstsp_ctx *ctx, int G2, int batch, const float2 *P, long long sPt, long long sPp, int parts, const float2 *Kf,
                      const float2 *Bdl, long long sBdl, const float2 *A, long long sA, const float2 *GA, long long sGA,
-                     const float2 *RV, float2 *Tc, float2 *Res, float2 *P1, uint32_t *pmax);
+                     const float2 *RV, float2 *Tc, float2 *Res, float2 *P1, uint32_t *pmax, const float2 *RVlo = nullptr);
 //   P1 = (G_hi + G_lo) X, G Hermitian 64 x 64 in two floats (sG = 0: shared), X and P1 64 x G2 per trial
 int launch_left2(jstsp_ctx *ctx, int G2, int batch, const float2 *Ghi, const float2 *Glo, long long sG, const float2 *X, float2 *P1,
                  uint32_t *pmax);
