@@ -150,6 +150,10 @@ struct jstsp_ctx {
     // reserved units only - the block Jacobi's chain of sub-problems runs there beside panel products that fill the rest
     hipStream_t cu_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     int cu_state = 0;            // 0 not tried, 1 available, -1 the runtime refused
+    // the block Jacobi's own plain streams and events (eig_large.hip is called from inside solvers that are using side[] and
+    // ev[] themselves - an SVT of order > 128 on a side stream of proposed_algorithm - and must not re-record their events)
+    hipStream_t bj_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t bj_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

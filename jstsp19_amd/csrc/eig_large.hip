@@ -351,12 +351,12 @@ int launch_eig_large(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *G
     hipStream_t sp = st, su = st, sj = st, sl = st;
     hipEvent_t ev_j = nullptr, ev_u[2] = {nullptr, nullptr}, ev_perm = nullptr, ev_la = nullptr, ev_io = nullptr;
     if (piped) {
-        JSTSP_TRY(ensure_side_streams(ctx));
+        JSTSP_TRY(ensure_bj_resources(ctx));
         // (only when the sub-problems of a round fit the reserved units one each; more of them want the whole chip)
         if (tune().bj_mask && cnt <= 32 && ensure_cu_streams(ctx)) { sp = ctx->cu_stream[0]; su = ctx->cu_stream[1]; sl = ctx->cu_stream[2]; sj = ctx->cu_stream[3]; }
-        else { su = ctx->side[0]; sj = sl = ctx->side[1]; }
+        else { su = ctx->bj_stream[0]; sj = sl = ctx->bj_stream[1]; }
         tmp.also[0] = su; tmp.also[1] = sj; tmp.also[2] = sl; tmp.also[3] = sp != st ? sp : nullptr;
-        ev_j = ctx->ev[0]; ev_u[0] = ctx->ev[1]; ev_u[1] = ctx->ev[2]; ev_perm = ctx->ev[3]; ev_la = ctx->ev[4]; ev_io = ctx->ev[5];
+        ev_j = ctx->bj_ev[0]; ev_u[0] = ctx->bj_ev[1]; ev_u[1] = ctx->bj_ev[2]; ev_perm = ctx->bj_ev[3]; ev_la = ctx->bj_ev[4]; ev_io = ctx->bj_ev[5];
         if (sp != st) { JSTSP_HIP(hipEventRecord(ev_io, st)); JSTSP_HIP(hipStreamWaitEvent(sp, ev_io, 0)); }
     }
     StreamScope main_sc(ctx, sp);

@@ -326,6 +326,15 @@ int ensure_side_streams(jstsp_ctx *ctx)
     return 0;
 }
 
+int ensure_bj_resources(jstsp_ctx *ctx)
+{
+    for (int i = 0; i < 3; ++i)
+        if (!ctx->bj_stream[i]) JSTSP_HIP(hipStreamCreateWithFlags(&ctx->bj_stream[i], hipStreamNonBlocking));
+    for (int i = 0; i < 6; ++i)
+        if (!ctx->bj_ev[i]) JSTSP_HIP(hipEventCreateWithFlags(&ctx->bj_ev[i], hipEventDisableTiming));
+    return 0;
+}
+
 // Compute-unit masks: 32 of the units are set aside (4 per XCD whichever way the mask bits are dealt over the XCDs: bit
 // 32 x + 8 y + (x + y) % 8 for x < 8, y < 4 lands in XCD x under "32 consecutive bits per XCD" and in XCD (x + y) % 8 under
 // "bits dealt round-robin"), the other streams get the complement.
@@ -486,6 +495,8 @@ int jstsp_destroy(jstsp_ctx *ctx)
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->pinned_done) (void)hipEventDestroy(ctx->pinned_done);
     for (int i = 0; i < 2; ++i) if (ctx->side[i]) { (void)hipStreamSynchronize(ctx->side[i]); (void)hipStreamDestroy(ctx->side[i]); }
+    for (int i = 0; i < 3; ++i) if (ctx->bj_stream[i]) { (void)hipStreamSynchronize(ctx->bj_stream[i]); (void)hipStreamDestroy(ctx->bj_stream[i]); }
+    for (int i = 0; i < 6; ++i) if (ctx->bj_ev[i]) (void)hipEventDestroy(ctx->bj_ev[i]);
     for (int i = 0; i < 4; ++i) if (ctx->cu_stream[i]) { (void)hipStreamSynchronize(ctx->cu_stream[i]); (void)hipStreamDestroy(ctx->cu_stream[i]); }
     for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -76,6 +76,7 @@ int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos
 int lmax_from_partials_range(jstsp_ctx *ctx, const GramWS &w, int first, int count, float *lam, bool lanczos);   // matrices [first, first + count)
 // Make sure the context's side streams / events exist.
 int ensure_side_streams(jstsp_ctx *ctx);
+int ensure_bj_resources(jstsp_ctx *ctx);    // ctx->bj_stream / bj_ev (common.h)
 bool ensure_cu_streams(jstsp_ctx *ctx);     // false: no masked streams on this runtime (callers use the side streams)
 // Temporarily route the launch helpers (which use ctx->stream) to another stream.
 struct StreamScope {
