@@ -96,3 +96,23 @@ def test_sweep_runner_at_the_configs3_shape_against_the_fixture():
         assert abs(float(mean[pt, 0]) - ref.mean()) < TOL
     ma = (fx["sweep_angles/sweep_idx"] == 0) & (fx["sweep_angles/trial"] < nt)
     assert np.abs(s1[0][:, 1].numpy() - fx["sweep_angles/nmse_port"][ma]).max() < TOL
+
+
+@pytest.mark.parametrize("env", [{"JSTSP_RV_COMP": "1"}, {"JSTSP_RV_COMP": "1", "JSTSP_RV_REFRESH": "1000"}],
+                         ids=["two_float_recurrence", "two_float_recurrence_never_recomputed"])
+def test_opt_in_two_float_recurrence_on_192_trials(env, monkeypatch):
+    """JSTSP_RV_COMP=1 (v and R v carried as two floats each; admm.hip / cgemm D_lo / C_lo): with the default recomputation
+    schedule inside the accuracy statement; with R v NEVER recomputed (the configuration DESIGN.md section 6 measures at +4 %) the
+    recurrence alone must hold the distribution - rms below a third of the tolerance, no trial beyond 1.5x of it (the statement
+    itself is not claimed for that setting: one of the 256 bench trials sits at 1.2e-6)."""
+    fx = fixture()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    snr, trial = fx["sweep_proposed/snr_db"], fx["sweep_proposed/trial"]
+    rows = np.nonzero(np.isin(snr, (-15.0, 0.0, 12.0)) & (trial < 64))[0]
+    assert len(rows) == 192
+    nmse, _ = solve_group(fx, "sweep_proposed", rows, want_ce=True, angles=False, chunk=64)
+    d = nmse - fx["sweep_proposed/nmse_port"][rows]
+    never = "JSTSP_RV_REFRESH" in env
+    assert np.abs(d).max() < (1.5 * TOL if never else TOL), float(np.abs(d).max())
+    assert np.sqrt(np.mean(d ** 2)) < TOL / 3
