@@ -501,6 +501,7 @@ int jstsp_destroy(jstsp_ctx *ctx)
     for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->diag) (void)hipFree(ctx->diag);
+    if (ctx->unit) (void)hipFree(ctx->unit);
     ctx->arena.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -354,13 +354,12 @@ int jstsp_vamp_c32(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c32 *y, 
     static const jstsp_c32 one_h = {1.f, 0.f};
     if (memspace == JSTSP_HOST)
         return jstsp_vamp_kron_c32(ctx, M, N, 1, batch, y, A, strideA, &one_h, 0, sigma, Lnz, nit, x_out, memspace);
-    // device arrays: keep a device copy of the 1 x 1 identity factor in the pinned/arena-independent static
-    static float2 *one_d = nullptr;
-    if (!one_d) {
-        JSTSP_HIP(hipMalloc((void **)&one_d, sizeof(float2)));
-        JSTSP_HIP(hipMemcpy(one_d, &one_h, sizeof(float2), hipMemcpyHostToDevice));
+    // device arrays: a device copy of the 1 x 1 identity factor, owned by the context (its device, its lifetime)
+    if (!ctx->unit) {
+        JSTSP_HIP(hipMalloc((void **)&ctx->unit, sizeof(float2)));
+        JSTSP_HIP(hipMemcpy(ctx->unit, &one_h, sizeof(float2), hipMemcpyHostToDevice));
     }
-    return jstsp_vamp_kron_c32(ctx, M, N, 1, batch, y, A, strideA, reinterpret_cast<const jstsp_c32 *>(one_d), 0, sigma,
+    return jstsp_vamp_kron_c32(ctx, M, N, 1, batch, y, A, strideA, reinterpret_cast<const jstsp_c32 *>(ctx->unit), 0, sigma,
                                Lnz, nit, x_out, memspace);
 }
 
