@@ -145,3 +145,16 @@ def test_nmse_spectral_above_128():
     out = np.asarray(J.nmse_spectral(S, Zb))
     for t in range(2):
         assert abs(out[t] - O.nmse_capped(S[t], Zb[t])) < 2e-6 * max(1.0, out[t])
+
+
+def test_svt_above_128_with_more_sub_problems_than_reserved_units():
+    """40 matrices of 150 x 170: 80 pair sub-problems per round - more than the 32 compute units the masked streams set aside,
+    so the block Jacobi runs its pipeline on plain streams without an environment switch (csrc/eig_large.hip)."""
+    from oracle import solvers as O
+    rng = np.random.default_rng(21)
+    Y = 0.2 * _lowrank(rng, 40, 150, 170, 4, 1.0)
+    tau = np.linspace(0.2, 6.0, 40)
+    X = np.asarray(J.svt(Y, tau))
+    for t in (0, 13, 39):
+        ref = O.svt(Y[t], tau[t])
+        assert rel_err(X[t], ref) < 3e-5, (t, rel_err(X[t], ref))
