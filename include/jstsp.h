@@ -20,7 +20,8 @@
  *                     the GPU.  EXCEPTIONS (the host needs a value the device computed):
  *                     jstsp_proposed_algorithm_* waits for its stream up to three times - twice at
  *                     setup (the flag of the block-Toeplitz probe of B, see jstsp_last_dictionary_block)
- *                     and once at the end (the per-trial overflow flags, see jstsp_last_fused_fallbacks);
+ *                     and once at the end (the per-trial overflow flags, see jstsp_last_fused_fallbacks;
+ *                     jstsp_proposed_algorithm_begin_c32 / _end split the call there: _begin returns while the GPU works);
  *                     eigen-decompositions above order 128 (csrc/eig_large.hip) wait once per sweep.
  *    Per-problem scalar arrays (tau_Y, tau_S, rho ...) are always HOST doubles.
  *  - Return value: 0 = ok; < 0 = bad argument (JSTSP_E_*); > 0 = hipError_t of a failed
@@ -181,6 +182,25 @@ int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
                                  const double *rho, int type, const int32_t *indx_S,
                                  jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out,
                                  int memspace);
+
+/* The same solve in two phases, for arrays in DEVICE memory: _begin enqueues the whole solve and the copies into S_out / Y_out /
+ * ce_out on the context's stream and returns WITHOUT waiting for it (its only waits are the two reads of the block-Toeplitz
+ * probe at setup, i.e. for work enqueued BEFORE the solve); _end waits for the solve's completion event, looks at the per-trial
+ * overflow flags (copied to pinned host memory by _begin) and, in the pathological case that any is set, enqueues the second
+ * solve of those trials (see jstsp_last_fused_fallbacks).  Between the two calls the host is free - e.g. to prepare the next
+ * batch - and the context may be used for other work; outputs are final in stream order after _end.
+ * Contract: every array argument stays allocated, and the inputs unmodified, until _end has returned; tau_Y / tau_S / rho are
+ * copied by _begin.  Exactly one _end per _begin (it frees *pending); fallbacks may be NULL. */
+typedef struct jstsp_pending jstsp_pending;
+int jstsp_proposed_algorithm_begin_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
+                                       const jstsp_c32 *subY, const float *Omega,
+                                       const jstsp_c32 *A, long long strideA,
+                                       const jstsp_c32 *B, long long strideB,
+                                       int Imax, const double *tau_Y, const double *tau_S,
+                                       const double *rho, int type, const int32_t *indx_S,
+                                       jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out,
+                                       jstsp_pending **pending);
+int jstsp_proposed_algorithm_end(jstsp_ctx *ctx, jstsp_pending *pending, int *fallbacks);
 
 /* Trials of the last jstsp_proposed_algorithm_c32/_c64 call on this context that were solved a second time.  The default
  * iteration for N = 64 (one pass over the dictionary per iteration, csrc/fused.hip) forms `k` (proposed_algorithm.m:43) and

@@ -55,6 +55,10 @@ SIGNATURES = {
     "jstsp_proposed_algorithm_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                              c_void_p, c_ll, c_void_p, c_ll, c_int, c_dp, c_dp, c_dp, c_int,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "jstsp_proposed_algorithm_begin_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                   c_void_p, c_ll, c_void_p, c_ll, c_int, c_dp, c_dp, c_dp, c_int,
+                                                   c_void_p, c_void_p, c_void_p, c_void_p, C.POINTER(c_void_p)]),
+    "jstsp_proposed_algorithm_end": (c_int, [c_void_p, c_void_p, c_ip]),
     "jstsp_ls_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
                              c_void_p, c_int]),
     "jstsp_pinv_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]),

@@ -825,6 +825,85 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
     return 0;
 }
 
+// ---- the two-phase form for device arrays (include/jstsp.h) ---------------------------------------------------------------------
+struct jstsp_pending {
+    int N, M, Gr, G2, batch, Imax, type;
+    const jstsp_c32 *subY, *A, *B;
+    const float *Omega;
+    long long strideA, strideB;
+    const int32_t *indx_S;
+    jstsp_c32 *S_out, *Y_out;
+    double *ce_out;
+    std::vector<double> tau_Y, tau_S, rho;
+    uint32_t *flags = nullptr;          // pinned host copy of the per-trial overflow flags (NULL: the solve did not use the fused pass)
+    hipEvent_t done = nullptr;
+};
+
+extern "C" int jstsp_proposed_algorithm_begin_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *subY,
+                                                  const float *Omega, const jstsp_c32 *A, long long strideA, const jstsp_c32 *B,
+                                                  long long strideB, int Imax, const double *tau_Y, const double *tau_S,
+                                                  const double *rho, int type, const int32_t *indx_S, jstsp_c32 *S_out,
+                                                  jstsp_c32 *Y_out, double *ce_out, jstsp_pending **pending)
+{
+    JSTSP_REQUIRE(ctx && pending, JSTSP_E_NULL, "proposed_algorithm_begin: NULL context or handle pointer");
+    *pending = nullptr;
+    ctx->fused_fallbacks = 0; ctx->last_dict_block = 0;
+    PendingSolve ps;
+    JSTSP_TRY(proposed_impl(ctx, N, M, Gr, G2, batch, subY, Omega, A, strideA, B, strideB, Imax, tau_Y, tau_S, rho, type, indx_S, S_out,
+                            Y_out, ce_out, JSTSP_DEVICE, true, nullptr, &ps));
+    JSTSP_ENTER(ctx);
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), ps.dS, ps.batch * ps.g, JSTSP_DEVICE));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), ps.dY, ps.batch * ps.nm, JSTSP_DEVICE));
+    if (ps.want_ce) JSTSP_TRY(stage_out(ctx, ce_out, ps.dce, (size_t)ps.batch * 3 * ps.Imax, JSTSP_DEVICE));
+    jstsp_pending *p = new (std::nothrow) jstsp_pending();
+    JSTSP_REQUIRE(p, JSTSP_E_NOMEM, "proposed_algorithm_begin: out of host memory");
+    p->N = N; p->M = M; p->Gr = Gr; p->G2 = G2; p->batch = batch; p->Imax = Imax; p->type = type;
+    p->subY = subY; p->A = A; p->B = B; p->Omega = Omega; p->strideA = strideA; p->strideB = strideB; p->indx_S = indx_S;
+    p->S_out = S_out; p->Y_out = Y_out; p->ce_out = ce_out;
+    p->tau_Y.assign(tau_Y, tau_Y + batch); p->tau_S.assign(tau_S, tau_S + batch); p->rho.assign(rho, rho + batch);
+    hipError_t e = hipSuccess;          // (positive status = the HIP error code, as everywhere in this ABI)
+    if (ps.ovf) {
+        e = hipHostMalloc((void **)&p->flags, (size_t)batch * sizeof(uint32_t), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMemcpyAsync(p->flags, ps.ovf, (size_t)batch * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(p->done, ctx->stream);
+    const int rc = (int)e;
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (p->flags) (void)hipHostFree(p->flags);
+        if (p->done) (void)hipEventDestroy(p->done);
+        delete p;
+        set_error("proposed_algorithm_begin: could not set up the completion record: %s", hipGetErrorString(e));
+        return rc;
+    }
+    *pending = p;
+    return 0;
+}
+
+extern "C" int jstsp_proposed_algorithm_end(jstsp_ctx *ctx, jstsp_pending *p, int *fallbacks)
+{
+    JSTSP_REQUIRE(ctx && p, JSTSP_E_NULL, "proposed_algorithm_end: NULL context or handle");
+    JSTSP_ENTER(ctx);
+    int rc = 0, count = 0;
+    const hipError_t e = hipEventSynchronize(p->done);
+    if (e != hipSuccess) { set_error("proposed_algorithm_end: waiting for the solve failed: %s", hipGetErrorString(e)); rc = (int)e; }
+    std::vector<int> ovf;
+    if (!rc && p->flags)
+        for (int t = 0; t < p->batch; ++t)
+            if (p->flags[t]) ovf.push_back(t);
+    if (!rc && !ovf.empty())
+        rc = resolve_overflowed(ctx, ovf, p->N, p->M, p->Gr, p->G2, p->subY, p->Omega, p->A, p->strideA, p->B, p->strideB, p->Imax,
+                                p->tau_Y.data(), p->tau_S.data(), p->rho.data(), p->type, p->indx_S, p->S_out, p->Y_out, p->ce_out,
+                                JSTSP_DEVICE, &count);
+    ctx->fused_fallbacks = count;
+    if (fallbacks) *fallbacks = count;
+    if (p->flags) (void)hipHostFree(p->flags);
+    (void)hipEventDestroy(p->done);
+    delete p;
+    return rc;
+}
+
 namespace jstsp {
 // (solver_common.h: the phases of a pipelined host call for c64.hip, which stages - and narrows - its inputs itself)
 int proposed_enqueue_device(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *subY, const float *Omega,

@@ -179,6 +179,64 @@ def proposed_algorithm(subY, Omega, A, B, Imax, tau_Y, tau_S, rho, type="approxi
     return fS(sq), fY(sq), (fce(sq) if want_ce else None)
 
 
+class PendingSolve:
+    """Handle of :func:`proposed_algorithm_begin`: the solve is running on the context's stream; :meth:`end` completes it and
+    returns ``(S, Y, convergence_error)``.  Keeps every array of the call alive until then."""
+
+    def __init__(self, ctx, handle, keep, result):
+        self._ctx, self._h, self._keep, self._result = ctx, handle, keep, result
+        self.fallbacks = None
+
+    def end(self):
+        if self._h is None:
+            raise JstspError("this solve has already been completed")
+        n = C.c_int(0)
+        h, self._h = self._h, None
+        check(self._ctx._lib.jstsp_proposed_algorithm_end(self._ctx.handle, h, C.byref(n)), "jstsp_proposed_algorithm_end")
+        self.fallbacks = int(n.value)
+        self._keep = None
+        return self._result
+
+
+def proposed_algorithm_begin(subY, Omega, A, B, Imax, tau_Y, tau_S, rho, type="approximate", *, indx_S=None, want_ce=True,
+                             ctx=None):
+    """The two-phase form of :func:`proposed_algorithm` for torch CUDA tensors (include/jstsp.h:
+    jstsp_proposed_algorithm_begin_c32 / _end): enqueues the solve and returns a :class:`PendingSolve` without waiting for the
+    GPU; ``handle.end()`` returns the outputs.  Between the two the host is free (e.g. to build the next batch)."""
+    a_sub = _Arg(subY, np.complex64, "subY")
+    a_om = _Arg(Omega, np.float32, "Omega")
+    a_A = _Arg(A, np.complex64, "A")
+    a_B = _Arg(B, np.complex64, "B")
+    a_ix = _Arg(None, np.int32, "indx_S", allow_none=True)
+    batch, N, M = a_sub.batch, a_sub.R, a_sub.C
+    Gr, G2 = a_A.C, a_B.R
+    if (a_om.batch, a_om.R, a_om.C) != (batch, N, M):
+        raise ValueError("Omega must have the shape of subY")
+    if a_A.R != N or a_B.C != M:
+        raise ValueError("size(A,1) must equal size(subY,1) and size(B,2) must equal size(subY,2)")
+    if indx_S is not None:
+        import torch
+        a_ix = _Arg(indx_S.reshape(batch, Gr * G2, 1).to(torch.int32).contiguous(), np.int32, "indx_S")
+    c, mem, dev = _ctx_for([a_sub, a_om, a_A, a_B, a_ix], ctx)
+    if mem != DEVICE:
+        raise ValueError("proposed_algorithm_begin takes torch CUDA tensors (a host call has nothing to overlap: use proposed_algorithm)")
+    sA = _shared_stride(a_A, N * Gr, batch, "A")
+    sB = _shared_stride(a_B, G2 * M, batch, "B")
+    tY, ptY = _scalars(tau_Y, batch, "tau_Y")
+    tS, ptS = _scalars(tau_S, batch, "tau_S")
+    rh, prh = _scalars(rho, batch, "rho")
+    pS, fS = _out(True, batch, Gr, G2, np.complex64, dev)
+    pY, fY = _out(True, batch, N, M, np.complex64, dev)
+    pce, fce = _out(True, batch, int(Imax), 3, np.float64, dev) if want_ce else (None, None)
+    tcode = _lib.TYPE_APPROXIMATE if type == "approximate" else _lib.TYPE_STD
+    h = C.c_void_p()
+    check(c._lib.jstsp_proposed_algorithm_begin_c32(c.handle, N, M, Gr, G2, batch, a_sub.ptr, a_om.ptr, a_A.ptr, sA, a_B.ptr, sB,
+                                                    int(Imax), ptY, ptS, prh, tcode, a_ix.ptr, pS, pY, pce, C.byref(h)),
+          "jstsp_proposed_algorithm_begin_c32")
+    sq = not a_sub.batched
+    return PendingSolve(c, h, (a_sub, a_om, a_A, a_B, a_ix, tY, tS, rh), (fS(sq), fY(sq), (fce(sq) if want_ce else None)))
+
+
 def proposed_algorithm_angles(subY, Omega, indx_S, A, B, Imax, tau_Y, tau_S, rho, type="approximate",
                               greedy_nnz=None, *, want_ce=True, ctx=None):
     """basic_system_functions/proposed_algorithm_angles.m:1 (``greedy_nnz`` is unused there too).
