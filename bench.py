@@ -66,6 +66,52 @@ def parse():
     return ap.parse_args()
 
 
+class HipHooks:
+    """What bench.py calls to build inputs, solve and score: the HIP library (the product).  tests/bench_stub.py replaces it
+    (JSTSP_BENCH_HOOKS=module:attr, CPU tier only) with a deterministic stand-in over the gloo backend, so that the rank /
+    partition / barrier / all-reduce code of THIS file runs under world_size 2 without a GPU (tests/test_bench_gloo.py); a
+    line produced that way carries "data": "stub" and is not a measurement."""
+    stub = False
+    backend = "nccl"
+
+    @staticmethod
+    def device(local):
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    @staticmethod
+    def sync():
+        torch.cuda.synchronize()
+
+    @staticmethod
+    def make_inputs(p, ids, device, shared_pilots):
+        return make_inputs(p, ids, device, shared_pilots)
+
+    @staticmethod
+    def solve(inp, imax, want_ce):
+        import jstsp19_amd as J
+        return J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], imax, inp["tau_Y"], inp["tau_Z"], inp["rho"],
+                                    "approximate", want_ce=want_ce)
+
+    @staticmethod
+    def nmse(S, inp):
+        import jstsp19_amd as J
+        return J.nmse_spectral(S, J.colmajor(inp["Zbar"].to(torch.complex64)))
+
+    @staticmethod
+    def sweep_kw():
+        return {}
+
+
+def load_hooks():
+    spec = os.environ.get("JSTSP_BENCH_HOOKS")
+    if not spec:
+        return HipHooks
+    import importlib
+    mod, attr = spec.split(":")
+    return getattr(importlib.import_module(mod), attr)
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (torch.distributed.run, one
     per GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU, pass their output through and return their exit
@@ -114,7 +160,7 @@ def emit(line, dist, rank):
         print(json.dumps(line), flush=True)
 
 
-def sweep_mode(a, rank, world, dist, device):
+def sweep_mode(a, rank, world, dist, device, hooks=HipHooks):
     """BASELINE configs[3]: the plot_errorVSsnr.m:48-180 sweep at the configs[1] shape - 10 SNR points x `sweep_trials`
     realisations, each solved by proposed_algorithm (:137) and proposed_algorithm_angles (:144), the (point, trial) pairs
     in contiguous blocks per rank, inputs built on the device, ONE all-reduce of the per-point NMSE sums (:170)."""
@@ -126,18 +172,18 @@ def sweep_mode(a, rank, world, dist, device):
     else:
         base, snrs = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8), list(range(-15, 15, 3))
         shape = "Nt=Nr=64 Nrf=8 K=64 L=8 (N=64 M=4096 Gr=64 G2=512)"
-    kw = dict(Imax=IMAX, batch=a.batch, device=device, dist=dist)
+    kw = dict(Imax=IMAX, batch=a.batch, device=device, dist=dist, **hooks.sweep_kw())
     run_sweep(base, snrs[:1], min(a.batch, 8) * world, **kw)     # priming: workspace + kernels (setup, not timed)
-    torch.cuda.synchronize()
+    hooks.sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    hooks.sync()
     t0 = time.perf_counter()
     out = run_sweep(base, snrs, a.sweep_trials, **kw)
-    torch.cuda.synchronize()
+    hooks.sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    hooks.sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist is not None:
@@ -149,7 +195,7 @@ def sweep_mode(a, rank, world, dist, device):
         line = {"metric": "channel-estimates/sec (batched MC) at Nt=Nr=64,K=64; NMSE vs ref",
                 "value": round(solves / dt, 3), "unit": "channel-estimates/s", "n_gpus": world, "steps": 1, "warmup": 0,
                 "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": "c32", "data": "synthetic",
+                "dtype": "c32", "data": "stub" if hooks.stub else "synthetic",
                 "config": {"workload": "plot_errorVSsnr sweep (BASELINE configs[3]): %s, %d SNR points x %d realisations, "
                                        "proposed_algorithm + proposed_algorithm_angles per realisation, Imax=%d, (point, trial) "
                                        "pairs sharded over ranks, one all-reduce of the NMSE sums" % (shape, len(snrs),
@@ -173,19 +219,20 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
                  "--nproc-per-node %d ... bench.py --gpus %d), or run `python bench.py --gpus %d` without a launcher"
                  % (a.gpus, world, a.gpus, a.gpus, a.gpus))
+    hooks = load_hooks()
+    device = hooks.device(local)
     # JSTSP_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL path on a 1-GPU box)
     if world > 1 or os.environ.get("JSTSP_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if hooks.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(hooks.backend)
     else:
         dist = None
-        torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
 
-    import jstsp19_amd as J
     from jstsp19_amd.system_model import SweepParams
 
     if a.small:   # plot_errorVSsnr.m:8-25
@@ -198,16 +245,14 @@ def main():
     want_ce = not a.no_ce
 
     if a.sweep:
-        sweep_mode(a, rank, world, dist, device)
+        sweep_mode(a, rank, world, dist, device, hooks)
         return
 
     ids = list(range(rank * a.batch, (rank + 1) * a.batch))
-    inp = make_inputs(p, ids, device, a.shared_pilots)
-    ctx = J.default_context(local)
+    inp = hooks.make_inputs(p, ids, device, a.shared_pilots)
 
     def step():
-        return J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], IMAX, inp["tau_Y"],
-                                    inp["tau_Z"], inp["rho"], "approximate", want_ce=want_ce)
+        return hooks.solve(inp, IMAX, want_ce)
 
     def barrier():
         if dist is not None:
@@ -215,19 +260,18 @@ def main():
 
     # one-iteration priming call: sizes the library's workspace and loads the kernels (setup, not a step), so that
     # the timing does not depend on --warmup being >= 1
-    J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], 1, inp["tau_Y"], inp["tau_Z"], inp["rho"],
-                         "approximate", want_ce=want_ce)
+    hooks.solve(inp, 1, want_ce)
     for _ in range(a.warmup):
         out = step()
-    torch.cuda.synchronize()
+    hooks.sync()
     barrier()
-    torch.cuda.synchronize()
+    hooks.sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
-    torch.cuda.synchronize()
+    hooks.sync()
     barrier()
-    torch.cuda.synchronize()
+    hooks.sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist is not None:
@@ -236,12 +280,25 @@ def main():
 
     S, Y, ce = out
     # NMSE per trial (plot_errorVSsnr.m:138-141), one all-reduce of the sum (:170 takes the mean)
-    nmse = J.nmse_spectral(S, J.colmajor(inp["Zbar"].to(torch.complex64)))
+    nmse = hooks.nmse(S, inp)
     acc = torch.stack([nmse.sum(), torch.tensor(float(a.batch), dtype=torch.float64, device=device)])
     if dist is not None:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
     mean_nmse = float(acc[0] / acc[1])
 
+    if hooks.stub:      # CPU-tier run of this file's distributed plumbing: no library, no measurement legs
+        line = None
+        if rank == 0:
+            line = {"metric": "channel-estimates/sec (batched MC) at Nt=Nr=64,K=64; NMSE vs ref", "value": round(a.batch * world * a.steps / dt, 3),
+                    "unit": "channel-estimates/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                    "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "stub", "data": "stub", "config": {"workload": workload, "trials_per_gpu_per_step": a.batch},
+                    "mean_nmse": mean_nmse, "trial_ids_rank0": [ids[0], ids[-1]]}
+        emit(line, dist, rank)
+        return
+
+    import jstsp19_amd as J
+    ctx = J.default_context(local)
     extra = {}
     # Informational, NOT the headline: the same step with the opt-in short-cut JSTSP_SVT_SKIP=1 (a trial whose svt threshold
     # is below 2^-27 max|Z| - every entry of Z - svt(Z, tau) is bounded by tau, so Y = Z is the fp32 answer - skips its
@@ -267,10 +324,37 @@ def main():
             step(); torch.cuda.synchronize()
             t1 = time.perf_counter()
             step(); torch.cuda.synchronize()
-            extra["strict_fp32_mfma"] = {"value": round(a.batch / (time.perf_counter() - t1), 1), "unit": "channel-estimates/s",
-                                         "env": "JSTSP_H2=0", "note": "informational; every contraction on the fp32 matrix pipe (157 TFLOP/s peak)"}
+            strict = {"value": round(a.batch / (time.perf_counter() - t1), 1), "unit": "channel-estimates/s",
+                      "env": "JSTSP_H2=0", "note": "informational; every contraction on the fp32 matrix pipe (157 TFLOP/s peak)"}
+            # its own roofline: one more step with HIP events around the two big contractions of the three-kernel iteration,
+            # K B^H (proposed_algorithm.m:47) and (A S) B with the C / V2 update (:58,:61,:65), both cgemm_kernel instances on
+            # v_mfma_f32_32x32x2_f32.  Algorithmic flops per launch = 8 N M G2 per trial, priced against
+            # the dense fp32-MFMA peak: "complex-fp32 MFMA as specified" beside "split-f16 as shipped" (`roofline` below).
+            ctx.set_profiling(True)
+            step(); torch.cuda.synchronize()
+            prof = {k: ctx.get_profile(k) for k in ("correlate", "synthesize")}
+            ctx.set_profiling(False)
+            fl = 8.0 * N * M * G2 * a.batch
+            rl = {}
+            for k, what in (("correlate", "K B^H (:47), Gauss 3-multiplication complex products, fp64 master accumulators"),
+                            ("synthesize", "(A S) B + C / V2 update in the epilogue (:58,:61,:65)")):
+                n_k, ms_k = prof[k]
+                if n_k:
+                    avg = ms_k / n_k
+                    rl[k] = {"kernel": "cgemm_kernel (v_mfma_f32_32x32x2_f32): " + what, "avg_launch_ms": round(avg, 4), "launches": n_k,
+                             "achieved": round(fl / (avg * 1e-3) / 1e12, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(fl / (avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "flops_per_launch": fl}
+            if rl:
+                dom = max(rl, key=lambda k: rl[k]["avg_launch_ms"])
+                strict["roofline"] = dict(rl[dom], bound="mfma", other={k: v for k, v in rl.items() if k != dom})
+                # whole-estimate view: SURVEY section 8d counts 262 GFLOP per estimate (2.62 per iteration)
+                strict["whole_estimate_tflops"] = round(strict["value"] * 262.0e9 / 1e12, 1)
+                strict["whole_estimate_frac_of_fp32_mfma_peak"] = round(strict["value"] * 262.0e9 / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+                strict["kernel_table"] = "profiles/r05_strict_fp32_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `JSTSP_H2=0 python bench.py`)"
+            extra["strict_fp32_mfma"] = strict
         finally:
             os.environ.pop("JSTSP_H2", None)
+            ctx.set_profiling(False)
 
     # ---- roofline of the dominant kernel: one extra untimed step with HIP events on the launch stream
     ctx.set_profiling(True)

@@ -105,6 +105,10 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *   JSTSP_HOST_PIPELINE=0 a JSTSP_HOST proposed_algorithm call of 128 or more problems as ONE staged solve (default: its two halves on
  *                         two internal contexts, the upload of the second overlapping the solve of the first)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
+ *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous
+ *                         iteration's Ritz vector)
+ *   JSTSP_LANCZOS_VERIFY=n  a warm-started lambda_max is checked against the cold run every n-th call per matrix (default 32;
+ *                         0 never, 1 always - then every returned value is the cold one; jstsp_last_lanczos_mismatches)
  *   JSTSP_EIG128=0        general Jacobi kernel (basis in HBM) for Gram orders 65..128
  *   JSTSP_OMP_GRAM=0      jstsp_omp_kron: measurement-space OMP instead of the coefficient-domain kernel
  *   JSTSP_BJ_MASK=0       block Jacobi (orders above 128) without streams restricted to a subset of the compute units
@@ -211,6 +215,21 @@ int jstsp_proposed_algorithm_end(jstsp_ctx *ctx, jstsp_pending *pending, int *fa
  * is involved: the call returns the same results as the three-kernel iteration for them.  *count is 0 for every input
  * that is a measurement of the reference's system model. */
 int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count);
+
+/* Spectral norms inside the ADMM loops (convergence_error of proposed_algorithm.m:67,69, sparse_admm.m:32, mc_admm.m:28):
+ * lambda_max of each Gram is computed by a Lanczos run that starts from the Ritz vector of the SAME matrix one iteration
+ * earlier and stops when the residual of the Ritz pair is below 1e-5 lambda (a cold n-step run otherwise, and always at the
+ * first iteration).  Every JSTSP_LANCZOS_VERIFY-th call per matrix (default 32, staggered over the matrices) the cold run is
+ * done as well and its value returned; *count = how many of those checks of the last solve on this context differed from
+ * the warm-started value by more than 2e-5 relative (0 on every input measured so far; one stream synchronisation). */
+int jstsp_last_lanczos_mismatches(jstsp_ctx *ctx, int *count);
+
+/* lambda_max of a sequence of batches of Hermitian matrices (n <= 128): G is [steps][batch][n*n] column-major, lam is
+ * [steps][batch] floats.  Matrix t of step s is warm-started from matrix t of step s - 1, exactly as the ADMM loops drive the
+ * kernel for convergence_error (proposed_algorithm.m:67,69; sparse_admm.m:32; mc_admm.m:28) - the entry exists so that the
+ * tracking can be checked on spectra the solvers do not produce (flat, clustered, crossing eigenvalues).  Accuracy of each
+ * value: 2e-5 relative (residual of the Ritz pair below 1e-5 lambda; typically 1e-6), a cold run's 1.5e-6 at step 0. */
+int jstsp_lambda_max_sequence_c32(jstsp_ctx *ctx, int n, int batch, int steps, const jstsp_c32 *G, float *lam, int memspace);
 
 /* Structure the last jstsp_proposed_algorithm_c32/_c64 call on this context found in its dictionary B (G2 x M).  The
  * dictionaries of the reference's drivers stack L delayed copies of one pilot frame under the transmit steering vectors

@@ -64,6 +64,7 @@ SIGNATURES = {
     "jstsp_pinv_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
     "jstsp_last_conditioning": (c_int, [c_void_p, c_dp, c_dp]),
     "jstsp_last_fused_fallbacks": (c_int, [c_void_p, c_ip]),
+    "jstsp_last_lanczos_mismatches": (c_int, [c_void_p, c_ip]),
     "jstsp_last_dictionary_block": (c_int, [c_void_p, c_ip]),
     "jstsp_svt_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_dp, c_void_p, c_int]),
     "jstsp_omp_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_ll, c_void_p, c_int, c_void_p,
@@ -83,6 +84,7 @@ SIGNATURES = {
                                c_void_p, c_int]),
     "jstsp_vamp_kron_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
                                     C.c_double, C.c_double, c_int, c_void_p, c_int]),
+    "jstsp_lambda_max_sequence_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
     "jstsp_nmse_spectral_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "jstsp_build_trials_c32": (c_int, [c_void_p, C.POINTER(Model), C.c_uint64, c_int, c_ll, c_int, C.POINTER(Trials),
                                        c_int]),
@@ -186,6 +188,12 @@ class Context:
         """Trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass."""
         n = C.c_int(0)
         check(self._lib.jstsp_last_fused_fallbacks(self.handle, C.byref(n)), "jstsp_last_fused_fallbacks")
+        return int(n.value)
+
+    def last_lanczos_mismatches(self):
+        """Periodic cold checks of the last solve's warm-started lambda_max values that disagreed (2e-5 relative)."""
+        n = C.c_int(0)
+        check(self._lib.jstsp_last_lanczos_mismatches(self.handle, C.byref(n)), "jstsp_last_lanczos_mismatches")
         return int(n.value)
 
     def last_dictionary_block(self):

@@ -476,6 +476,39 @@ int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp
     return 0;
 }
 
+int jstsp_lambda_max_sequence_c32(jstsp_ctx *ctx, int n, int batch, int steps, const jstsp_c32 *G_, float *lam, int memspace)
+{
+    // lambda_max of a SEQUENCE of batches of Hermitian matrices, matrix t of step s warm-started from matrix t of step s - 1:
+    // the kernel behind convergence_error(:,1:2) (proposed_algorithm.m:67,69) as the ADMM loops drive it, on the caller's matrices
+    JSTSP_TRY(check_common(ctx, memspace));
+    JSTSP_ENTER(ctx);
+    JSTSP_REQUIRE(G_ && lam, JSTSP_E_NULL, "lambda_max_sequence: NULL argument");
+    JSTSP_REQUIRE(n > 0 && n <= 128 && batch > 0 && steps > 0, JSTSP_E_SHAPE, "lambda_max_sequence: 1 <= n <= 128, batch, steps > 0");
+    const size_t nn = (size_t)n * n, tot = (size_t)steps * batch;
+    size_t need = rnd256((size_t)batch * lanczos_ne(n) * sizeof(float2)) + rnd256((size_t)batch * sizeof(int)) + rnd256(tot * sizeof(float));
+    if (memspace == JSTSP_HOST) need += rnd256(tot * nn * sizeof(float2));
+    JSTSP_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    const float2 *G;
+    JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(G_), tot * nn, memspace, &G));
+    GramWS w;                                   // (only the warm-start record and the shape are used)
+    w.n = n; w.batch = batch; w.nsplit = 1;
+    w.lz.ne = lanczos_ne(n);
+    w.lz.x = ctx->arena.get<float2>((size_t)batch * w.lz.ne);
+    w.lz.state = ctx->arena.get<int>((size_t)batch);
+    float *o = ctx->arena.get<float>(tot);
+    JSTSP_REQUIRE(w.lz.x && w.lz.state && o, JSTSP_E_NOMEM, "lambda_max_sequence: workspace exhausted");
+    JSTSP_TRY(lanczos_warm_reset(ctx, w));
+    for (int s = 0; s < steps; ++s) {
+        w.lz.call = s;
+        JSTSP_TRY(launch_lmax(ctx, n, batch, G + (size_t)s * batch * nn, (long long)nn, 1, 0, o + (size_t)s * batch, true,
+                              w.lz.mismatch ? &w.lz : nullptr, 0));
+    }
+    JSTSP_TRY(stage_out(ctx, lam, o, tot, memspace));
+    if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int jstsp_rate_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S_, const jstsp_c32 *Zbar_,
                    double noise_var, double *rate, int memspace)
 {
@@ -606,6 +639,7 @@ int jstsp_mc_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c32
     JSTSP_HIP(hipMemsetAsync(Zn, 0, batch * nm * sizeof(float2), st));
     JSTSP_TRY(launch_inv_d(ctx, (long long)nm, batch, Omega, 1.f, prm, invD));        // :11-17  A = diag(Omega) + rho I
     if (want_ce) JSTSP_TRY(sigma_max_sq(ctx, wn, Htrue, den));
+    if (want_ce) JSTSP_TRY(lanczos_warm_reset(ctx, wn));       // the error curve's lambda_max, warm-started from iteration to iteration
     const long long tot = (long long)batch * nm;
     for (int it = 0; it < Imax; ++it) {                                               // :20
         JSTSP_TRY(svt_batched(ctx, w, Zn, prm, nullptr, X, true));                    // :22  X = svt(Y - Z/rho, tau/rho)

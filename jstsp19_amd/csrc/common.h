@@ -69,6 +69,8 @@ struct Tuning {
     int overlap = -1;       // JSTSP_OVERLAP: side streams between the kernels of an iteration (-1: on with the fused pass)
     int svt_skip = 0;       // JSTSP_SVT_SKIP: 1 trials whose threshold is below fp32 resolution skip the eigen-decomposition (opt-in)
     int lanczos = 1;        // JSTSP_LANCZOS: 0 Householder + Sturm instead of Lanczos for the convergence_error norms
+    int lanczos_warm = 1;   // JSTSP_LANCZOS_WARM: 0 every lambda_max of an ADMM loop by the cold n-step Lanczos run (rounds 2-4)
+    int lanczos_verify = 32; // JSTSP_LANCZOS_VERIFY: every this many calls a warm-started lambda_max is checked against the cold run (0: never, 1: always)
     int eig128 = 1;         // JSTSP_EIG128: 0 general Jacobi kernel for Gram orders 65..128
     int omp_gram = 1;       // JSTSP_OMP_GRAM: 0 measurement-space OMP on a Kronecker dictionary
     int grad_head = 0;      // JSTSP_GRAD_HEAD: bit 0 - Res / P1 of the gradient step, bit 1 - the first factor of a recomputed R v, on the
@@ -142,6 +144,9 @@ struct jstsp_ctx {
     // float bits of [0] the smallest sigma_min/sigma_max met by the float64 pinv kernel, [1] the largest Newton-Schulz
     // residual max|I - G X|, [2] the smallest lambda_min/lambda_max of an eigen-inverted factor Gram
     uint32_t *diag = nullptr;
+    // [0] warm-started lambda_max values of the last ADMM solve that a periodic cold verification contradicted (eig2.hip:
+    // lanczos_lmax_kernel; jstsp_last_lanczos_mismatches), device memory
+    unsigned *lz_mismatch = nullptr;
     int last_dict_block = 0;     // block height of the block-Toeplitz structure the last fused solve found in its dictionary (0: none)
     int fused_fallbacks = 0;     // trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass
     float2 *unit = nullptr;      // device copy of the 1 x 1 identity factor (vamp.hip: the dense call is the Kronecker call with it)
@@ -281,8 +286,17 @@ int launch_eig128(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long lo
                   const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm = nullptr, int warm = 0,
                   int max_sweeps = 16);
 int eig_fast_ne(int n);           // padded order (32 or 64) of the warm-start basis
+// Warm-start record of the Lanczos lambda_max kernel (eig2.hip): per matrix the Ritz vector of the previous call.
+struct LanczosWarm {
+    float2 *x = nullptr;            // [count][ne] Ritz vectors
+    int *state = nullptr;           // [count] 0: no vector yet, 1: x valid
+    unsigned *mismatch = nullptr;   // [1] periodic cold verifications that disagreed with the warm-started value
+    int ne = 0;                     // lanczos_ne(n)
+    int call = 0;                   // call counter of the owning loop (staggers the verification over the matrices)
+};
+int lanczos_ne(int n);            // padded order (64 or 128) of the warm-start vectors
 int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
-                float *lam_out, bool lanczos = false);   // true: pass Vg = batch * ne*ne float2 (ne = n rounded up to even)
+                float *lam_out, bool lanczos = false, const LanczosWarm *lw = nullptr, int first = 0);
 
 // ---- fused element-wise / reduction kernels (admm.hip) -----------------------------------
 int launch_form_z(jstsp_ctx *ctx, long long nm, int batch, const float2 *X, const float2 *V1,

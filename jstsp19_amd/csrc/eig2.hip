@@ -524,27 +524,127 @@ __global__ __launch_bounds__(256) void lmax_kernel(int n, const float2 *Gpart, l
 // over the wave's columns (v_k broadcast by v_readlane), an exchange of the four partial products through a
 // double-buffered 4 KiB of LDS, and two wave reductions that every wave repeats identically (same operands, same
 // order: the copies of v stay bitwise equal).
-// n steps (or until the Krylov space is exhausted) without reorthogonalisation: the largest Ritz value converges
-// first and stays converged (ghost copies do not move it); measured against float64 on Gram matrices with flat,
-// clustered, graded (1e-8) and structured low-rank spectra: <= 1.5e-6 relative, typically 1e-7.  The
-// convergence_error ratios of proposed_algorithm.m:67,69 take this path (three matrices per trial and iteration);
-// the Householder + Sturm kernel above (1e-7) stays for jstsp_nmse_spectral_c32.  Largest eigenvalue of the
-// tridiagonal matrix by 64-way multisection on the Sturm count, d / e^2 held one entry per lane.
+//
+// COLD (no warm-start record, or no usable vector in it): n steps from a generic start vector (or until the Krylov space is
+// exhausted) without reorthogonalisation: the largest Ritz value converges first and stays converged (ghost copies do not
+// move it); measured against float64 on Gram matrices with flat, clustered, graded (1e-8) and structured low-rank spectra:
+// <= 1.5e-6 relative, typically 1e-7.  Largest eigenvalue of the tridiagonal matrix by 256-way multisection on the Sturm count.
+//
+// WARM (round 5; the convergence_error norms of proposed_algorithm.m:67,69 and sparse_admm.m:32 / mc_admm.m:28 ask for
+// lambda_max of matrices that barely move from one ADMM iteration to the next): the Ritz vector of the previous call is the
+// start vector.  Phase 0 runs at most LZ_KMAX steps from it; after each step from the LZ_KMIN-th on, wave 0 takes the top
+// Ritz pair (theta, y) of the small tridiagonal T_m (64-way multisection, then the eigenvector by the twisted factorisation
+// of T_m - theta I: both recurrences run in their stable direction) and stops when the residual of the Ritz pair,
+// ||G x - theta x|| = beta_m |y_m|, is below tol * theta (1e-5: the eigenvalue itself is then right to
+// min(res, res^2 / gap), i.e. to fp32 resolution for every gap above 1e-3); the new Ritz vector x = sum_i y_i v_i comes from
+// the m start-up vectors wave 0 kept in LDS.  If phase 0 does not converge the matrix is done COLD (phase 1: generic start,
+// n steps, multisection - exactly the cold path) and a fresh Ritz vector is formed for the next call: y from the twisted
+// factorisation of the full T_m (wave 0, serial), then the SAME recurrence is run once more (phase 2: same code, same bits)
+// accumulating x = sum_j y_j v_j - no n x n basis is ever stored.
+// A residual test cannot tell the largest eigenpair from another one, and a vector that tracked the largest eigenvalue
+// through an exact crossing would keep following the wrong branch.  So every `vperiod`-th call (staggered over the matrices
+// by their index) a converged phase 0 is followed by the cold phase 1 anyway: its value is the one returned, a relative
+// difference above 2e-5 counts as a mismatch (device counter, reported per solve) and replaces the vector.
 // NW waves per matrix (4: lowest latency - the default of rounds 1-2; 1: no exchange, no barrier, no redundant reductions -
 // a quarter of the instructions per matrix at four times the latency)
-template <int NE, int NW>
-__global__ __launch_bounds__(64 * NW) void lanczos_lmax_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
-                                                           long long sGs, float *lam_out)
+constexpr int LZ_KMAX = 12, LZ_KMIN = 3;
+
+__device__ __forceinline__ float lz_guard(float d) { return fabsf(d) < 1e-30f ? (d < 0.f ? -1e-30f : 1e-30f) : d; }
+
+// Largest eigenvalue of the m x m tridiagonal matrix (diagonal sd[0..m-1], squared off-diagonals se[0..m-2]) by ONE wave:
+// five rounds of 64-way multisection on the Sturm count between max(diag) and the Gershgorin bound.
+__device__ __forceinline__ float lz_top_small(const float *sd, const float *se, int m, int lane)
+{
+    float lo = sd[0], hi = -3.0e38f;
+    for (int i = 0; i < m; ++i) {
+        const float r = (i > 0 ? sqrtf(se[i - 1]) : 0.f) + (i + 1 < m ? sqrtf(se[i]) : 0.f);
+        lo = fmaxf(lo, sd[i]);
+        hi = fmaxf(hi, sd[i] + r);
+    }
+    const float span0 = fmaxf(hi - lo, 1e-30f);
+    lo -= 1e-6f * fabsf(lo) + 1e-30f;           // count(lo) < m strictly
+    hi += 1e-6f * span0 + 1e-30f;
+    for (int round = 0; round < 5; ++round) {
+        const float step = (hi - lo) / 65.f;
+        const float x = lo + (lane + 1) * step;
+        float q = 1.f, eprev = 0.f;
+        int c = 0;
+        for (int i = 0; i < m; ++i) {
+            q = (sd[i] - x) - eprev * __builtin_amdgcn_rcpf(q);
+            if (fabsf(q) < 1e-30f) q = -1e-30f;
+            c += (q < 0.f);
+            eprev = se[i];
+        }
+        const unsigned long long full = __ballot(c >= m);
+        const int first = full ? (int)__ffsll((long long)full) - 1 : 64;
+        const float nlo = lo + first * step;
+        const float nhi = (first < 64) ? lo + (first + 1) * step : hi;
+        lo = nlo; hi = nhi;
+    }
+    return 0.5f * (lo + hi);
+}
+
+// Eigenvector of the m x m tridiagonal matrix for the (approximate) eigenvalue th by the twisted factorisation of T - th I:
+// pivots of the factorisation from the top (sdp) and from the bottom (sdm), the twist index r where |gamma_r| is smallest,
+// then y_r = 1 and both recurrences away from r.  Every lane of the calling wave runs the same serial code (uniform LDS
+// addresses); y goes to sy[0..m-1] UNNORMALISED, the return value is ||y||^2.
+__device__ __forceinline__ float lz_twisted(const float *sd, const float *se, int m, float th, float *sdp, float *sdm, float *sy)
+{
+    float dp = sd[0] - th;
+    sdp[0] = dp;
+    for (int i = 1; i < m; ++i) {
+        dp = (sd[i] - th) - se[i - 1] * __builtin_amdgcn_rcpf(lz_guard(dp));
+        sdp[i] = dp;
+    }
+    float dm = sd[m - 1] - th;
+    sdm[m - 1] = dm;
+    for (int i = m - 2; i >= 0; --i) {
+        dm = (sd[i] - th) - se[i] * __builtin_amdgcn_rcpf(lz_guard(dm));
+        sdm[i] = dm;
+    }
+    int r = 0;
+    float best = 3.0e38f;
+    for (int i = 0; i < m; ++i) {
+        const float g = fabsf(sdp[i] + sdm[i] - (sd[i] - th));
+        if (g < best) { best = g; r = i; }
+    }
+    float y = 1.f, nrm = 1.f;
+    sy[r] = 1.f;
+    for (int i = r; i + 1 < m; ++i) {
+        y = -sqrtf(se[i]) * y * __builtin_amdgcn_rcpf(lz_guard(sdm[i + 1]));
+        sy[i + 1] = y;
+        nrm += y * y;
+    }
+    y = 1.f;
+    for (int i = r; i > 0; --i) {
+        y = -sqrtf(se[i - 1]) * y * __builtin_amdgcn_rcpf(lz_guard(sdp[i - 1]));
+        sy[i - 1] = y;
+        nrm += y * y;
+    }
+    return nrm;
+}
+
+template <int NE, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void lanczos_lmax_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
+                                                           long long sGs, float *lam_out, float2 *wx, int *wst,
+                                                           unsigned *wmis, int call, int vperiod, float tol)
 {
     constexpr int R = NE / 64;              // components per lane
     constexpr int KW = NE / NW;             // columns of G per wave
     constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    // LDS: only the exchange of the partial products and the tridiagonal matrix (round 3: the matrix itself is no longer
-    // staged here - 33 KiB per workgroup for the kernel's whole life kept eigen-decomposition workgroups, 101 KiB, off the CU)
+    // LDS: the exchange of the partial products, the tridiagonal matrix, and (warm start) the first LZ_KMAX Lanczos vectors
+    // (round 3: the matrix itself is no longer staged here - 33 KiB per workgroup for the kernel's whole life kept
+    // eigen-decomposition workgroups, 101 KiB, off the CU)
     float2 *part = reinterpret_cast<float2 *>(smem_raw);       // [2][NW waves][NE] partial products
-    int *sflag = reinterpret_cast<int *>(part + 2 * NW * NE);   // [2]: wave 0's "Krylov space exhausted" of step j, slot j & 1
-    float *sd = reinterpret_cast<float *>(sflag + 4);          // [NE] d, [NE] e2, then [2][4] firsts, then m
+    int *sflag = reinterpret_cast<int *>(part + 2 * NW * NE);   // [2]: wave 0's verdict on step j, slot j & 1
+    float *sd = reinterpret_cast<float *>(sflag + 4);          // [NE] d, [NE] e2, then [2][4] firsts, m, ...
+    float *se = sd + NE;
+    int *sfirst = reinterpret_cast<int *>(se + NE);             // [12]
+    float *sy = reinterpret_cast<float *>(sfirst + 12);         // [NE] eigenvector of T
+    float *sdp = sy + NE, *sdm = sdp + NE;                      // [NE] each: pivots of the twisted factorisation
+    float *sres = sdm + NE;                                     // [4]
+    float2 *vb = reinterpret_cast<float2 *>(sres + 4);          // [LZ_KMAX][NE] start-up vectors of phase 0 (wave 0's copy)
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // this wave's columns straight from memory: lane i owns row i (coalesced), the split-K partials summed on the way.
@@ -585,162 +685,248 @@ __global__ __launch_bounds__(64 * NW) void lanczos_lmax_kernel(int n, const floa
         return (bcast(x, 0) + bcast(x, 16)) + (bcast(x, 32) + bcast(x, 48));
     };
 
-    // generic start vector: no structured eigenvector is orthogonal to it
+    // phase 0: warm attempt; 1: cold run (generic start vector, n steps); 2: the cold recurrence once more for its Ritz vector.
+    // Every decision below is uniform over the workgroup: kernel arguments, one global word read by all, or LDS words
+    // written by wave 0 and read behind a barrier.
+    const bool warm_on = wx != nullptr;
+    int phase = 1;
+    if (warm_on && wst[t] == 1) phase = 0;
+    const bool verify = warm_on && vperiod > 0 && ((call + t) % vperiod == 0);
+    bool have_w = false;
+    float theta_w = 0.f;
+    int m = 0, mcold = 0;
     float2 v[R], vp[R], u[R];
-    float nrm = 0.f;
+    for (;;) {
+        // start vector: the previous call's Ritz vector, or a generic one (no structured eigenvector is orthogonal to it)
+        float nrm = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int i = lane + 64 * r;
-        const float fi = (float)i;
-        v[r] = (i < n) ? make_float2(cosf(0.7f + 1.37f * fi + 0.011f * fi * fi), sinf(0.3f + 2.11f * fi))
-                       : make_float2(0.f, 0.f);
-        vp[r] = make_float2(0.f, 0.f);
-        nrm += v[r].x * v[r].x + v[r].y * v[r].y;
-    }
-    {
-        const float inv = 1.f / sqrtf(wsum(nrm));
+        for (int r = 0; r < R; ++r) {
+            const int i = lane + 64 * r;
+            const float fi = (float)i;
+            if (phase == 0) v[r] = (i < n) ? wx[(long long)t * NE + i] : make_float2(0.f, 0.f);
+            else v[r] = (i < n) ? make_float2(cosf(0.7f + 1.37f * fi + 0.011f * fi * fi), sinf(0.3f + 2.11f * fi))
+                                : make_float2(0.f, 0.f);
+            vp[r] = make_float2(0.f, 0.f);
+            if (phase == 2 && wave == 0) vb[lane + 64 * r] = make_float2(0.f, 0.f);     // x accumulates here (wave 0's own words)
+            nrm += v[r].x * v[r].x + v[r].y * v[r].y;
+        }
+        {
+            const float inv = 1.f / sqrtf(wsum(nrm));
 #pragma unroll
-        for (int r = 0; r < R; ++r) { v[r].x *= inv; v[r].y *= inv; }
-    }
-    float dl[R], el[R];                     // lane (k & 63) of register k >> 6: d[k], e2[k] (off-diagonal k | k+1, squared)
+            for (int r = 0; r < R; ++r) { v[r].x *= inv; v[r].y *= inv; }
+        }
+        float beta = 0.f, scale = 0.f;
+        m = 0;
+        const int jmax = (phase == 0) ? min(LZ_KMAX, n) : (phase == 2 ? mcold : n);
+        __syncthreads();                    // the LDS words of the previous phase are free (and sy of phase 1 is visible)
+        for (int j = 0; j < jmax; ++j) {
+            if (phase == 0 && wave == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) { dl[r] = 0.f; el[r] = 0.f; }
-    float beta = 0.f, scale = 0.f;
-    int m = 0;
-    for (int j = 0; j < n; ++j) {
-        // partial product over this wave's columns (two independent chains per component)
-        float px[R][2], py[R][2];
+                for (int r = 0; r < R; ++r) vb[j * NE + lane + 64 * r] = v[r];
+            }
+            if (phase == 2 && wave == 0) {
+                const float yj = sy[j];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { px[r][0] = px[r][1] = 0.f; py[r][0] = py[r][1] = 0.f; }
+                for (int r = 0; r < R; ++r) {
+                    float2 xa = vb[lane + 64 * r];
+                    xa.x = fmaf(yj, v[r].x, xa.x); xa.y = fmaf(yj, v[r].y, xa.y);
+                    vb[lane + 64 * r] = xa;
+                }
+            }
+            // partial product over this wave's columns (two independent chains per component)
+            float px[R][2], py[R][2];
 #pragma unroll
-        for (int kk = 0; kk < KW; ++kk) {
-            const int k = kbase + kk;                                   // wave-uniform; (k >> 6) selects the register
-            const float vx = (R == 1 || k < 64) ? bcast(v[0].x, k & 63) : bcast(v[R - 1].x, k & 63);
-            const float vy = (R == 1 || k < 64) ? bcast(v[0].y, k & 63) : bcast(v[R - 1].y, k & 63);
+            for (int r = 0; r < R; ++r) { px[r][0] = px[r][1] = 0.f; py[r][0] = py[r][1] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < KW; ++kk) {
+                const int k = kbase + kk;                                   // wave-uniform; (k >> 6) selects the register
+                const float vx = (R == 1 || k < 64) ? bcast(v[0].x, k & 63) : bcast(v[R - 1].x, k & 63);
+                const float vy = (R == 1 || k < 64) ? bcast(v[0].y, k & 63) : bcast(v[R - 1].y, k & 63);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float2 g = grow[kk * R + r];
+                    px[r][kk & 1] = fmaf(g.x, vx, px[r][kk & 1]);
+                    py[r][kk & 1] = fmaf(g.x, vy, py[r][kk & 1]);
+                    px[r][kk & 1] = fmaf(-g.y, vy, px[r][kk & 1]);
+                    py[r][kk & 1] = fmaf(g.y, vx, py[r][kk & 1]);
+                }
+            }
+            float2 *pw = part + (j & 1) * NW * NE;
+            if constexpr (NW > 1) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    pw[wave * NE + lane + 64 * r] = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
+                __syncthreads();
+            }
+            // The ONLY data-dependent exit: wave 0's verdict on the previous step, read by every wave from one LDS word behind
+            // the barrier above - the number of barriers each wave executes cannot differ, whatever the four waves' redundant
+            // arithmetic does (round 2 relied on it being bitwise identical; the step computed in between is discarded).
+            if (j > 0 && sflag[(j - 1) & 1]) break;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float2 g = grow[kk * R + r];
-                px[r][kk & 1] = fmaf(g.x, vx, px[r][kk & 1]);
-                py[r][kk & 1] = fmaf(g.x, vy, py[r][kk & 1]);
-                px[r][kk & 1] = fmaf(-g.y, vy, px[r][kk & 1]);
-                py[r][kk & 1] = fmaf(g.y, vx, py[r][kk & 1]);
+                const int i = lane + 64 * r;
+                float2 ps;
+                if constexpr (NW == 4) {
+                    const float2 p0 = pw[i], p1 = pw[NE + i], p2 = pw[2 * NE + i], p3 = pw[3 * NE + i];
+                    ps = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+                } else if constexpr (NW == 2) {
+                    const float2 p0 = pw[i], p1 = pw[NE + i];
+                    ps = make_float2(p0.x + p1.x, p0.y + p1.y);
+                } else {
+                    ps = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
+                }
+                u[r] = make_float2(ps.x - beta * vp[r].x, ps.y - beta * vp[r].y);
             }
-        }
-        float2 *pw = part + (j & 1) * NW * NE;
-        if constexpr (NW > 1) {
+            float a = 0.f;
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                pw[wave * NE + lane + 64 * r] = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
-            __syncthreads();
-        }
-        // The ONLY data-dependent exit: wave 0's verdict on the previous step, read by every wave from one LDS word behind
-        // the barrier above - the number of barriers each wave executes cannot differ, whatever the four waves' redundant
-        // arithmetic does (round 2 relied on it being bitwise identical; the step computed in between is discarded).
-        if (j > 0 && sflag[(j - 1) & 1]) break;
+            for (int r = 0; r < R; ++r) a += v[r].x * u[r].x + v[r].y * u[r].y;
+            const float alpha = wsum(a);
+            float b2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = lane + 64 * r;
-            float2 ps;
-            if constexpr (NW == 4) {
-                const float2 p0 = pw[i], p1 = pw[NE + i], p2 = pw[2 * NE + i], p3 = pw[3 * NE + i];
-                ps = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
-            } else if constexpr (NW == 2) {
-                const float2 p0 = pw[i], p1 = pw[NE + i];
-                ps = make_float2(p0.x + p1.x, p0.y + p1.y);
-            } else {
-                ps = make_float2(px[r][0] + px[r][1], py[r][0] + py[r][1]);
+            for (int r = 0; r < R; ++r) {
+                u[r].x -= alpha * v[r].x; u[r].y -= alpha * v[r].y;
+                b2 += u[r].x * u[r].x + u[r].y * u[r].y;
             }
-            u[r] = make_float2(ps.x - beta * vp[r].x, ps.y - beta * vp[r].y);
+            const float bb = wsum(b2);
+            const float bnew = sqrtf(bb);
+            scale = fmaxf(scale, fabsf(alpha) + beta + bnew);
+            const bool last = (j == n - 1) || !(bnew > 4e-7f * scale);      // Krylov space exhausted (also catches NaN)
+            // T_m: diagonal sd[0..m-1], squared off-diagonals se[0..m-2]; se[m-1] is the outgoing beta^2 (not part of T_m)
+            if (wave == 0) { sd[j] = alpha; se[j] = bb; }
+            m = j + 1;
+            int flag = last ? 1 : 0;        // 1: tridiagonalisation complete, 2: phase 0 converged, 3: phase 0 gave up
+            if (phase == 0 && wave == 0 && !last) {
+                if (m >= LZ_KMIN) {
+                    const float th = lz_top_small(sd, se, m, lane);
+                    const float ny = lz_twisted(sd, se, m, th, sdp, sdm, sy);
+                    const float res = bnew * fabsf(sy[m - 1]) * __builtin_amdgcn_rsqf(ny);   // ||G x - theta x||
+                    if (res <= tol * th) { flag = 2; if (lane == 0) { sres[0] = th; sres[1] = ny; } }      // (NaN: false)
+                }
+                if (flag == 0 && m == jmax) flag = 3;
+            }
+            if (wave == 0 && lane == 0) sflag[j & 1] = flag;
+            if (j + 1 == jmax) break;
+            const float ib = 1.f / bnew;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                vp[r] = v[r];
+                v[r] = make_float2(u[r].x * ib, u[r].y * ib);
+            }
+            beta = bnew;
         }
-        float a = 0.f;
-#pragma unroll
-        for (int r = 0; r < R; ++r) a += v[r].x * u[r].x + v[r].y * u[r].y;
-        const float alpha = wsum(a);
-        float b2 = 0.f;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            u[r].x -= alpha * v[r].x; u[r].y -= alpha * v[r].y;
-            b2 += u[r].x * u[r].x + u[r].y * u[r].y;
-        }
-        const float bb = wsum(b2);
-        const float bnew = sqrtf(bb);
-        scale = fmaxf(scale, fabsf(alpha) + beta + bnew);
-        const bool last = (j == n - 1) || !(bnew > 4e-7f * scale);      // Krylov space exhausted (also catches NaN)
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-            if (lane + 64 * r == j) { dl[r] = alpha; el[r] = last ? 0.f : bb; }
-        m = j + 1;
-        if (wave == 0 && lane == 0) sflag[j & 1] = last ? 1 : 0;
-        if (j == n - 1) break;              // (uniform: n is a kernel argument)
-        const float ib = 1.f / bnew;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            vp[r] = v[r];
-            v[r] = make_float2(u[r].x * ib, u[r].y * ib);
-        }
-        beta = bnew;
-    }
-
-    // ---- Gershgorin bounds of T_m, then 256-way multisection for its largest eigenvalue: every wave takes 64 of
-    //      the candidates (all four hold identical copies of d / e^2), the waves' results meet in LDS
-    // d / e^2 and the step count to LDS: WAVE 0's copies are the ones every wave works with from here on (uniform-address
-    // reads broadcast and run ahead of the serial Sturm recurrence).
-    float *se = sd + NE;
-    int *sfirst = reinterpret_cast<int *>(se + NE);
-    if (wave == 0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) { sd[lane + 64 * r] = dl[r]; se[lane + 64 * r] = (lane + 64 * r == m - 1) ? 0.f : el[r]; }
-        if (lane == 0) sfirst[8] = m;
-    }
-    __syncthreads();
-    m = sfirst[8];
-    float lo, hi;
-    {
-        float emax = 0.f, dmin = 3.0e38f, dmax = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int i = lane + 64 * r;
-            if (i < m) { emax = fmaxf(emax, sqrtf(se[i])); dmin = fminf(dmin, sd[i]); dmax = fmaxf(dmax, sd[i]); }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            emax = fmaxf(emax, __shfl_xor(emax, o));
-            dmin = fminf(dmin, __shfl_xor(dmin, o));
-            dmax = fmaxf(dmax, __shfl_xor(dmax, o));
-        }
-        lo = dmin - 2.f * emax;             // every Gershgorin disc lies inside [dmin - 2 emax, dmax + 2 emax]
-        hi = dmax + 2.f * emax;
-    }
-    const float span0 = fmaxf(hi - lo, 1e-30f);
-    hi += 1e-6f * span0 + 1e-30f;
-    constexpr int NROUND = NW == 4 ? 4 : (NW == 2 ? 5 : 6);         // (64 NW + 1)^NROUND >= 3e10 sub-intervals
-    for (int round = 0; round < NROUND; ++round) {
-        // candidates x_c = lo + (c+1) (hi-lo)/257, c = 64 wave + lane; count(x) = #eigenvalues < x;
-        // lambda_max in (x_first-1, x_first]
-        const float step = (hi - lo) / (float)(NT + 1);
-        const float x = lo + (64 * wave + lane + 1) * step;
-        float q = 1.f, eprev = 0.f;
-        int c = 0;
-        for (int i = 0; i < m; ++i) {
-            q = (sd[i] - x) - eprev * __builtin_amdgcn_rcpf(q);      // (1 ulp reciprocal: the count only has to be
-            if (fabsf(q) < 1e-30f) q = -1e-30f;                      //  right away from the eigenvalues)
-            c += (q < 0.f);
-            eprev = se[i];
-        }
-        const unsigned long long full = __ballot(c >= m);            // candidates above every eigenvalue
-        if (lane == 0) sfirst[(round & 1) * 4 + wave] = full ? 64 * wave + (int)__ffsll((long long)full) - 1 : NT;
         __syncthreads();
-        const int *sf = sfirst + (round & 1) * 4;
-        int first = sf[0];
+        const int fin = m > 0 ? sflag[(m - 1) & 1] : 1;
+
+        if (phase == 0) {
+            if (fin == 2) {
+                theta_w = sres[0];
+                have_w = true;
+                if (wave == 0) {            // x = sum_i y_i v_i from the start-up vectors; y (unnormalised) is still in sy
+                    const float iny = __builtin_amdgcn_rsqf(sres[1]);
+                    float2 x[R];
+                    float nx = 0.f;
 #pragma unroll
-        for (int wv = 1; wv < NW; ++wv) first = min(first, sf[wv]);
-        const float nlo = lo + first * step;
-        const float nhi = (first < NT) ? lo + (first + 1) * step : hi;
-        lo = nlo; hi = nhi;
+                    for (int r = 0; r < R; ++r) {
+                        x[r] = make_float2(0.f, 0.f);
+                        for (int i = 0; i < m; ++i) {
+                            const float yi = sy[i] * iny;
+                            const float2 vi = vb[i * NE + lane + 64 * r];
+                            x[r].x = fmaf(yi, vi.x, x[r].x); x[r].y = fmaf(yi, vi.y, x[r].y);
+                        }
+                        nx += x[r].x * x[r].x + x[r].y * x[r].y;
+                    }
+                    const float inx = __builtin_amdgcn_rsqf(wsum(nx));
+#pragma unroll
+                    for (int r = 0; r < R; ++r) wx[(long long)t * NE + lane + 64 * r] = make_float2(x[r].x * inx, x[r].y * inx);
+                }
+                if (!verify) {
+                    if (tid == 0) lam_out[t] = theta_w;
+                    return;
+                }
+            }
+            phase = 1;                      // not converged (or due for verification): the cold run
+            continue;
+        }
+        if (phase == 2) {
+            if (wave == 0) {
+                float2 xacc[R];
+                float nx = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { xacc[r] = vb[lane + 64 * r]; nx += xacc[r].x * xacc[r].x + xacc[r].y * xacc[r].y; }
+                const float sx = wsum(nx);
+                const bool ok = sx > 1e-30f && sx < 3.0e38f;        // (NaN: false)
+                const float inx = ok ? __builtin_amdgcn_rsqf(sx) : 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) wx[(long long)t * NE + lane + 64 * r] = make_float2(xacc[r].x * inx, xacc[r].y * inx);
+                if (lane == 0) wst[t] = ok ? 1 : 0;
+            }
+            return;
+        }
+
+        // ---- phase 1: Gershgorin bounds of T_m, then 256-way multisection for its largest eigenvalue: every wave takes 64
+        //      of the candidates (all read wave 0's d / e^2 from LDS: uniform-address reads broadcast and run ahead of the
+        //      serial Sturm recurrence), the waves' results meet in LDS
+        float lo, hi;
+        {
+            float emax = 0.f, dmin = 3.0e38f, dmax = -3.0e38f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                if (i < m) {
+                    emax = fmaxf(emax, i < m - 1 ? sqrtf(se[i]) : 0.f);
+                    dmin = fminf(dmin, sd[i]); dmax = fmaxf(dmax, sd[i]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                emax = fmaxf(emax, __shfl_xor(emax, o));
+                dmin = fminf(dmin, __shfl_xor(dmin, o));
+                dmax = fmaxf(dmax, __shfl_xor(dmax, o));
+            }
+            lo = dmin - 2.f * emax;             // every Gershgorin disc lies inside [dmin - 2 emax, dmax + 2 emax]
+            hi = dmax + 2.f * emax;
+        }
+        const float span0 = fmaxf(hi - lo, 1e-30f);
+        hi += 1e-6f * span0 + 1e-30f;
+        constexpr int NROUND = NW == 4 ? 4 : (NW == 2 ? 5 : 6);         // (64 NW + 1)^NROUND >= 3e10 sub-intervals
+        for (int round = 0; round < NROUND; ++round) {
+            // candidates x_c = lo + (c+1) (hi-lo)/257, c = 64 wave + lane; count(x) = #eigenvalues < x;
+            // lambda_max in (x_first-1, x_first]
+            const float step = (hi - lo) / (float)(NT + 1);
+            const float x = lo + (64 * wave + lane + 1) * step;
+            float q = 1.f, eprev = 0.f;
+            int c = 0;
+            for (int i = 0; i < m; ++i) {
+                q = (sd[i] - x) - eprev * __builtin_amdgcn_rcpf(q);      // (1 ulp reciprocal: the count only has to be
+                if (fabsf(q) < 1e-30f) q = -1e-30f;                      //  right away from the eigenvalues)
+                c += (q < 0.f);
+                eprev = se[i];
+            }
+            const unsigned long long full = __ballot(c >= m);            // candidates above every eigenvalue
+            if (lane == 0) sfirst[(round & 1) * 4 + wave] = full ? 64 * wave + (int)__ffsll((long long)full) - 1 : NT;
+            __syncthreads();
+            const int *sf = sfirst + (round & 1) * 4;
+            int first = sf[0];
+#pragma unroll
+            for (int wv = 1; wv < NW; ++wv) first = min(first, sf[wv]);
+            const float nlo = lo + first * step;
+            const float nhi = (first < NT) ? lo + (first + 1) * step : hi;
+            lo = nlo; hi = nhi;
+        }
+        const float lam = 0.5f * (lo + hi);
+        if (tid == 0) lam_out[t] = lam;
+        if (!warm_on) return;
+        if (have_w) {
+            if (fabsf(lam - theta_w) <= 2e-5f * fabsf(lam)) return;      // verified: the vector phase 0 stored stands
+            if (tid == 0) atomicAdd(wmis, 1u);
+        }
+        // a fresh Ritz vector for the next call: y of T_m for lam (wave 0), then the recurrence once more
+        mcold = m;
+        if (wave == 0) (void)lz_twisted(sd, se, m, lam, sdp, sdm, sy);
+        phase = 2;
     }
-    if (wave != 0) return;
-    if (lane == 0) lam_out[t] = 0.5f * (lo + hi);
 }
+
 
 template <int NE> static size_t jacobi2_smem()
 {
@@ -802,31 +988,41 @@ static int launch_lmax_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, 
     return 0;
 }
 
-template <int NE, int NW>
+template <int NE, int NW, int OCC>
 static int launch_lanczos_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit,
-                            long long sGs, float *lam_out)
+                            long long sGs, float *lam_out, const LanczosWarm *lw, int first)
 {
-    const size_t sh = (size_t)2 * NW * NE * sizeof(float2) + 16 + (size_t)(2 * NE + 16) * sizeof(float);   // exchange, flags, T
-    JSTSP_HIP(hipFuncSetAttribute((const void *)lanczos_lmax_kernel<NE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    // exchange, flags, T, firsts, y + the two pivot arrays of the twisted factorisation, 4 scalars, start-up vectors
+    const size_t sh = (size_t)2 * NW * NE * sizeof(float2) + 16 + (size_t)2 * NE * sizeof(float) + 12 * sizeof(int) +
+                      (size_t)3 * NE * sizeof(float) + 16 + (size_t)LZ_KMAX * NE * sizeof(float2);
+    JSTSP_HIP(hipFuncSetAttribute((const void *)lanczos_lmax_kernel<NE, NW, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh));
-    hipLaunchKernelGGL((lanczos_lmax_kernel<NE, NW>), dim3(batch), dim3(64 * NW), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs,
-                       lam_out);
+    const bool warm = lw && lw->x && lw->ne == NE && tune().lanczos_warm != 0;
+    hipLaunchKernelGGL((lanczos_lmax_kernel<NE, NW, OCC>), dim3(batch), dim3(64 * NW), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs,
+                       lam_out, warm ? lw->x + (size_t)first * NE : nullptr, warm ? lw->state + first : nullptr,
+                       warm ? lw->mismatch : nullptr, warm ? lw->call + first : 0, tune().lanczos_verify, 1e-5f);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }
 
+int lanczos_ne(int n) { return n <= 64 ? 64 : 128; }
+
 // lam_out[t] = lambda_max of the n x n Hermitian matrix sum_s Gpart[t][s]; n <= 128.
-// lanczos: the one-wave Lanczos kernel (1e-6 relative; the ADMM loop's convergence_error) instead of Householder + Sturm
+// lanczos: the four-wave Lanczos kernel (1e-6 relative; the ADMM loops' convergence_error) instead of Householder + Sturm;
+// lw (with lanczos): warm-start record of matrices [first, first + batch) - see the kernel
 int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
-                float *lam_out, bool lanczos)
+                float *lam_out, bool lanczos, const LanczosWarm *lw, int first)
 {
     if (n > 128) return launch_eig_large(ctx, EIG_LMAX, n, batch, Gpart, sGt, nsplit, sGs, nullptr, nullptr, nullptr, lam_out);
     JSTSP_REQUIRE(n >= 1, JSTSP_E_UNSUPPORTED, "launch_lmax: n = %d", n);
     const bool lz = lanczos && tune().lanczos != 0;
     if (lz) {
         // four waves per matrix (one or two measured slower: too little parallelism per matrix, round 2)
-        if (n <= 64) return launch_lanczos_t<64, 4>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
-        return launch_lanczos_t<128, 4>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
+        if (n <= 64) return launch_lanczos_t<64, 4, 1>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out, lw, first);
+        // order 65..128: two workgroups per CU (256 registers per lane, a dozen spilled) or one (JSTSP_LZ128_OCC=1) - TEMPORARY switch
+        if (getenv("JSTSP_LZ128_OCC") && atoi(getenv("JSTSP_LZ128_OCC")) == 1)
+            return launch_lanczos_t<128, 4, 1>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out, lw, first);
+        return launch_lanczos_t<128, 4, 2>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out, lw, first);
     }
     if (n <= 32) return launch_lmax_t<32>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);
     if (n <= 64) return launch_lmax_t<64>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);

@@ -454,7 +454,11 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // norm partials, the whole side chain behind the step's head, other gate positions, stream priorities) are gone from
     // the code; their numbers are in DESIGN.md.
     hipEvent_t ev_q1 = ctx->ev[7];
+    // convergence_error(:,1:2): lambda_max of three Grams per trial and iteration, each warm-started from its own Ritz vector
+    // of the previous iteration (eig2.hip); the record starts empty
+    if (want_ce) JSTSP_TRY(lanczos_warm_reset(ctx, w.gn));
     for (int it = 0; it < Imax; ++it) {
+        if (want_ce) w.gn.lz.call = it;
         float2 *Zc = fz ? Zbuf[it & 1] : w.Zb, *Zn = fz ? Zbuf[(it + 1) & 1] : w.Zb;
         // every operand maximum of this iteration starts from zero (one memset instead of four)
         // (block it & 1; every consumer of the same block from iteration it-2 has been waited for by the main stream
@@ -626,7 +630,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             }
             //    v += alpha res; ce(i,3); s = soft(v) (.* Omega_S)                            (:49-56, angles :36,:68)
             JSTSP_TRY(launch_step_v(ctx, (int)g, batch, w.Res, w.RRes, w.V, w.S, w.rank, (int)cnt_ll, w.prm, w.ce,
-                                    Imax, it, rv_refresh > 1 ? w.RV : nullptr, svt_split, comp ? w.Vlo : nullptr,
+                                    Imax, it, (rv_refresh > 1 || comp) ? w.RV : nullptr, svt_split, comp ? w.Vlo : nullptr,
                                     comp ? w.RVlo : nullptr, refreshed ? 1 : 0));
         } else {
             //    v = U\(L\k) = pinv(A) K pinv(B)   [ = G_A^-1 (A^H Tc) G_B^-1 on the Gram route: GA / GB hold the inverses ]  (:53)

@@ -32,6 +32,8 @@ void load_tuning()
     t.overlap = env_int("JSTSP_OVERLAP", t.overlap);
     t.svt_skip = env_int("JSTSP_SVT_SKIP", t.svt_skip);
     t.lanczos = env_int("JSTSP_LANCZOS", t.lanczos);
+    t.lanczos_warm = env_int("JSTSP_LANCZOS_WARM", t.lanczos_warm);
+    t.lanczos_verify = env_int("JSTSP_LANCZOS_VERIFY", t.lanczos_verify);
     t.eig128 = env_int("JSTSP_EIG128", t.eig128);
     t.omp_gram = env_int("JSTSP_OMP_GRAM", t.omp_gram);
     t.bj_trace = env_int("JSTSP_BJ_TRACE", t.bj_trace);
@@ -178,6 +180,7 @@ size_t GramWS::bytes(int rows, int cols, int batch, bool need_q, int force_nspli
     const int n = std::min(rows, cols), kc = std::max(rows, cols);
     const int ns = force_nsplit > 0 ? force_nsplit : pick_nsplit(n, kc, batch);
     size_t b = rnd256((size_t)batch * ns * n * n * sizeof(float2));
+    if (!need_q && n <= 128) b += rnd256((size_t)batch * lanczos_ne(n) * sizeof(float2)) + rnd256((size_t)batch * sizeof(int));
     if (need_q) {
         b += rnd256((size_t)batch * n * n * sizeof(float2));
         if (n <= 64) b += rnd256((size_t)batch * eig_fast_ne(n) * eig_fast_ne(n) * sizeof(float2));
@@ -199,6 +202,13 @@ int GramWS::alloc(Arena &a, int rows_, int cols_, int batch_, bool need_q, int f
     Gpart = a.get<float2>((size_t)batch * nsplit * n * n);
     JSTSP_REQUIRE(Gpart, JSTSP_E_NOMEM, "workspace exhausted (Gram partials)");
     Q = nullptr; Vg = nullptr; Uwarm = nullptr; Twarm = nullptr; warm = 0;
+    lz = LanczosWarm();
+    if (!need_q && n <= 128) {
+        lz.ne = lanczos_ne(n);
+        lz.x = a.get<float2>((size_t)batch * lz.ne);
+        lz.state = a.get<int>((size_t)batch);
+        JSTSP_REQUIRE(lz.x && lz.state, JSTSP_E_NOMEM, "workspace exhausted (Lanczos warm-start vectors)");
+    }
     if (need_q) {
         Q = a.get<float2>((size_t)batch * n * n);
         JSTSP_REQUIRE(Q, JSTSP_E_NOMEM, "workspace exhausted (SVT projector)");
@@ -249,16 +259,32 @@ int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long l
                 GEMM_GRAM, w.nsplit, sG);
 }
 
+int lanczos_warm_reset(jstsp_ctx *ctx, const GramWS &w)
+{
+    w.lz.call = 0;
+    w.lz.mismatch = nullptr;
+    if (!w.lz.x) return 0;
+    if (!ctx->lz_mismatch) JSTSP_HIP(hipMalloc((void **)&ctx->lz_mismatch, 256));
+    JSTSP_HIP(hipMemsetAsync(ctx->lz_mismatch, 0, sizeof(unsigned), ctx->stream));
+    JSTSP_HIP(hipMemsetAsync(w.lz.state, 0, (size_t)w.batch * sizeof(int), ctx->stream));
+    w.lz.mismatch = ctx->lz_mismatch;
+    return 0;
+}
+
+// (a record that was never reset - lz.mismatch == NULL - is not used: the vectors' states are uninitialised memory)
+static const LanczosWarm *lz_of(const GramWS &w, bool lanczos) { return (lanczos && w.lz.x && w.lz.mismatch) ? &w.lz : nullptr; }
+
 int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos)
 {
     const long long sG = (long long)w.n * w.n;
-    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam, lanczos);
+    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam, lanczos, lz_of(w, lanczos), 0);
 }
 
 int lmax_from_partials_range(jstsp_ctx *ctx, const GramWS &w, int first, int count, float *lam, bool lanczos)
 {
     const long long sG = (long long)w.n * w.n;
-    return launch_lmax(ctx, w.n, count, w.Gpart + (long long)first * sG * w.nsplit, sG * w.nsplit, w.nsplit, sG, lam + first, lanczos);
+    return launch_lmax(ctx, w.n, count, w.Gpart + (long long)first * sG * w.nsplit, sG * w.nsplit, w.nsplit, sG, lam + first, lanczos,
+                       lz_of(w, lanczos), first);
 }
 
 int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialParams *prm, const float *tau,
@@ -413,7 +439,10 @@ int sigma_max_sq(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, float *lam, b
     const long long sZ = (long long)w.rows * w.cols;
     const long long sG = (long long)w.n * w.n;
     JSTSP_TRY(gram_partials(ctx, w, Z, sZ));
-    return launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam, lanczos);
+    // (with a reset warm-start record: one call per iteration of the owning loop - the record's call counter advances here)
+    JSTSP_TRY(launch_lmax(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, lam, lanczos, lz_of(w, lanczos), 0));
+    if (lanczos) ++w.lz.call;
+    return 0;
 }
 
 int upload(jstsp_ctx *ctx, void *dst, const void *src, size_t bytes)
@@ -501,6 +530,7 @@ int jstsp_destroy(jstsp_ctx *ctx)
     for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->diag) (void)hipFree(ctx->diag);
+    if (ctx->lz_mismatch) (void)hipFree(ctx->lz_mismatch);
     if (ctx->unit) (void)hipFree(ctx->unit);
     ctx->arena.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -548,6 +578,17 @@ int jstsp_last_conditioning(jstsp_ctx *ctx, double *rcond_min, double *ns_residu
     JSTSP_ENTER(ctx);
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     return diag_read(ctx, rcond_min, ns_residual_max);
+}
+
+int jstsp_last_lanczos_mismatches(jstsp_ctx *ctx, int *count)
+{
+    JSTSP_REQUIRE(ctx && count, JSTSP_E_NULL, "ctx/count is NULL");
+    JSTSP_ENTER(ctx);
+    unsigned h = 0;
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->lz_mismatch) JSTSP_HIP(hipMemcpy(&h, ctx->lz_mismatch, sizeof(h), hipMemcpyDeviceToHost));
+    *count = (int)h;
+    return 0;
 }
 
 size_t jstsp_workspace_bytes(const jstsp_ctx *ctx) { return ctx ? ctx->arena.cap : 0; }

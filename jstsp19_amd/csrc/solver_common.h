@@ -49,6 +49,7 @@ struct GramWS {
     float2 *Uwarm = nullptr;   // eigenvector basis of the previous call (warm start): NE x NE padded for n <= 64, n x n above
     float2 *Twarm = nullptr;   // n > 64: temporary of the warm-start transform G <- Uw^H (G Uw)
     mutable int warm = 0;      // 1 once Uwarm holds a basis
+    mutable LanczosWarm lz;    // norm workspaces (need_q == false, n <= 128): warm-start record of the Lanczos lambda_max kernel
     static size_t bytes(int rows, int cols, int batch, bool need_q, int force_nsplit = 0);
     int alloc(Arena &a, int rows, int cols, int batch, bool need_q, int force_nsplit = 0);
 };
@@ -72,6 +73,9 @@ int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long l
                         const uint32_t *amax = nullptr, const TrialParams *skip_prm = nullptr, const float2 *Z2 = nullptr,
                         const TrialParams *zprm = nullptr);
 // lam[t] = lambda_max of the Gram partials already in the workspace, all w.batch problems
+// The warm-start record of a norm workspace: all vectors invalid, the context's mismatch counter zeroed (on ctx->stream;
+// once per solve, before the first lambda_max of its loop).  `call` of the record is set by the loop's owner.
+int lanczos_warm_reset(jstsp_ctx *ctx, const GramWS &w);
 int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos = false);
 int lmax_from_partials_range(jstsp_ctx *ctx, const GramWS &w, int first, int count, float *lam, bool lanczos);   // matrices [first, first + count)
 // Make sure the context's side streams / events exist.

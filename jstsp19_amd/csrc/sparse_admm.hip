@@ -151,6 +151,7 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     JSTSP_HIP(hipMemsetAsync(Z, 0, batch * nm * sizeof(float2), st));
     JSTSP_HIP(hipMemsetAsync(S, 0, batch * nm * sizeof(float2), st));
     if (want_ce) JSTSP_TRY(sigma_max_sq(ctx, wn, Htrue, den));
+    if (want_ce) JSTSP_TRY(lanczos_warm_reset(ctx, wn));       // the error curve's lambda_max, warm-started from iteration to iteration
 
     for (int it = 0; it < Imax; ++it) {                                            // :18
         hipLaunchKernelGGL(sadmm_soft_rhs_kernel, g1(tot), dim3(256), 0, st, tot, R, Z, AhOH, S, RHS, rho,

@@ -223,7 +223,7 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
     float2 *AAh = a.get<float2>((size_t)nA * Na * Na), *Ua = a.get<float2>((size_t)nA * Na * Na);
     float2 *Ub = a.get<float2>((size_t)nG * G2 * G2);
     float *lamA = a.get<float>((size_t)nA * Na), *lamB = a.get<float>((size_t)nG * G2);
-    const int nea = (Na + 1) & ~1, neb = (G2 + 1) & ~1;
+    const int nea = (Da + 1) & ~1, neb = (G2 + 1) & ~1;     // order of the decomposition (Da), as vamp_bytes() budgets it
     // (orders above 128 go to the block Jacobi of eig_large.hip, which brings its own stream-ordered temporaries)
     float2 *Vga = a.get<float2>(Da <= 128 ? (size_t)nA * nea * nea : 16), *Vgb = a.get<float2>(G2 <= 128 ? (size_t)nG * neb * neb : 16);
     VampScal *sc = a.get<VampScal>(batch);

@@ -343,6 +343,23 @@ def nmse_spectral(S, Zbar, *, ctx=None):
     return out if a_S.batched else out[0]
 
 
+def lambda_max_sequence(G, *, ctx=None):
+    """``lambda_max`` of a sequence of batches of Hermitian matrices, ``G``: (steps, batch, n, n) numpy complex64 (each matrix
+    column-major = its transpose in C order; Hermitian, so the conjugate).  Matrix t of step s is warm-started from matrix t of
+    step s - 1 — the kernel behind ``convergence_error(:,1:2)`` (proposed_algorithm.m:67,69) as the ADMM loops drive it.
+    Returns (steps, batch) float32."""
+    G = np.asarray(G)
+    if G.ndim != 4 or G.shape[2] != G.shape[3]:
+        raise ValueError("G must be (steps, batch, n, n)")
+    steps, batch, n, _ = G.shape
+    Gc = np.ascontiguousarray(np.swapaxes(G, 2, 3).astype(np.complex64))        # column-major matrices
+    c = ctx if ctx is not None else _lib.default_context(0)
+    out = np.empty((steps, batch), dtype=np.float32)
+    check(c._lib.jstsp_lambda_max_sequence_c32(c.handle, n, batch, steps, Gc.ctypes.data, out.ctypes.data, HOST),
+          "jstsp_lambda_max_sequence_c32")
+    return out
+
+
 def rate(S, Zbar, noise_var, *, ctx=None):
     """plot_rateVSframelength.m:81,113,130,135 — ``log2(real(det(eye(Nr) + 1/Nr*Zbar*Zbar'/(noise_var + nmse))))`` with
     the (uncapped) spectral-norm NMSE of ``S``."""

@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--trials", type=int, default=256, help="realisations per SNR point")
     ap.add_argument("--snrs", type=str, default="-15,-12,-9,-6,-3,0,3,6,9,12")
     ap.add_argument("--bench-trials", type=int, default=256, help="trials of the bench workload (5 dB, sweep index 0)")
-    ap.add_argument("--angles-trials", type=int, default=64, help="proposed_algorithm_angles trials per point at -15, 0, 12 dB")
+    ap.add_argument("--angles-trials", type=int, default=64, help="proposed_algorithm_angles trials per point of --angles-snrs")
+    ap.add_argument("--angles-snrs", type=str, default="-15,0,12", help="SNR points (members of --snrs) of the _angles trials")
+    ap.add_argument("--seed", type=int, default=20190913, help="generator seed (the held-out fixture uses another one)")
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--variants", type=str, default=",".join(VARIANTS))
@@ -86,9 +88,9 @@ def main():
     work = []
     for t0 in range(0, a.bench_trials, a.chunk):
         work.append(("bench", "proposed", 5.0, 0, t0, min(a.chunk, a.bench_trials - t0)))
-    for s in (-15.0, 0.0, 12.0):
-        if s in snrs and a.angles_trials:
-            for t0 in range(0, a.angles_trials, a.chunk):
+    for t0 in range(0, a.angles_trials, a.chunk):
+        for s in [float(x) for x in a.angles_snrs.split(",") if x]:
+            if s in snrs:
                 work.append(("sweep", "angles", s, snrs.index(s), t0, min(a.chunk, a.angles_trials - t0)))
     for t0 in range(0, a.trials, a.chunk):          # trial blocks outermost: every SNR point is covered early
         for i, s in enumerate(snrs):
@@ -103,12 +105,12 @@ def main():
         if time.perf_counter() - t_start > a.budget_s:
             break
         p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=snr)
-        inp = build_trials(p, t0, cnt, sweep_idx=sidx, device=dev)
+        inp = build_trials(p, t0, cnt, seed=a.seed, sweep_idx=sidx, device=dev)
         idx = inp["indx_S"] if solver == "angles" else None
         hyp = [inp[k].numpy() for k in ("tau_Y", "tau_Z", "rho")]
         zb = inp["Zbar"].cpu().numpy().astype(np.complex128)
         rec = {"snr_db": np.full(cnt, snr), "sweep_idx": np.full(cnt, sidx), "trial": np.arange(t0, t0 + cnt),
-               "fingerprint": fingerprint(inp)}
+               "fingerprint": fingerprint(inp), "seed": np.full(cnt, a.seed, dtype=np.int64)}
         for v in variants:
             env, want_ce = VARIANTS[v]
             if solver == "angles" and v not in ("default", "two_output"):
@@ -190,8 +192,9 @@ def summarise(out):
         s["default_by_snr"] = by_snr
         s["max_rel_dS_default"] = float(g["rel_dS_default"].max())
         summ[gname] = s
-        for k in ("snr_db", "sweep_idx", "trial", "fingerprint", "nmse_port", "ce_port"):
-            fix[gname + "/" + k] = g[k] if k != "ce_port" else g[k].astype(np.float64)
+        for k in ("snr_db", "sweep_idx", "trial", "fingerprint", "nmse_port", "ce_port", "seed"):
+            if k in g:
+                fix[gname + "/" + k] = g[k] if k != "ce_port" else g[k].astype(np.float64)
     with open(os.path.join(out, "summary.json"), "w") as f:
         json.dump(summ, f, indent=1)
     np.savez_compressed(os.path.join(out, "fixture.npz"), **fix)
