@@ -204,6 +204,13 @@ int jstsp_proposed_algorithm_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
         const int h = ((batch / 2 + 7) / 8) * 8, cnt[2] = {h, batch - h}, t0[2] = {0, h};
         Conv half0(cx[0], JSTSP_HOST), half1(cx[1], JSTSP_HOST);
         Conv *cvk[2] = {&half0, &half1};
+        // (a failure inside the pipeline must not return while the other half still reads the caller's host arrays or writes its
+        //  outputs: both streams are drained first - as in the _c32 entry)
+        auto drained = [&](int rc) {
+            if (rc) for (int k = 0; k < 2; ++k) { DeviceScope ds(cx[k]->device); (void)hipStreamSynchronize(cx[k]->stream); }
+            return rc;
+        };
+#define JSTSP_TRY_PIPE(expr) do { int rc_ = drained(expr); if (rc_ != 0) return rc_; } while (0)
         PendingSolve pend[2];
         const jstsp_c32 *yk[2], *ak[2], *bk[2];
         const float *ok[2];
@@ -215,22 +222,26 @@ int jstsp_proposed_algorithm_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
             ak[k] = c.in_dict(A + (size_t)t0[k] * strideA, (size_t)N * Gr, strideA, cnt[k]);
             bk[k] = c.in_dict(B + (size_t)t0[k] * strideB, (size_t)G2 * M, strideB, cnt[k]);
             ik[k] = c.in_raw(indx_S ? indx_S + t0[k] * g1 : nullptr, cnt[k] * g1);
-            JSTSP_TRY(c.rc);
-            JSTSP_TRY(proposed_enqueue_device(cx[k], N, M, Gr, G2, cnt[k], yk[k], ok[k], ak[k], strideA, bk[k], strideB, Imax, tau_Y + t0[k],
+            JSTSP_TRY_PIPE(c.rc);
+            JSTSP_TRY_PIPE(proposed_enqueue_device(cx[k], N, M, Gr, G2, cnt[k], yk[k], ok[k], ak[k], strideA, bk[k], strideB, Imax, tau_Y + t0[k],
                                               tau_S + t0[k], rho + t0[k], type, ik[k], ce_out != nullptr, &pend[k]));
         }
         int fallbacks = 0;
         for (int k = 0; k < 2; ++k) {
             Conv &c = *cvk[k];
             const PendingSolve &p = pend[k];
-            JSTSP_TRY(c.deliver(reinterpret_cast<const float *>(p.dS), reinterpret_cast<double *>(S_out + t0[k] * g1), 2 * cnt[k] * g1));
-            JSTSP_TRY(c.deliver(reinterpret_cast<const float *>(p.dY), reinterpret_cast<double *>(Y_out + t0[k] * nm1), 2 * cnt[k] * nm1));
+            JSTSP_TRY_PIPE(c.deliver(reinterpret_cast<const float *>(p.dS), reinterpret_cast<double *>(S_out + t0[k] * g1), 2 * cnt[k] * g1));
+            JSTSP_TRY_PIPE(c.deliver(reinterpret_cast<const float *>(p.dY), reinterpret_cast<double *>(Y_out + t0[k] * nm1), 2 * cnt[k] * nm1));
             if (p.want_ce)
-                JSTSP_HIP(hipMemcpyAsync(ce_out + (size_t)t0[k] * 3 * Imax, p.dce, (size_t)cnt[k] * 3 * Imax * sizeof(double),
-                                         hipMemcpyDeviceToHost, cx[k]->stream));
-            JSTSP_TRY(c.rc);
+            {
+                const hipError_t e_ = hipMemcpyAsync(ce_out + (size_t)t0[k] * 3 * Imax, p.dce, (size_t)cnt[k] * 3 * Imax * sizeof(double),
+                                                     hipMemcpyDeviceToHost, cx[k]->stream);
+                if (e_ != hipSuccess) set_error("proposed_algorithm: copying convergence_error failed: %s", hipGetErrorString(e_));
+                JSTSP_TRY_PIPE((int)e_);
+            }
+            JSTSP_TRY_PIPE(c.rc);
             std::vector<int> o;
-            JSTSP_TRY(proposed_pending_flags(cx[k], p, &o));
+            JSTSP_TRY_PIPE(proposed_pending_flags(cx[k], p, &o));
             for (size_t i = 0; i < o.size();) {            // runs of flagged trials again, without the fused pass
                 size_t j = i + 1;
                 while (j < o.size() && o[j] == o[j - 1] + 1) ++j;
@@ -238,15 +249,16 @@ int jstsp_proposed_algorithm_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
                 Conv cr(cx[k], JSTSP_HOST);
                 jstsp_c32 *s = cr.out(S_out + tg * g1, nrun * g1), *yo = cr.out(Y_out + tg * nm1, nrun * nm1);
                 double *ce = cr.out_raw(ce_out ? ce_out + (size_t)tg * 3 * Imax : nullptr, (size_t)nrun * 3 * Imax);
-                JSTSP_TRY(cr.rc);
-                JSTSP_TRY(proposed_resolve_device(cx[k], N, M, Gr, G2, nrun, yk[k] + r0 * nm1, ok[k] + r0 * nm1, ak[k] + (size_t)r0 * strideA,
+                JSTSP_TRY_PIPE(cr.rc);
+                JSTSP_TRY_PIPE(proposed_resolve_device(cx[k], N, M, Gr, G2, nrun, yk[k] + r0 * nm1, ok[k] + r0 * nm1, ak[k] + (size_t)r0 * strideA,
                                                   strideA, bk[k] + (size_t)r0 * strideB, strideB, Imax, tau_Y + tg, tau_S + tg, rho + tg,
                                                   type, ik[k] ? ik[k] + r0 * g1 : nullptr, s, yo, ce));
-                JSTSP_TRY(cr.finish());
+                JSTSP_TRY_PIPE(cr.finish());
                 fallbacks += nrun;
                 i = j;
             }
         }
+#undef JSTSP_TRY_PIPE
         ctx->fused_fallbacks = fallbacks;
         ctx->last_dict_block = (cx[0]->last_dict_block == cx[1]->last_dict_block) ? cx[0]->last_dict_block : 0;
         return 0;

@@ -308,7 +308,9 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         //  three-output call and never in a two-output call - pack_bs below)
     }
     if (refine) {
-        if (toep_gt && toep_env >= 2) {      // (JSTSP_TOEPLITZ=1 stays bit-identical to the unstructured path: full product there)
+        // (the assembly reads B columns below L = G2 / Gt and above M - L: it needs M >= L - a constant dictionary with fewer columns
+        //  than delay blocks passes the probe and takes the full product)
+        if (toep_gt && toep_env >= 2 && M >= G2 / toep_gt) {      // (JSTSP_TOEPLITZ=1 stays bit-identical to the unstructured path: full product there)
             // block (ld, ld') of G_B from block (0, ld' - ld) of the first block row and at most 3 (L - 1) products of leading /
             // trailing columns (fused.hip: toeplitz_gram_kernel), all in float64: 1 / L of the product
             float2 *G0 = ctx->arena.get<float2>((size_t)nB * toep_gt * G2), *G0lo = ctx->arena.get<float2>((size_t)nB * toep_gt * G2);
@@ -800,9 +802,16 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         jstsp_ctx *cx[2] = {ctx, ctx->helper};
         const int h = ((batch / 2 + 7) / 8) * 8, cnt[2] = {h, batch - h}, t0[2] = {0, h};
         PendingSolve pend[2];
+        // (a failure inside the pipeline - typically JSTSP_E_NOMEM for the helper's workspace - must not return while the other
+        //  half still reads the caller's host arrays or writes its outputs: both streams are drained first)
+        auto drained = [&](int rc) {
+            if (rc) for (int k = 0; k < 2; ++k) { DeviceScope ds(cx[k]->device); (void)hipStreamSynchronize(cx[k]->stream); }
+            return rc;
+        };
+#define JSTSP_TRY_PIPE(expr) do { int rc_ = drained(expr); if (rc_ != 0) return rc_; } while (0)
         for (int k = 0; k < 2; ++k) {
             cx[k]->fused_fallbacks = 0; cx[k]->last_dict_block = 0;
-            JSTSP_TRY(proposed_impl(cx[k], N, M, Gr, G2, cnt[k], subY + t0[k] * nm, Omega + t0[k] * nm, A + (size_t)t0[k] * strideA, strideA,
+            JSTSP_TRY_PIPE(proposed_impl(cx[k], N, M, Gr, G2, cnt[k], subY + t0[k] * nm, Omega + t0[k] * nm, A + (size_t)t0[k] * strideA, strideA,
                                     B + (size_t)t0[k] * strideB, strideB, Imax, tau_Y + t0[k], tau_S + t0[k], rho + t0[k], type,
                                     indx_S ? indx_S + t0[k] * g : nullptr, S_out + t0[k] * g, Y_out + t0[k] * nm,
                                     ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, JSTSP_HOST, true, nullptr, &pend[k]));
@@ -810,12 +819,13 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         int fallbacks = 0;
         for (int k = 0; k < 2; ++k) {
             std::vector<int> o;
-            JSTSP_TRY(proposed_finish(cx[k], pend[k], S_out + t0[k] * g, Y_out + t0[k] * nm, ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, &o));
-            JSTSP_TRY(resolve_overflowed(cx[k], o, N, M, Gr, G2, subY + t0[k] * nm, Omega + t0[k] * nm, A + (size_t)t0[k] * strideA, strideA,
+            JSTSP_TRY_PIPE(proposed_finish(cx[k], pend[k], S_out + t0[k] * g, Y_out + t0[k] * nm, ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, &o));
+            JSTSP_TRY_PIPE(resolve_overflowed(cx[k], o, N, M, Gr, G2, subY + t0[k] * nm, Omega + t0[k] * nm, A + (size_t)t0[k] * strideA, strideA,
                                          B + (size_t)t0[k] * strideB, strideB, Imax, tau_Y + t0[k], tau_S + t0[k], rho + t0[k], type,
                                          indx_S ? indx_S + t0[k] * g : nullptr, S_out + t0[k] * g, Y_out + t0[k] * nm,
                                          ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, JSTSP_HOST, &fallbacks));
         }
+#undef JSTSP_TRY_PIPE
         ctx->fused_fallbacks = fallbacks;
         ctx->last_dict_block = (cx[0]->last_dict_block == cx[1]->last_dict_block) ? cx[0]->last_dict_block : 0;
         return 0;

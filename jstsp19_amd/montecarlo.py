@@ -198,12 +198,16 @@ def _hip_solvers(device, metric="nmse"):
     return solve
 
 
-def _resolve_builder(builder):
+def _resolve_builder(builder, device=None):
     """None / "hip": the library's own input kernels; otherwise a callable hook (see ``run_points``)."""
     if builder is None or builder == "hip":
+        if device is not None and torch.device(device).type != "cuda":
+            raise ValueError("builder=None / 'hip' builds the inputs with the library's kernels and needs a CUDA (ROCm) device; on "
+                             "device=%r pass a callable builder (the CPU-side tests use tests/torch_builder.py: builder)" % (device,))
         return "hip"
     if not callable(builder):
-        raise ValueError("builder must be None, 'hip' or a callable (p, trial_ids, seed, sweep_idx, device, with_hbf) -> inputs")
+        raise ValueError("builder must be None, 'hip' or a callable (p, trial_ids, seed, sweep_idx, device, with_hbf) -> inputs "
+                         "(the torch tensor-op builder of rounds 1-3 is tests/torch_builder.py: builder)")
     return builder
 
 
@@ -260,7 +264,7 @@ def run_points(points, n_trials, *, Imax=100, batch=64, seed=20190913, device=No
     world = dist.get_world_size() if dist is not None else 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    builder = _resolve_builder(builder)
+    builder = _resolve_builder(builder, device)
     if metric not in ("nmse", "rate"):
         raise ValueError("metric must be 'nmse' or 'rate'")
     custom = solve_fn is not None
@@ -353,7 +357,7 @@ def run_approx_sweep(base: TrainingParams, snr_db_list, Imax_list, n_trials, *, 
     world = dist.get_world_size() if dist is not None else 1
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    builder = _resolve_builder(builder)
+    builder = _resolve_builder(builder, device)
     if solve_fn is None:
         solve_fn = _hip_alg12
     pts = [(si, ii) for si in range(len(snr_db_list)) for ii in range(len(Imax_list))]    # loop order of :34-38
@@ -429,7 +433,7 @@ def run_convergence_curves(points, n_trials=20, *, Imax=100, batch=20, seed=2019
     """
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    builder = _resolve_builder(builder)
+    builder = _resolve_builder(builder, device)
 
     def hip(inp, Imax_):
         from . import solvers as J
@@ -464,7 +468,7 @@ def run_zy(points=None, n_trials=1, *, Imax=50, batch=32, seed=20190913, device=
         points = zy_points()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    builder = _resolve_builder(builder)
+    builder = _resolve_builder(builder, device)
 
     def hip(inp, Imax_):
         from . import solvers as J

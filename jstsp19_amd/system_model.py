@@ -104,7 +104,8 @@ def build_trials_training(p: TrainingParams, trial0, batch, *, seed=20190913, sw
     the HIP path: the same library call as ``build_trials`` with the model fields that make it that builder — Gaussian
     Hermitian-Toeplitz pilots (:19-22), the unitary DFT combiner over all Nr outputs (:10), ``Lr = round(ratio*Nr)``
     of them kept per column (:5,:48-53), the frame T itself, ``rho = sqrt(lambda_6 (tau_X + tau_S)/2)`` (:51-53).
-    Same dict as ``build_inputs_training`` (tau_X, tau_S, rho; Zbar complex64, column-major)."""
+    Keys: subY, Omega, A, B, Zbar (complex64, column-major), indx_S, tau_X, tau_S, rho - the dict ``build_inputs_training`` of
+    tests/torch_builder.py returns."""
     q = SweepParams(p.Nt, p.Nr, p.L, p.T, p.Lr, Mr_e=p.Nr, Gr=p.Gr, Gt=p.Gt, clusters=p.clusters, rays=p.rays,
                     snr_db=p.snr_db, beamformer="fft", rho_rule="min", rho_scale=math.sqrt(0.75), T_prop=p.T)
     o = build_trials(q, trial0, batch, seed=seed, sweep_idx=sweep_idx, device=device, want_draws=want_draws, want_H=want_H,
@@ -120,7 +121,8 @@ def build_trials(p: SweepParams, trial0, batch, *, seed=20190913, sweep_idx=0, d
     """plot_errorVSsnr.m:57-136 for trials [trial0, trial0 + batch) on the HIP path
     (``jstsp_build_trials_c32``, csrc/inputgen.hip): draws, channel, pilots, measurement, A, B,
     hyper-parameters and indx_S are produced by the library's own kernels — nothing but the output
-    allocation goes through torch.  Same dict as ``build_inputs`` (Zbar complex64, column-major);
+    allocation goes through torch.  Keys: subY, Omega, A, B, Zbar (complex64, column-major), indx_S, tau_Y, tau_Z, rho
+    (the dict ``build_inputs`` of tests/torch_builder.py returns);
     ``shared_pilots``: one pilot set for the whole sweep point (``B`` identical for every trial: pass ``B[0]``).
     ``want_draws`` adds the raw draws (gains, u_r, u_t, noise, qam_idx) for checking against a CPU
     restatement.  The Philox streams are keyed by (seed, sweep_idx, global trial index).

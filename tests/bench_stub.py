@@ -42,6 +42,8 @@ class StubHooks:
 
     @staticmethod
     def solve(inp, imax, want_ce):
+        import time
+        time.sleep(0.02)                        # (so that the line's rounded ms_per_step resolves the step)
         v = trial_value(inp["ids"])
         return v, None, None
 

@@ -54,7 +54,7 @@ def test_headline_mode_two_ranks_partition_and_all_reduce():
     assert abs(two["mean_nmse"] - float(trial_value(range(2 * batch)).mean())) < 1e-12
     assert abs(one["mean_nmse"] - float(trial_value(range(batch)).mean())) < 1e-12
     # value = whole-job trials / max-over-ranks time
-    assert abs(two["value"] - 2 * batch * steps / (two["ms_per_step"] * 1e-3 * steps)) / two["value"] < 1e-3
+    assert abs(two["value"] - 2 * batch * steps / (two["ms_per_step"] * 1e-3 * steps)) / two["value"] < 1e-2
 
 
 @pytest.mark.timeout(900)
@@ -67,4 +67,4 @@ def test_sweep_mode_two_ranks_equals_one_rank():
     np.testing.assert_allclose(two["mean_nmse_proposed"], one["mean_nmse_proposed"], rtol=0, atol=1e-6)   # (rounded to 6 places in the line)
     np.testing.assert_allclose(two["mean_nmse_angles"], one["mean_nmse_angles"], rtol=0, atol=1e-6)
     assert len(set(two["mean_nmse_proposed"])) > 3             # the points differ: the stub scored real, per-key inputs
-    assert abs(two["value"] - 2 * 11 * 3 / (two["ms_per_step"] * 1e-3)) / two["value"] < 1e-3
+    assert abs(two["value"] - 2 * 11 * 3 / (two["ms_per_step"] * 1e-3)) / two["value"] < 1e-2
