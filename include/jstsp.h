@@ -104,6 +104,9 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         then the fp32 answer); never used for a reported number
  *   JSTSP_HOST_PIPELINE=0 a JSTSP_HOST proposed_algorithm call of 128 or more problems as ONE staged solve (default: its two halves on
  *                         two internal contexts, the upload of the second overlapping the solve of the first)
+ *   JSTSP_HOST_COMPACT=0  a JSTSP_HOST dictionary is uploaded whole (default 1: per-trial dictionaries of 64 MiB or more are tested
+ *                         for the block-Toeplitz structure on the host while they are staged and uploaded as first block +
+ *                         leading columns - bit-identical results; 2: at any size)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous
  *                         iteration's Ritz vector)

@@ -81,6 +81,28 @@ struct Conv {
     {
         return in(src, stride ? (size_t)(batch - 1) * (size_t)stride + elems : elems);
     }
+    // the per-trial dictionaries B of a JSTSP_HOST proposed_algorithm call: tested for the block-Toeplitz structure on the host
+    // and uploaded as fp32 first blocks + leading columns (hostpack.hip) - the link carries 1 / (2 L) of the doubles.  *gt = the
+    // block height (the caller hands it to the solver as a hint: no device probe), 0 = the plain route was taken.
+    const jstsp_c32 *in_dict_toeplitz(const jstsp_c64 *src, int G2, int M, long long stride, int batch, int *gt)
+    {
+        *gt = 0;
+        const size_t per = (size_t)G2 * M;
+        const bool tryit = memspace == JSTSP_HOST && tune().host_compact != 0 && tune().toeplitz != 0 && batch > 1 && G2 >= 32 &&
+                           stride == (long long)per && (per * batch * sizeof(jstsp_c64) >= ((size_t)128 << 20) || tune().host_compact >= 2) &&
+                           (long long)per < (1ll << 31);
+        if (tryit && !rc) {
+            const size_t ce = host_toeplitz_compact_elems(G2, M, batch);
+            float2 *bd = (float2 *)dmalloc(per * batch * sizeof(float2)), *cd = (float2 *)dmalloc(ce * sizeof(float2));
+            if (bd && cd) {
+                const int r = host_toeplitz_stage(ctx, reinterpret_cast<const double2 *>(src), G2, M, batch, bd, cd, ce, gt);
+                if (r) { rc = r; return nullptr; }
+                if (*gt) return reinterpret_cast<const jstsp_c32 *>(bd);
+            }
+            if (rc) return nullptr;
+        }
+        return in_dict(src, per, stride, batch);
+    }
     // arrays passed through unchanged (int32 indices, doubles the _c32 entry already takes)
     template <class T> const T *in_raw(const T *src, size_t n)
     {
@@ -220,9 +242,11 @@ int jstsp_proposed_algorithm_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
             yk[k] = c.in(subY + t0[k] * nm1, cnt[k] * nm1);
             ok[k] = c.in_real(Omega + t0[k] * nm1, cnt[k] * nm1);
             ak[k] = c.in_dict(A + (size_t)t0[k] * strideA, (size_t)N * Gr, strideA, cnt[k]);
-            bk[k] = c.in_dict(B + (size_t)t0[k] * strideB, (size_t)G2 * M, strideB, cnt[k]);
+            int hgt = 0;
+            bk[k] = c.in_dict_toeplitz(B + (size_t)t0[k] * strideB, G2, M, strideB, cnt[k], &hgt);
             ik[k] = c.in_raw(indx_S ? indx_S + t0[k] * g1 : nullptr, cnt[k] * g1);
             JSTSP_TRY_PIPE(c.rc);
+            cx[k]->dict_block_hint = hgt;               // (consumed by the solve enqueued next on this context)
             JSTSP_TRY_PIPE(proposed_enqueue_device(cx[k], N, M, Gr, G2, cnt[k], yk[k], ok[k], ak[k], strideA, bk[k], strideB, Imax, tau_Y + t0[k],
                                               tau_S + t0[k], rho + t0[k], type, ik[k], ce_out != nullptr, &pend[k]));
         }
@@ -264,13 +288,15 @@ int jstsp_proposed_algorithm_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, i
         return 0;
     }
     const size_t nm = (size_t)N * M * batch;
+    int hgt = 0;
     const jstsp_c32 *y = cv.in(subY, nm), *a = cv.in_dict(A, (size_t)N * Gr, strideA, batch),
-                    *b = cv.in_dict(B, (size_t)G2 * M, strideB, batch);
+                    *b = cv.in_dict_toeplitz(B, G2, M, strideB, batch, &hgt);
     const float *om = cv.in_real(Omega, nm);
     const int32_t *ix = cv.in_raw(indx_S, (size_t)Gr * G2 * batch);
     jstsp_c32 *s = cv.out(S_out, (size_t)Gr * G2 * batch), *yo = cv.out(Y_out, nm);
     double *ce = cv.out_raw(ce_out, (size_t)Imax * 3 * batch);
     JSTSP_TRY(cv.rc);
+    ctx->dict_block_hint = hgt;
     JSTSP_TRY(jstsp_proposed_algorithm_c32(ctx, N, M, Gr, G2, batch, y, om, a, strideA, b, strideB, Imax, tau_Y, tau_S,
                                            rho, type, ix, s, yo, ce, JSTSP_DEVICE));
     JSTSP_TRY(cv.finish());

@@ -78,6 +78,7 @@ struct Tuning {
                             // +2 % channel-estimates/s, but WORSE parity (rms |dNMSE| 2.18e-7 against 1.73e-7, a +5e-8 bias): off
     int rv_comp = 0;        // JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
     int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
+    int host_compact = 1;   // JSTSP_HOST_COMPACT: 0 a JSTSP_HOST dictionary is uploaded whole (no host-side block-Toeplitz test / compaction)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
     int bj_mask = 1;        // JSTSP_BJ_MASK: 0 the block Jacobi above order 128 without compute-unit masks (its sub-problems then compete with the panel products for units)
@@ -147,6 +148,13 @@ struct jstsp_ctx {
     // [0] warm-started lambda_max values of the last ADMM solve that a periodic cold verification contradicted (eig2.hip:
     // lanczos_lmax_kernel; jstsp_last_lanczos_mismatches), device memory
     unsigned *lz_mismatch = nullptr;
+    // pinned staging buffer of the host-side block-Toeplitz compaction (hostpack.hip), grow-only; hpin_done: its last upload
+    void *hpin = nullptr;
+    size_t hpin_cap = 0;
+    hipEvent_t hpin_done = nullptr;
+    bool hpin_pending = false;
+    int dict_block_hint = 0;     // set by a caller that has staged an EXPANDED block-Toeplitz dictionary itself (c64.hip): the block height,
+                                 // consumed by the next proposed_algorithm solve on this context instead of the device probe
     int last_dict_block = 0;     // block height of the block-Toeplitz structure the last fused solve found in its dictionary (0: none)
     int fused_fallbacks = 0;     // trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass
     float2 *unit = nullptr;      // device copy of the 1 x 1 identity factor (vamp.hip: the dense call is the Kronecker call with it)

@@ -196,10 +196,17 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     if (approx && tn.gram_refine && tn.rv_comp) need += 2 * rnd256((size_t)batch * g * sizeof(float2));     // low-order parts of v, R v
     if (approx && tn.gram_refine)      // low-order part of G_A, G_B's first block row (hi, lo)
         need += rnd256((size_t)nA * Gr * Gr * sizeof(float2)) + 2 * rnd256((size_t)nB * (G2 / 2 + 1) * G2 * sizeof(float2));
+    // a JSTSP_HOST dictionary of some size, one per trial, contiguous: tested for the block-Toeplitz structure on the host while
+    // it is staged, and uploaded as its first block + leading columns (hostpack.hip)
+    const bool host_compact = memspace == JSTSP_HOST && tn.host_compact != 0 && tn.toeplitz != 0 && nB > 1 && G2 >= 32 &&
+                              strideB == (long long)G2 * M && (szB * sizeof(float2) >= ((size_t)64 << 20) || tn.host_compact >= 2) &&
+                              (long long)G2 * M < (1ll << 31);       // (JSTSP_HOST_COMPACT=2: at any size - the tests)
+    const size_t compact_elems = host_compact ? host_toeplitz_compact_elems(G2, M, nB) : 0;
     if (memspace == JSTSP_HOST) {
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(batch * nm * sizeof(float)) +
                 rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
         if (angles) need += rnd256(batch * g * sizeof(int32_t));
+        need += rnd256(compact_elems * sizeof(float2));
     }
     JSTSP_TRY(ctx->arena.reserve(need));
     ctx->arena.reset();
@@ -210,6 +217,15 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(subY_), batch * nm, memspace, &subY));
     JSTSP_TRY(stage_in(ctx, Omega_, batch * nm, memspace, &Omega));
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
+    int known_gt = ctx->dict_block_hint;        // (a caller that expanded a block-Toeplitz dictionary itself: c64.hip)
+    ctx->dict_block_hint = 0;
+    if (host_compact) {
+        float2 *Bd = ctx->arena.get<float2>(szB), *Cd = ctx->arena.get<float2>(compact_elems);
+        JSTSP_REQUIRE(Bd && Cd, JSTSP_E_NOMEM, "workspace exhausted while staging an input");
+        JSTSP_TRY(host_toeplitz_stage(ctx, reinterpret_cast<const float2 *>(B_), G2, M, nB, Bd, Cd, compact_elems, &known_gt));
+        if (!known_gt) JSTSP_HIP(hipMemcpyAsync(Bd, B_, szB * sizeof(float2), hipMemcpyHostToDevice, ctx->stream));
+        B = Bd;
+    } else
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(B_), szB, memspace, &B));
     if (angles) JSTSP_TRY(stage_in(ctx, indx_S_, batch * g, memspace, &indx_S));
     if (memspace == JSTSP_DEVICE)
@@ -297,6 +313,10 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     } else
     JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, Gr, N, nA, Am, Am, w.GA, (long long)Gr * Gr, Gr));
     // the block-Toeplitz probe (fused.hip) serves the Gram as well as the pass
+    if (toep_env != 0 && known_gt && strideB) {        // found on the host while staging (exact by construction): no device probe
+        toep_gt = known_gt;
+        toep_probed = true;
+    } else
     if (toep_env != 0 && (long long)G2 * M < (1ll << 31) && refine) {
         JSTSP_TRY(fused_probe_toeplitz(ctx, ctx->arena, B, strideB, G2, M, nB, &toep_gt));
         toep_probed = true;

@@ -40,6 +40,7 @@ void load_tuning()
     t.bj_mask = env_int("JSTSP_BJ_MASK", t.bj_mask);
     t.gram_refine = env_int("JSTSP_GRAM_REFINE", t.gram_refine);
     t.host_pipeline = env_int("JSTSP_HOST_PIPELINE", t.host_pipeline);
+    t.host_compact = env_int("JSTSP_HOST_COMPACT", t.host_compact);
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     t.rv_comp = env_int("JSTSP_RV_COMP", t.rv_comp);
@@ -531,6 +532,8 @@ int jstsp_destroy(jstsp_ctx *ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->diag) (void)hipFree(ctx->diag);
     if (ctx->lz_mismatch) (void)hipFree(ctx->lz_mismatch);
+    if (ctx->hpin_done) { (void)hipEventSynchronize(ctx->hpin_done); (void)hipEventDestroy(ctx->hpin_done); }
+    if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->unit) (void)hipFree(ctx->unit);
     ctx->arena.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

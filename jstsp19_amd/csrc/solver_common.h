@@ -154,6 +154,13 @@ template <class T> int stage_out(jstsp_ctx *ctx, T *dst, const T *dev, size_t n,
 }
 inline size_t rnd256(size_t b) { return (b + 255) & ~size_t(255); }
 
+// Host-side staging of a block-Toeplitz dictionary (hostpack.hip): T = float2 or double2 (narrowed while copying).
+// *gt_out = the block height when the compact route was taken (Bdev then receives the expanded array on ctx->stream), 0 otherwise
+// (nothing uploaded).  Cdev: device room for the compact form, host_toeplitz_compact_elems() float2.
+template <class T>
+int host_toeplitz_stage(jstsp_ctx *ctx, const T *Bh, int G2, int M, int nB, float2 *Bdev, float2 *Cdev, size_t cdev_elems, int *gt_out);
+size_t host_toeplitz_compact_elems(int G2, int M, int nB);
+
 // ---- one pass over the dictionary per iteration (fused.hip) ---------------------------------
 struct FusedWS {
     uint4 *Bf = nullptr; long long sBf = 0;       // tile images of B, uint4 per problem

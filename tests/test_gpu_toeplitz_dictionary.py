@@ -218,3 +218,65 @@ def test_window_kernel_at_odd_batch_sizes_and_frame_lengths(L, T, batch, Imax):
     _same(r1, r0)
     _close(r2, r0)
     _close(w2, w0)
+
+
+def _host_solve(inp, Imax, env, B=None, c64=False):
+    """The JSTSP_HOST call through the C ABI (numpy arrays in and out: what a MEX gateway passes); c64: MATLAB's doubles."""
+    import ctypes as C
+    import jstsp19_amd as J
+    from jstsp19_amd import _lib
+    env = dict(env)
+    for k, v in env.items():
+        os.environ[k] = v
+    try:
+        cd, rd = (np.complex128, np.float64) if c64 else (np.complex64, np.float32)
+        f = lambda x, dt: np.ascontiguousarray(np.swapaxes(x.cpu().numpy(), -1, -2)).astype(dt)      # column-major bytes, trial slowest
+        Bt = inp["B"] if B is None else B
+        sy, om, a, b = f(inp["subY"], cd), f(inp["Omega"], rd), f(inp["A"], cd), f(Bt, cd)
+        batch, N, M = inp["subY"].shape
+        Gr, G2 = inp["A"].shape[-1], Bt.shape[1]
+        S, Y = np.empty(batch * Gr * G2, cd), np.empty(batch * N * M, cd)
+        ce = np.empty(batch * 3 * Imax, np.float64)
+        p = lambda z: z.ctypes.data_as(C.c_void_p)
+        dp = lambda z: np.ascontiguousarray(z.numpy(), np.float64)
+        ty, ts, rh = dp(inp["tau_Y"]), dp(inp["tau_Z"]), dp(inp["rho"])
+        ctx = J.default_context(0)
+        fn = getattr(ctx._lib, "jstsp_proposed_algorithm_" + ("c64" if c64 else "c32"))
+        d = lambda z: z.ctypes.data_as(C.POINTER(C.c_double))
+        _lib.check(fn(ctx.handle, N, M, Gr, G2, batch, p(sy), p(om), p(a), 0, p(b), G2 * M, Imax, d(ty), d(ts), d(rh), 0, None,
+                      p(S), p(Y), p(ce), 0), "proposed")
+        gt = ctx.last_dictionary_block()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    return [S, Y, ce], gt
+
+
+@pytest.mark.parametrize("c64", [False, True], ids=["c32", "c64"])
+@pytest.mark.parametrize("Nt,L,T,batch", [(64, 8, 4, 5), (16, 8, 32, 6), (32, 12, 24, 3)])
+def test_host_side_compaction_is_bit_identical_and_falls_back_on_the_first_mismatch(Nt, L, T, batch, c64):
+    """JSTSP_HOST: the dictionary is tested on the host while it is staged and uploaded as first block + leading columns
+    (csrc/hostpack.hip; JSTSP_HOST_COMPACT=2 forces the route at these small sizes).  Same results, bit for bit, as the plain
+    upload (=0) - with free leading columns, and for a dictionary with one entry off by one ulp (the plain upload is taken)."""
+    import torch
+    from jstsp19_amd.system_model import build_trials
+    p = _params(Nt, L, T)
+    inp = build_trials(p, 0, batch, seed=31)
+    B = inp["B"].clone()
+    g = torch.Generator(device=B.device); g.manual_seed(2)
+    for ld in range(1, L):                                       # columns m < ld of block ld: anything goes
+        blk = B[:, ld * Nt:(ld + 1) * Nt, :ld]
+        B[:, ld * Nt:(ld + 1) * Nt, :ld] = 0.3 * torch.complex(torch.randn(blk.shape, generator=g, device=B.device),
+                                                               torch.randn(blk.shape, generator=g, device=B.device))
+    for Bt in (None, B):
+        r0, gt0 = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "0"}, B=Bt, c64=c64)
+        r1, gt1 = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "2"}, B=Bt, c64=c64)
+        assert gt0 == Nt and gt1 == Nt
+        _same(r1, r0)
+    B2 = inp["B"].clone()
+    v = torch.view_as_real(B2)
+    v[batch - 1, 3 * Nt + 1, 40, 1] = torch.nextafter(v[batch - 1, 3 * Nt + 1, 40, 1], torch.tensor(10.0, device=B.device))
+    r2, gt2 = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "2"}, B=B2, c64=c64)
+    r3, gt3 = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "0"}, B=B2, c64=c64)
+    assert gt2 == 0 and gt3 == 0
+    _same(r2, r3)
