@@ -78,6 +78,7 @@ struct Tuning {
                             // +2 % channel-estimates/s, but WORSE parity (rms |dNMSE| 2.18e-7 against 1.73e-7, a +5e-8 bias): off
     int rv_comp = 0;        // JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
     int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
+    int pass_acc = 0;       // JSTSP_PASS_ACC: 0 products of K B^H straight into the pass's running sums, 1 / 2 per-tile block sums first (fused.hip)
     int host_compact = 1;   // JSTSP_HOST_COMPACT: 0 a JSTSP_HOST dictionary is uploaded whole (no host-side block-Toeplitz test / compaction)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v

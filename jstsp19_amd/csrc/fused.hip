@@ -746,7 +746,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
 // The leading columns (m < ld of block ld: 28 of the 4096 x 8 column-blocks) are outside the Toeplitz part.  They enter
 // as fp32 corrections: XsD = (A S) Delta is added to Xs in the first tile (xs_delta, formed with the (A S) fragments), the
 // first L - 1 columns of k are stored, and the sum of the partial sums adds k(:, m) conj(B(g, m)) (reduce_parts_delta_kernel).
-template <int GB, int DBG>
+template <int GB, int DBG, int ACC = 0>
 __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
 {
     constexpr int G2 = 128 * GB;
@@ -1084,13 +1084,39 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                     u32x4 k0 = *reinterpret_cast<const u32x4 *>(kp), k1 = *reinterpret_cast<const u32x4 *>(kp + 1024);
                     const u32x4 k2 = *reinterpret_cast<const u32x4 *>(kp + 2048), k3 = *reinterpret_cast<const u32x4 *>(kp + 3072);
                     // re += Br kr + Bi ki ; im += Br ki - Bi kr
-                    pr[gb][n2] = mma(bf[0], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k2, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[0], k1, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k3, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[1], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[1], k2, pi[gb][n2]);
-                    k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
-                    pr[gb][n2] = mma(bf[2], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k0, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[2], k3, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k1, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[3], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[3], k0, pi[gb][n2]);
+                    // ACC = 0: every product accumulates straight into the running sums (rounds 2-4).  ACC = 1 / 2 (round 5): the six
+                    // products of a tile's block are summed in fresh accumulators and added to the running sums ONCE - the running
+                    // sum, 32 tiles long, is rounded once per tile instead of six times (the fp32 accumulation noise of K B^H is the
+                    // largest single term of the parity floor); 1: real and imaginary chains interleaved (8 more
+                    // registers), 2: one after the other (4)
+                    if constexpr (ACC == 0) {
+                        pr[gb][n2] = mma(bf[0], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k2, pi[gb][n2]);
+                        pr[gb][n2] = mma(bf[0], k1, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k3, pi[gb][n2]);
+                        pr[gb][n2] = mma(bf[1], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[1], k2, pi[gb][n2]);
+                        k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
+                        pr[gb][n2] = mma(bf[2], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k0, pi[gb][n2]);
+                        pr[gb][n2] = mma(bf[2], k3, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k1, pi[gb][n2]);
+                        pr[gb][n2] = mma(bf[3], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[3], k0, pi[gb][n2]);
+                    } else if constexpr (ACC == 1) {
+                        f32x4 tr = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f}), ti = mma(bf[0], k2, f32x4{0.f, 0.f, 0.f, 0.f});
+                        tr = mma(bf[0], k1, tr); ti = mma(bf[0], k3, ti);
+                        tr = mma(bf[1], k0, tr); ti = mma(bf[1], k2, ti);
+                        k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
+                        tr = mma(bf[2], k2, tr); ti = mma(bf[2], k0, ti);
+                        tr = mma(bf[2], k3, tr); ti = mma(bf[2], k1, ti);
+                        tr = mma(bf[3], k2, tr); ti = mma(bf[3], k0, ti);
+                        pr[gb][n2] += tr; pi[gb][n2] += ti;
+                    } else {
+                        f32x4 tt = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f});
+                        tt = mma(bf[0], k1, tt); tt = mma(bf[1], k0, tt);
+                        tt = mma(bf[2], k2, tt); tt = mma(bf[2], k3, tt); tt = mma(bf[3], k2, tt);
+                        k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
+                        f32x4 tu = mma(bf[0], k2, f32x4{0.f, 0.f, 0.f, 0.f});
+                        pr[gb][n2] += tt;
+                        tu = mma(bf[0], k3, tu); tu = mma(bf[1], k2, tu);
+                        tu = mma(bf[2], k0, tu); tu = mma(bf[2], k1, tu); tu = mma(bf[3], k0, tu);
+                        pi[gb][n2] += tu;
+                    }
                     {
                         const int grp = 4 * gb + n2;
                         if (grp >= 6 && grp - 6 < 12) F64_STORE(grp - 6, (i + 1) & 1, rf[((grp - 6) >> 2) & 1][(grp - 6) & 3])
@@ -1367,8 +1393,20 @@ template <int GB> static int launch_fused64(jstsp_ctx *ctx, const FusedDesc &d)
 #undef DBG_CASE
     }
 #endif
-    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL((fused_pass64_kernel<GB, 0>), dim3(grid), dim3(512), sh, ctx->stream, d);
+    // JSTSP_PASS_ACC: how the products of K B^H enter their running sums (see phase B of the kernel)
+    switch (tune().pass_acc) {
+    case 1:
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 1>), dim3(grid), dim3(512), sh, ctx->stream, d);
+        break;
+    case 2:
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 2>), dim3(grid), dim3(512), sh, ctx->stream, d);
+        break;
+    default:
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 0>), dim3(grid), dim3(512), sh, ctx->stream, d);
+    }
     return 0;
 }
 

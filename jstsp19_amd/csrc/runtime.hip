@@ -41,6 +41,7 @@ void load_tuning()
     t.gram_refine = env_int("JSTSP_GRAM_REFINE", t.gram_refine);
     t.host_pipeline = env_int("JSTSP_HOST_PIPELINE", t.host_pipeline);
     t.host_compact = env_int("JSTSP_HOST_COMPACT", t.host_compact);
+    t.pass_acc = env_int("JSTSP_PASS_ACC", t.pass_acc);
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     t.rv_comp = env_int("JSTSP_RV_COMP", t.rv_comp);

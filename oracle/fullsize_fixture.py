@@ -15,8 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 IMAX = 100
 
 
-def fixture():
-    z = np.load(os.path.join(ROOT, "tests", "golden", "fullsize_port.npz"))
+def fixture(name="fullsize_port"):
+    """``fullsize_port``: the 3008 trials of round 4 (generator seed 20190913 - the set the round-4 defaults were chosen on);
+    ``fullsize_port_heldout``: 2560 + 1280 trials of another seed (round 5), never used to choose a switch."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
     return {k: z[k] for k in z.files}
 
 
@@ -39,7 +41,8 @@ def solve_group(fx, group, rows, *, want_ce, angles, chunk=256):
             j += 1
         r = rows[i:j]
         p = SweepParams(Nt=64, Nr=64, L=8, T=64, Mr=8, snr_db=float(snr[r[0]]))
-        inp = build_trials(p, int(trial[r[0]]), len(r), sweep_idx=int(sidx[r[0]]))
+        seed = int(fx[group + "/seed"][r[0]]) if (group + "/seed") in fx else 20190913
+        inp = build_trials(p, int(trial[r[0]]), len(r), seed=seed, sweep_idx=int(sidx[r[0]]))
         f = torch.stack([inp["subY"].abs().double().sum((1, 2)), inp["B"].abs().double().sum((1, 2)),
                          inp["Omega"].double().sum((1, 2))], 1).cpu().numpy()
         np.testing.assert_allclose(f, fp[r][:, :3], rtol=1e-9, err_msg="the generator no longer reproduces the fixture's inputs")

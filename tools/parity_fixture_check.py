@@ -19,11 +19,12 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="rows (0 = all), taken with a stride that covers every SNR point")
     ap.add_argument("--two-output", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--fixture", default="fullsize_port", help="fullsize_port (the set defaults are chosen on) or fullsize_port_heldout")
     ap.add_argument("variants", nargs="*", default=[""])
     a = ap.parse_args()
     import time
     from oracle.fullsize_fixture import fixture, solve_group
-    fx = fixture()
+    fx = fixture(a.fixture)
     total = len(fx[a.group + "/nmse_port"])
     rows = np.arange(total)
     if a.n and a.n < total:                       # blocks of 64 consecutive trials spread over the group
