@@ -104,13 +104,17 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         then the fp32 answer); never used for a reported number
  *   JSTSP_HOST_PIPELINE=0 a JSTSP_HOST proposed_algorithm call of 128 or more problems as ONE staged solve (default: its two halves on
  *                         two internal contexts, the upload of the second overlapping the solve of the first)
+ *   JSTSP_PASS_ACC=0      window pass: every product of K B^H accumulates straight into the 32-tile running sums (rounds 2-4;
+ *                         default 1: the six products of a tile's block are summed first, the running sum rounded once per tile)
+ *   JSTSP_INV2=0          the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (default 1: formed in the pass from
+ *                         Omega as two floats)
  *   JSTSP_HOST_COMPACT=0  a JSTSP_HOST dictionary is uploaded whole (default 1: per-trial dictionaries of 64 MiB or more are tested
  *                         for the block-Toeplitz structure on the host while they are staged and uploaded as first block +
  *                         leading columns - bit-identical results; 2: at any size)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous
  *                         iteration's Ritz vector)
- *   JSTSP_LANCZOS_VERIFY=n  a warm-started lambda_max is checked against the cold run every n-th call per matrix (default 32;
+ *   JSTSP_LANCZOS_VERIFY=n  a warm-started lambda_max is checked against the cold run every n-th call (default 32;
  *                         0 never, 1 always - then every returned value is the cold one; jstsp_last_lanczos_mismatches)
  *   JSTSP_EIG128=0        general Jacobi kernel (basis in HBM) for Gram orders 65..128
  *   JSTSP_OMP_PERSIST=0   jstsp_omp with ONE problem: two launches per OMP iteration instead of all iterations in one
@@ -224,8 +228,8 @@ int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count);
 /* Spectral norms inside the ADMM loops (convergence_error of proposed_algorithm.m:67,69, sparse_admm.m:32, mc_admm.m:28):
  * lambda_max of each Gram is computed by a Lanczos run that starts from the Ritz vector of the SAME matrix one iteration
  * earlier and stops when the residual of the Ritz pair is below 1e-5 lambda (a cold n-step run otherwise, and always at the
- * first iteration).  Every JSTSP_LANCZOS_VERIFY-th call per matrix (default 32, staggered over the matrices) the cold run is
- * done as well and its value returned; *count = how many of those checks of the last solve on this context differed from
+ * first iteration).  Every JSTSP_LANCZOS_VERIFY-th call (default 32) the cold run is done as well, for all matrices of the
+ * call, and its value returned; *count = how many of those checks of the last solve on this context differed from
  * the warm-started value by more than 2e-5 relative (0 on every input measured so far; one stream synchronisation). */
 int jstsp_last_lanczos_mismatches(jstsp_ctx *ctx, int *count);
 

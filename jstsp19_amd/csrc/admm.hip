@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void form_z_kernel(long long nm, const float2 
                                                      const TrialParams *prm, float2 *Z)
 {
     const int t = blockIdx.y;
-    const float ir = prm[t].irho;
+    const TrialParams p = prm[t];
     const long long base = (long long)t * nm;
     const long long stride = (long long)gridDim.x * 256 * 2;
     const bool vec = (nm & 1) == 0;     // per-problem bases stay 16-byte aligned only for even nm
@@ -47,13 +47,13 @@ __global__ __launch_bounds__(256) void form_z_kernel(long long nm, const float2 
         if (vec && i + 1 < nm) {
             const c2 x = ld2(X, base + i), v = ld2(V1, base + i);
             c2 z;
-            z.a = make_float2(x.a.x - ir * v.a.x, x.a.y - ir * v.a.y);
-            z.b = make_float2(x.b.x - ir * v.b.x, x.b.y - ir * v.b.y);
+            z.a = make_float2(admm_z(p, x.a.x, v.a.x), admm_z(p, x.a.y, v.a.y));
+            z.b = make_float2(admm_z(p, x.b.x, v.b.x), admm_z(p, x.b.y, v.b.y));
             st2(Z, base + i, z);
         } else {
             for (long long j = i; j < nm && j < i + 2; ++j) {
                 const float2 x = X[base + j], v = V1[base + j];
-                Z[base + j] = make_float2(x.x - ir * v.x, x.y - ir * v.y);
+                Z[base + j] = make_float2(admm_z(p, x.x, v.x), admm_z(p, x.y, v.y));
             }
         }
     }
@@ -65,13 +65,15 @@ __global__ __launch_bounds__(256) void form_z_kernel(long long nm, const float2 
 //   V1 = V1 + rho (Y - X)                                                    (:64; depends only on Y, X)
 __device__ __forceinline__ void upd_x_one(float2 &x, float2 &v1, const float2 v2, const float2 c,
                                           const float2 xs, const float2 y, const float2 sy,
-                                          const float id, const float rho, const float ir, float2 &k)
+                                          const float id, const TrialParams &p, float2 &k)
 {
-    const float bx = v1.x + rho * y.x + sy.x + v2.x + rho * c.x + rho * xs.x;
-    const float by = v1.y + rho * y.y + sy.y + v2.y + rho * c.y + rho * xs.y;
+    // (rho and 1/rho as two floats each: common.h)
+    const float tx = (y.x + c.x) + xs.x, ty = (y.y + c.y) + xs.y;
+    const float bx = (v1.x + sy.x) + v2.x + mul2(p.rho, p.rho_lo, tx);
+    const float by = (v1.y + sy.y) + v2.y + mul2(p.rho, p.rho_lo, ty);
     x = make_float2(bx * id, by * id);
-    k = make_float2(x.x - ir * v2.x - c.x, x.y - ir * v2.y - c.y);
-    v1 = make_float2(v1.x + rho * (y.x - x.x), v1.y + rho * (y.y - x.y));
+    k = make_float2((fmaf(-p.irho, v2.x, x.x) - p.irho_lo * v2.x) - c.x, (fmaf(-p.irho, v2.y, x.y) - p.irho_lo * v2.y) - c.y);
+    v1 = make_float2(admm_v1(p, v1.x, y.x, x.x), admm_v1(p, v1.y, y.y, x.y));
 }
 
 __global__ __launch_bounds__(256) void update_x_kernel(long long nm, float2 *X, float2 *V1,
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void update_x_kernel(long long nm, float2 *X, 
                                                        const TrialParams *prm, float2 *K)
 {
     const int t = blockIdx.y;
-    const float rho = prm[t].rho, ir = prm[t].irho;
+    const TrialParams p = prm[t];
     const long long base = (long long)t * nm;
     const long long stride = (long long)gridDim.x * 256 * 2;
     const bool vec = (nm & 1) == 0;     // per-problem bases stay 16-byte aligned only for even nm
@@ -91,14 +93,14 @@ __global__ __launch_bounds__(256) void update_x_kernel(long long nm, float2 *X, 
             const c2 v2 = ld2(V2, base + i), c = ld2(C, base + i), xs = ld2(Xs, base + i),
                      y = ld2(Y, base + i), sy = ld2(subY, base + i);
             const float2 id = *reinterpret_cast<const float2 *>(invD + base + i);
-            upd_x_one(x.a, v1.a, v2.a, c.a, xs.a, y.a, sy.a, id.x, rho, ir, k.a);
-            upd_x_one(x.b, v1.b, v2.b, c.b, xs.b, y.b, sy.b, id.y, rho, ir, k.b);
+            upd_x_one(x.a, v1.a, v2.a, c.a, xs.a, y.a, sy.a, id.x, p, k.a);
+            upd_x_one(x.b, v1.b, v2.b, c.b, xs.b, y.b, sy.b, id.y, p, k.b);
             st2(X, base + i, x); st2(V1, base + i, v1); st2(K, base + i, k);
         } else {
             for (long long j = i; j < nm && j < i + 2; ++j) {
                 float2 x, k, v1 = V1[base + j];
                 upd_x_one(x, v1, V2[base + j], C[base + j], Xs[base + j], Y[base + j], subY[base + j],
-                          invD[base + j], rho, ir, k);
+                          invD[base + j], p, k);
                 X[base + j] = x; V1[base + j] = v1; K[base + j] = k;
             }
         }
@@ -108,18 +110,21 @@ __global__ __launch_bounds__(256) void update_x_kernel(long long nm, float2 *X, 
 // ---- sub-problem 4 + V2 dual update --------------------------------------------------------
 //   C  = rho/(rho+1) (X - Xs - V2/rho)        (:61)
 //   V2 = V2 + rho (C - X + Xs)                (:65)
-__device__ __forceinline__ void upd_c_one(const float2 x, const float2 xs, float2 &v2, float2 &c,
-                                          const float rho, const float ir, const float cc)
+__device__ __forceinline__ void upd_c_one(const float2 x, const float2 xs, float2 &v2, float2 &c, const TrialParams &p)
 {
-    c = make_float2(cc * (x.x - xs.x - ir * v2.x), cc * (x.y - xs.y - ir * v2.y));
-    v2 = make_float2(v2.x + rho * (c.x - x.x + xs.x), v2.y + rho * (c.y - x.y + xs.y));
+    // (rho, 1/rho and rho/(rho+1) as two floats each: common.h)
+    const float dx = x.x - xs.x, dy = x.y - xs.y;
+    const float tx = fmaf(-p.irho, v2.x, dx) - p.irho_lo * v2.x, ty = fmaf(-p.irho, v2.y, dy) - p.irho_lo * v2.y;
+    c = make_float2(mul2(p.c_coef, p.c_lo, tx), mul2(p.c_coef, p.c_lo, ty));
+    const float ux = c.x - dx, uy = c.y - dy;
+    v2 = make_float2(fmaf(p.rho, ux, v2.x) + p.rho_lo * ux, fmaf(p.rho, uy, v2.y) + p.rho_lo * uy);
 }
 
 __global__ __launch_bounds__(256) void update_c_kernel(long long nm, const float2 *X, const float2 *Xs,
                                                        float2 *V2, float2 *C, const TrialParams *prm)
 {
     const int t = blockIdx.y;
-    const float rho = prm[t].rho, ir = prm[t].irho, cc = prm[t].c_coef;
+    const TrialParams p = prm[t];
     const long long base = (long long)t * nm;
     const long long stride = (long long)gridDim.x * 256 * 2;
     const bool vec = (nm & 1) == 0;     // per-problem bases stay 16-byte aligned only for even nm
@@ -127,13 +132,13 @@ __global__ __launch_bounds__(256) void update_c_kernel(long long nm, const float
         if (vec && i + 1 < nm) {
             const c2 x = ld2(X, base + i), xs = ld2(Xs, base + i);
             c2 v2 = ld2(V2, base + i), c;
-            upd_c_one(x.a, xs.a, v2.a, c.a, rho, ir, cc);
-            upd_c_one(x.b, xs.b, v2.b, c.b, rho, ir, cc);
+            upd_c_one(x.a, xs.a, v2.a, c.a, p);
+            upd_c_one(x.b, xs.b, v2.b, c.b, p);
             st2(C, base + i, c); st2(V2, base + i, v2);
         } else {
             for (long long j = i; j < nm && j < i + 2; ++j) {
                 float2 v2 = V2[base + j], c;
-                upd_c_one(X[base + j], Xs[base + j], v2, c, rho, ir, cc);
+                upd_c_one(X[base + j], Xs[base + j], v2, c, p);
                 C[base + j] = c; V2[base + j] = v2;
             }
         }
@@ -145,11 +150,11 @@ __global__ __launch_bounds__(256) void inv_d_kernel(long long nm, const float *O
                                                     const TrialParams *prm, float *invD)
 {
     const int t = blockIdx.y;
-    const float add = scale * prm[t].rho;
+    const double add = (double)scale * ((double)prm[t].rho + (double)prm[t].rho_lo);      // (rho as two floats: common.h)
     const long long base = (long long)t * nm;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nm; i += stride)
-        invD[base + i] = 1.f / (Omega[base + i] + add);
+        invD[base + i] = (float)(1.0 / ((double)Omega[base + i] + add));
 }
 
 __device__ __forceinline__ float soft1(float v, float t)

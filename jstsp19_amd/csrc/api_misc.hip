@@ -30,14 +30,15 @@ __global__ __launch_bounds__(256) void mc_svt_update_kernel(long long nm, float2
                                                             const TrialParams *prm)
 {
     const int t = blockIdx.y;
-    const float rho = prm[t].rho;
+    const TrialParams p = prm[t];               // (rho as two floats: common.h)
     const long long base = (long long)t * nm, stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nm; i += stride) {
         const float om = Omega[base + i];
         const float2 x = X[base + i], oh = OH[base + i];
         float2 y = Y[base + i];
-        y.x += rho * (oh.x - om * x.x);
-        y.y += rho * (oh.y - om * x.y);
+        const float dx = oh.x - om * x.x, dy = oh.y - om * x.y;
+        y.x = fmaf(p.rho, dx, y.x) + p.rho_lo * dx;
+        y.y = fmaf(p.rho, dy, y.y) + p.rho_lo * dy;
         Y[base + i] = y;
     }
 }
@@ -49,18 +50,18 @@ __global__ __launch_bounds__(256) void mc_admm_update_kernel(long long nm, float
                                                              float2 *Zn)
 {
     const int t = blockIdx.y;
-    const float rho = prm[t].rho, ir = prm[t].irho;
+    const TrialParams p = prm[t];               // (rho, 1/rho as two floats each: common.h)
     const long long base = (long long)t * nm, stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nm; i += stride) {
         const float id = invD[base + i];
         const float2 x = X[base + i], oh = OH[base + i];
         float2 z = Z[base + i];
-        const float2 y = make_float2((oh.x + z.x + rho * x.x) * id, (oh.y + z.y + rho * x.y) * id);
-        z.x += rho * (x.x - y.x);
-        z.y += rho * (x.y - y.y);
+        const float2 y = make_float2(((oh.x + z.x) + mul2(p.rho, p.rho_lo, x.x)) * id, ((oh.y + z.y) + mul2(p.rho, p.rho_lo, x.y)) * id);
+        z.x = admm_v1(p, z.x, x.x, y.x);        // Z + rho (X - Y)
+        z.y = admm_v1(p, z.y, x.y, y.y);
         Y[base + i] = y;
         Z[base + i] = z;
-        Zn[base + i] = make_float2(y.x - ir * z.x, y.y - ir * z.y);
+        Zn[base + i] = make_float2(admm_z(p, y.x, z.x), admm_z(p, y.y, z.y));
     }
 }
 
@@ -170,12 +171,7 @@ static int upload_tau_rho(jstsp_ctx *ctx, int batch, const double *tau, const do
 {
     std::vector<TrialParams> hp(batch);
     for (int t = 0; t < batch; ++t) {
-        const double r = rho ? rho[t] : 1.0;
-        hp[t].rho = (float)r;
-        hp[t].irho = (float)(1.0 / r);
-        hp[t].tauY_rho = (float)(tau[t] / r);
-        hp[t].tauS_rho = 0.f;
-        hp[t].c_coef = (float)(r / (r + 1.0));
+        hp[t] = make_trial_params(rho ? rho[t] : 1.0, tau[t], 0.0);
     }
     return upload(ctx, prm, hp.data(), batch * sizeof(TrialParams));
 }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
     float2 rb2[(EPI == EPI_UPDATE_X) ? NLB : 1];        // second b source (EPI_UPDATE_X: Z = X - V1/rho formed here)
     const bool two_b = (EPI == EPI_UPDATE_X) && d.B2 != nullptr;
     const long long boff2 = two_b ? (d.B2 - d.B) : 0;   // same strides: element e of B2 sits boff2 elements after B's
-    const float bir = two_b ? d.prm[t].irho : 0.f;
+    const float bir = two_b ? d.prm[t].irho : 0.f, birl = two_b ? d.prm[t].irho_lo : 0.f;     // (1/rho as two floats: common.h)
     const float2 *pa[NLA], *pb[NLB];
     int la[NLA], lb[NLB], ka[NLA], kb[NLB];
     bool va[NLA], vb[NLB];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
 #pragma unroll
         for (int p = 0; p < NLB; ++p) {
             float2 v = rb[p];
-            if constexpr (EPI == EPI_UPDATE_X) { if (two_b) { v.x -= bir * rb2[p].x; v.y -= bir * rb2[p].y; } }
+            if constexpr (EPI == EPI_UPDATE_X) { if (two_b) { v.x = fmaf(-bir, rb2[p].x, v.x) - birl * rb2[p].x; v.y = fmaf(-bir, rb2[p].y, v.y) - birl * rb2[p].y; } }
             const bool ok = vb[p] && (!tail || (tail_k0 + kb[p] < kend));
             if (!ok) v = make_float2(0.f, 0.f);
             v.y *= sgnB;
@@ -297,8 +297,7 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
             };
             const bool odd = lane & 1;
             const int gi2 = gi & ~1;
-            const float rho = d.prm[t].rho, ir = d.prm[t].irho;
-            const float omr = 1.f - rho, omir = 1.f - ir;
+            const TrialParams prm = d.prm[t];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -321,18 +320,16 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                     const float4 xs = *reinterpret_cast<const float4 *>(d.e_r2 + ix);
                     const float4 sy = *reinterpret_cast<const float4 *>(d.e_r3 + ix);
                     const float2 id = *reinterpret_cast<const float2 *>(d.e_f0 + ix);
-                    const float4 x = make_float4((v1.x + rho * y.x + sy.x + omr * v2.x + rho * xs.x) * id.x,
-                                                 (v1.y + rho * y.y + sy.y + omr * v2.y + rho * xs.y) * id.x,
-                                                 (v1.z + rho * y.z + sy.z + omr * v2.z + rho * xs.z) * id.y,
-                                                 (v1.w + rho * y.w + sy.w + omr * v2.w + rho * xs.w) * id.y);
+                    const float4 x = make_float4(admm_x(prm, v1.x, y.x, sy.x, v2.x, xs.x, id.x), admm_x(prm, v1.y, y.y, sy.y, v2.y, xs.y, id.x),
+                                                 admm_x(prm, v1.z, y.z, sy.z, v2.z, xs.z, id.y), admm_x(prm, v1.w, y.w, sy.w, v2.w, xs.w, id.y));
                     *reinterpret_cast<float4 *>(d.e_w1 + ix) = x;
-                    const float4 kk = make_float4(x.x + omir * v2.x, x.y + omir * v2.y, x.z + omir * v2.z, x.w + omir * v2.w);
+                    const float4 kk = make_float4(admm_k(prm, x.x, v2.x), admm_k(prm, x.y, v2.y), admm_k(prm, x.z, v2.z), admm_k(prm, x.w, v2.w));
                     *reinterpret_cast<float4 *>(d.e_w2 + ix) = kk;
                     tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(kk.x), fabsf(kk.y))), fmaxf(fabsf(kk.z), fabsf(kk.w)));
-                    v1 = make_float4(v1.x + rho * (y.x - x.x), v1.y + rho * (y.y - x.y), v1.z + rho * (y.z - x.z),
-                                     v1.w + rho * (y.w - x.w));
+                    v1 = make_float4(admm_v1(prm, v1.x, y.x, x.x), admm_v1(prm, v1.y, y.y, x.y), admm_v1(prm, v1.z, y.z, x.z),
+                                     admm_v1(prm, v1.w, y.w, x.w));
                     *reinterpret_cast<float4 *>(d.e_rw0 + ix) = v1;
-                    const float4 zn = make_float4(x.x - ir * v1.x, x.y - ir * v1.y, x.z - ir * v1.z, x.w - ir * v1.w);
+                    const float4 zn = make_float4(admm_z(prm, x.x, v1.x), admm_z(prm, x.y, v1.y), admm_z(prm, x.z, v1.z), admm_z(prm, x.w, v1.w));
                     if (d.e_w3) *reinterpret_cast<float4 *>(d.e_w3 + ix) = zn;
                     xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(x.x), fabsf(x.y))), fmaxf(fabsf(x.z), fabsf(x.w)));
                     v1max = fmaxf(fmaxf(v1max, fmaxf(fabsf(v1.x), fabsf(v1.y))), fmaxf(fabsf(v1.z), fabsf(v1.w)));
@@ -379,30 +376,28 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                             make_float2((float)(mst[nb][0][r] - (double)vr), (float)(mst[nb][1][r] - (double)vi));
                     if (EPI == EPI_UPDATE_C) {
                         // o = Xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (= the reference's :61 + :65, C == -V2)
-                        const float rho = d.prm[t].rho, omc = 1.f - d.prm[t].c_coef;
+                        const TrialParams prm = d.prm[t];
                         const float2 x = d.e_r0[ix];
                         float2 v2 = d.e_rw0[ix];
-                        v2.x = omc * (v2.x - rho * (x.x - o.x));
-                        v2.y = omc * (v2.y - rho * (x.y - o.y));
+                        v2.x = admm_v2(prm, v2.x, x.x, o.x);
+                        v2.y = admm_v2(prm, v2.y, x.y, o.y);
                         d.e_rw0[ix] = v2;
                         Cp[gi + (long long)gj * d.ldc] = o;
                     } else if (EPI == EPI_UPDATE_X) {
                         // o = Y
                         if (d.epi_store_c == 2) { Cp[gi + (long long)gj * d.ldc] = o; continue; }
-                        const float rho = d.prm[t].rho, ir = d.prm[t].irho;
+                        const TrialParams prm = d.prm[t];
                         float2 v1 = d.e_rw0[ix];
                         const float2 v2 = d.e_r0[ix], xs = d.e_r2[ix], sy = d.e_r3[ix];
                         const float id = d.e_f0[ix];
-                        const float omr = 1.f - rho, omir = 1.f - ir;
-                        const float2 x = make_float2((v1.x + rho * o.x + sy.x + omr * v2.x + rho * xs.x) * id,
-                                                     (v1.y + rho * o.y + sy.y + omr * v2.y + rho * xs.y) * id);
+                        const float2 x = make_float2(admm_x(prm, v1.x, o.x, sy.x, v2.x, xs.x, id), admm_x(prm, v1.y, o.y, sy.y, v2.y, xs.y, id));
                         d.e_w1[ix] = x;
-                        const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);
+                        const float2 kk = make_float2(admm_k(prm, x.x, v2.x), admm_k(prm, x.y, v2.y));
                         d.e_w2[ix] = kk;
                         tmax = fmaxf(tmax, fmaxf(fabsf(kk.x), fabsf(kk.y)));
-                        v1 = make_float2(v1.x + rho * (o.x - x.x), v1.y + rho * (o.y - x.y));
+                        v1 = make_float2(admm_v1(prm, v1.x, o.x, x.x), admm_v1(prm, v1.y, o.y, x.y));
                         d.e_rw0[ix] = v1;
-                        const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+                        const float2 zn = make_float2(admm_z(prm, x.x, v1.x), admm_z(prm, x.y, v1.y));
                         if (d.e_w3) d.e_w3[ix] = zn;
                         xmax = fmaxf(xmax, fmaxf(fabsf(x.x), fabsf(x.y)));
                         v1max = fmaxf(v1max, fmaxf(fabsf(v1.x), fabsf(v1.y)));

@@ -79,7 +79,8 @@ struct Tuning {
                             // +2 % channel-estimates/s, but WORSE parity (rms |dNMSE| 2.18e-7 against 1.73e-7, a +5e-8 bias): off
     int rv_comp = 0;        // JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
     int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
-    int pass_acc = 0;       // JSTSP_PASS_ACC: 0 products of K B^H straight into the pass's running sums, 1 / 2 per-tile block sums first (fused.hip)
+    int inv_two_float = 1;  // JSTSP_INV2: 0 the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (rounds 1-4)
+    int pass_acc = 1;       // JSTSP_PASS_ACC: 0 products of K B^H straight into the window pass's running sums (rounds 2-4), 1 / 2 per-tile block sums first (fused.hip)
     int host_compact = 1;   // JSTSP_HOST_COMPACT: 0 a JSTSP_HOST dictionary is uploaded whole (no host-side block-Toeplitz test / compaction)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
@@ -95,13 +96,90 @@ void load_tuning();
     jstsp::load_tuning()
 
 // Per-problem scalars of the ADMM solvers, resident on the device.
+// Round 5: every coefficient of the iteration map is held as TWO floats, hi + lo, all derived in float64 from the caller's
+// double rho.  Rounding each of rho, 1/rho, rho/(rho+1), 1 - rho ... to fp32 ON ITS OWN breaks the relations between them
+// (irho * rho = 1, 1 - c = 1/(1 + rho)) at the 3e-8 level - a CONSTANT perturbation of the iteration map, applied to every
+// entry in every iteration, that the dual variables integrate: measured with the float64 restatement (tools/precision_study.py,
+// mask 1048576) it alone costs 1.0e-7 rms of dNMSE at BASELINE configs[1] - more than all fp32 storage roundings together
+// (0.4e-7) - while a CONSISTENT fp32 rho costs 2e-9.  A product c * x is formed as fma(c_hi, x, c_lo * x): one random
+// rounding of the result, no systematic one.
 struct TrialParams {
-    float rho, irho;        // rho, 1/rho
+    float rho, irho;        // rho, 1/rho                                   (hi parts)
     float tauY_rho;         // tau_Y / rho   (svt threshold, proposed_algorithm.m:35)
     float tauS_rho;         // tau_S / rho   (soft threshold, :56)
     float c_coef;           // rho/(rho+1)   (:61)
-    float pad[3];
+    float rho_lo, irho_lo, c_lo;            // value - (float)value of the three above
+    float omc, omc_lo;      // 1 - rho/(rho+1) = 1/(1+rho)
+    float omr, omr_lo;      // 1 - rho
+    float omir, omir_lo;    // 1 - 1/rho
+    float pad[2];
 };
+#if defined(__cplusplus)
+inline TrialParams make_trial_params(double rho, double tau_Y, double tau_S)
+{
+    TrialParams p;
+    auto split = [](double v, float &h, float &l) { h = (float)v; l = (float)(v - (double)h); };
+    split(rho, p.rho, p.rho_lo);
+    split(1.0 / rho, p.irho, p.irho_lo);
+    split(rho / (rho + 1.0), p.c_coef, p.c_lo);
+    split(1.0 / (rho + 1.0), p.omc, p.omc_lo);
+    split(1.0 - rho, p.omr, p.omr_lo);
+    split(1.0 - 1.0 / rho, p.omir, p.omir_lo);
+    p.tauY_rho = (float)(tau_Y / rho);
+    p.tauS_rho = (float)(tau_S / rho);
+    p.pad[0] = p.pad[1] = 0.f;
+    return p;
+}
+#if defined(__HIPCC__)
+// c * x with c = ch + cl
+__device__ __forceinline__ float mul2(float ch, float cl, float x) { return fmaf(ch, x, cl * x); }
+// The element-wise updates of an ADMM iteration (C == -V2 eliminated: DESIGN.md section 3), one real component, the same
+// expressions in every kernel that applies them (fused.hip, cgemm.hip / hgemm.hip epilogues):
+//   V2 <- (1 - cc)(V2 - rho (X - Xs))                                   (:61 + :65)
+__device__ __forceinline__ float admm_v2(const TrialParams &p, float v2, float x, float xs)
+{
+    const float dx = x - xs;
+    const float t = fmaf(-p.rho, dx, v2) - p.rho_lo * dx;
+    return mul2(p.omc, p.omc_lo, t);
+}
+//   X <- (V1 + rho Y + subY + (1 - rho) V2 + rho Xs) / (Omega + 2 rho)    (:38-40 with V2 + rho C = (1 - rho) V2)
+__device__ __forceinline__ float admm_x(const TrialParams &p, float v1, float y, float sy, float v2, float xs, float invd)
+{
+    const float ys = y + xs;
+    return ((v1 + sy) + mul2(p.rho, p.rho_lo, ys) + mul2(p.omr, p.omr_lo, v2)) * invd;
+}
+//   the same with 1 / (Omega + 2 rho) as two floats (admm_invd)
+__device__ __forceinline__ float admm_x2(const TrialParams &p, float v1, float y, float sy, float v2, float xs, float rh, float rl)
+{
+    const float ys = y + xs;
+    const float s = (v1 + sy) + mul2(p.rho, p.rho_lo, ys) + mul2(p.omr, p.omr_lo, v2);
+    return fmaf(s, rh, s * rl);
+}
+//   1 / (Omega + 2 rho) = rh + rl: the sum as two floats (two-sum + the low part of rho), a 1-ulp reciprocal of its high part and
+//   one Newton correction carrying the low parts.  (An fp32 ARRAY of these values - iK1 of :14-20 - rounds 1/(2 rho) and
+//   1/(1 + 2 rho) once and applies the same two relative errors to every entry in every iteration: 0.5e-7 rms of dNMSE,
+//   tools/precision_study.py mask 4194304.)
+__device__ __forceinline__ void admm_invd(const TrialParams &p, float om, float &rh, float &rl)
+{
+    const float a = 2.f * p.rho, al = 2.f * p.rho_lo;
+    const float dh = om + a;
+    const float bb = dh - om;
+    const float dl = ((om - (dh - bb)) + (a - bb)) + al;
+    rh = __builtin_amdgcn_rcpf(dh);
+    rl = rh * (fmaf(-dh, rh, 1.f) - dl * rh);
+}
+//   k = X - V2/rho - C = X + (1 - 1/rho) V2                               (:43)
+__device__ __forceinline__ float admm_k(const TrialParams &p, float x, float v2) { return fmaf(p.omir, v2, x) + p.omir_lo * v2; }
+//   V1 <- V1 + rho (Y - X)                                                (:64)
+__device__ __forceinline__ float admm_v1(const TrialParams &p, float v1, float y, float x)
+{
+    const float d = y - x;
+    return fmaf(p.rho, d, v1) + p.rho_lo * d;
+}
+//   Z = X - V1/rho                                                        (:35)
+__device__ __forceinline__ float admm_z(const TrialParams &p, float x, float v1) { return fmaf(-p.irho, v1, x) - p.irho_lo * v1; }
+#endif
+#endif
 
 // Grow-only device arena: one hipMalloc'd slab, bump allocation, reset per call.
 struct Arena {
@@ -302,7 +380,7 @@ struct LanczosWarm {
     int *state = nullptr;           // [count] 0: no vector yet, 1: x valid
     unsigned *mismatch = nullptr;   // [1] periodic cold verifications that disagreed with the warm-started value
     int ne = 0;                     // lanczos_ne(n)
-    int call = 0;                   // call counter of the owning loop (staggers the verification over the matrices)
+    int call = 0;                   // call counter of the owning loop (every lanczos_verify-th call is verified)
 };
 int lanczos_ne(int n);            // padded order (64 or 128) of the warm-start vectors
 int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,

@@ -542,9 +542,12 @@ __global__ __launch_bounds__(256) void lmax_kernel(int n, const float2 *Gpart, l
 // factorisation of the full T_m (wave 0, serial), then the SAME recurrence is run once more (phase 2: same code, same bits)
 // accumulating x = sum_j y_j v_j - no n x n basis is ever stored.
 // A residual test cannot tell the largest eigenpair from another one, and a vector that tracked the largest eigenvalue
-// through an exact crossing would keep following the wrong branch.  So every `vperiod`-th call (staggered over the matrices
-// by their index) a converged phase 0 is followed by the cold phase 1 anyway: its value is the one returned, a relative
-// difference above 2e-5 counts as a mismatch (device counter, reported per solve) and replaces the vector.
+// through an exact crossing would keep following the wrong branch.  So every `vperiod`-th call a converged phase 0 is
+// followed by the cold phase 1 anyway: its value is the one returned, a relative difference above 2e-5 counts as a mismatch
+// (device counter, reported per solve) and replaces the vector.  ALL matrices of a launch are verified in the same call: a
+// launch lasts as long as its slowest workgroup, and a cold run is 12 x a warm one - staggering the verifications over the
+// matrices (the first version) put a few cold workgroups into EVERY launch and the kernel took as long as before
+// (profiles/r05a_kernel_stats.csv: 280 us average with 5 Lanczos steps per matrix instead of 64).
 // NW waves per matrix (4: lowest latency - the default of rounds 1-2; 1: no exchange, no barrier, no redundant reductions -
 // a quarter of the instructions per matrix at four times the latency)
 constexpr int LZ_KMAX = 12, LZ_KMIN = 3;
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void lanczos_lmax_kernel(int n, const
     const bool warm_on = wx != nullptr;
     int phase = 1;
     if (warm_on && wst[t] == 1) phase = 0;
-    const bool verify = warm_on && vperiod > 0 && ((call + t) % vperiod == 0);
+    const bool verify = warm_on && vperiod > 0 && (call % vperiod == vperiod - 1);      // (all matrices of a launch together: see above)
     bool have_w = false;
     float theta_w = 0.f;
     int m = 0, mcold = 0;
@@ -839,11 +842,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void lanczos_lmax_kernel(int n, const
 #pragma unroll
                     for (int r = 0; r < R; ++r) wx[(long long)t * NE + lane + 64 * r] = make_float2(x[r].x * inx, x[r].y * inx);
                 }
+                if (tid == 0 && wmis) atomicAdd(wmis + 3, (unsigned)m);               // [3] steps of converged warm attempts
                 if (!verify) {
                     if (tid == 0) lam_out[t] = theta_w;
                     return;
                 }
             }
+            if (tid == 0 && wmis) { atomicAdd(wmis + (fin == 2 ? 2 : 1), 1u); }      // [2] verifications, [1] warm attempts that failed
             phase = 1;                      // not converged (or due for verification): the cold run
             continue;
         }
@@ -1000,7 +1005,7 @@ static int launch_lanczos_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpar
     const bool warm = lw && lw->x && lw->ne == NE && tune().lanczos_warm != 0;
     hipLaunchKernelGGL((lanczos_lmax_kernel<NE, NW, OCC>), dim3(batch), dim3(64 * NW), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs,
                        lam_out, warm ? lw->x + (size_t)first * NE : nullptr, warm ? lw->state + first : nullptr,
-                       warm ? lw->mismatch : nullptr, warm ? lw->call + first : 0, tune().lanczos_verify, 1e-5f);
+                       warm ? lw->mismatch : nullptr, warm ? lw->call : 0, tune().lanczos_verify, 1e-5f);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

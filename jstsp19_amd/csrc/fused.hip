@@ -413,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
     // of the sums).  An overflow raises d.ovf.
     const int ek = fscale_exp(d.kmax_prev[t]) - d.kback;
     const float sxs = ldexpf(1.f, -(eb + ew)), sk = ldexpf(1.f, ek), sp = ldexpf(1.f, -(eb + ek));
-    const float rho = prm.rho, ir = prm.irho, omc = 1.f - prm.c_coef, omr = 1.f - rho, omir = 1.f - ir;
+    // (the coefficients of the element-wise updates: admm_* of common.h, two floats each)
 
     // refill of the tile: wave w owns the rows g of its phase-B range, block gb of them = 256 chunks, 4 per lane (plane p = c)
     // compact image: chunk (block gb, plane c) of lane l = E[(c G8t + g8'(gb) + g8i) ecols + ehalo + m - ld(gb)], m = 4 mq + r:
@@ -600,14 +600,16 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
             const uint32_t ix = ebase + 512u * (uint32_t)(m0 + s);
             const float2 xs = make_float2(xr[s] * sxs, xi[s] * sxs);
             // V2 <- (1 - cc)(V2 - rho (X - Xs))                       (:61 + :65, C == -V2)
-            const float2 v2 = make_float2(omc * (ev2[s].x - rho * (ex[s].x - xs.x)), omc * (ev2[s].y - rho * (ex[s].y - xs.y)));
+            const float2 v2 = make_float2(admm_v2(prm, ev2[s].x, ex[s].x, xs.x), admm_v2(prm, ev2[s].y, ex[s].y, xs.y));
             // X <- iK1 (V1 + rho Y + subY + V2 + rho C + rho Xs)      (:38-40)
-            const float2 x = make_float2((ev1[s].x + rho * ey[s].x + esy[s].x + omr * v2.x + rho * xs.x) * eid[s],
-                                         (ev1[s].y + rho * ey[s].y + esy[s].y + omr * v2.y + rho * xs.y) * eid[s]);
-            const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);                  // (:43)
-            const float2 v1 = make_float2(ev1[s].x + rho * (ey[s].x - x.x), ev1[s].y + rho * (ey[s].y - x.y));   // (:64)
+            float rh = eid[s], rl = 0.f;            // 1 / (Omega + 2 rho): read (one float), or formed here from Omega (two)
+            if (d.inv_is_omega) admm_invd(prm, eid[s], rh, rl);
+            const float2 x = make_float2(admm_x2(prm, ev1[s].x, ey[s].x, esy[s].x, v2.x, xs.x, rh, rl),
+                                         admm_x2(prm, ev1[s].y, ey[s].y, esy[s].y, v2.y, xs.y, rh, rl));
+            const float2 kk = make_float2(admm_k(prm, x.x, v2.x), admm_k(prm, x.y, v2.y));        // (:43)
+            const float2 v1 = make_float2(admm_v1(prm, ev1[s].x, ey[s].x, x.x), admm_v1(prm, ev1[s].y, ey[s].y, x.y));   // (:64)
             if (!(DBG & 2)) { stg_nt2(V2t, ix, v2); stg_nt2(Xt, ix, x); stg_nt2(V1t, ix, v1); }
-            const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+            const float2 zn = make_float2(admm_z(prm, x.x, v1.x), admm_z(prm, x.y, v1.y));
             if (YIN) stg_nt2(Zot, ix, zn);
             if (Yot) stg(Yot, ix, ey[s]);
             v2mx = fmaxf(v2mx, fmaxf(fabsf(v2.x), fabsf(v2.y)));
@@ -670,13 +672,18 @@ __global__ __launch_bounds__(512, 1) void fused_pass_kernel(FusedDesc d)
                     u32x4 k0 = *reinterpret_cast<const u32x4 *>(kp), k1 = *reinterpret_cast<const u32x4 *>(kp + 1024);
                     const u32x4 k2 = *reinterpret_cast<const u32x4 *>(kp + 2048), k3 = *reinterpret_cast<const u32x4 *>(kp + 3072);
                     // re += Br kr + Bi ki ; im += Br ki - Bi kr
-                    pr[gb][n2] = mma(bf[0], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k2, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[0], k1, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k3, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[1], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[1], k2, pi[gb][n2]);
+                    // (round 5: the six products of a tile's block are summed in fresh accumulators and added to the running sums
+                    //  ONCE - see fused_pass64_kernel, ACC = 1)
+                    {
+                    f32x4 tr = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f}), ti = mma(bf[0], k2, f32x4{0.f, 0.f, 0.f, 0.f});
+                    tr = mma(bf[0], k1, tr); ti = mma(bf[0], k3, ti);
+                    tr = mma(bf[1], k0, tr); ti = mma(bf[1], k2, ti);
                     k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
-                    pr[gb][n2] = mma(bf[2], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k0, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[2], k3, pr[gb][n2]); pi[gb][n2] = mma(bf[2], k1, pi[gb][n2]);
-                    pr[gb][n2] = mma(bf[3], k2, pr[gb][n2]); pi[gb][n2] = mma(bf[3], k0, pi[gb][n2]);
+                    tr = mma(bf[2], k2, tr); ti = mma(bf[2], k0, ti);
+                    tr = mma(bf[2], k3, tr); ti = mma(bf[2], k1, ti);
+                    tr = mma(bf[3], k2, tr); ti = mma(bf[3], k0, ti);
+                    pr[gb][n2] += tr; pi[gb][n2] += ti;
+                    }
                     __builtin_amdgcn_sched_barrier(0);      // (else the fragment reads of all four n-blocks are hoisted: spills)
                 }
                 if (!(DBG & 8)) {
@@ -780,7 +787,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
     const int eb = fscale_exp(d.bmax[(long long)t * d.sbmax]), ew = fscale_exp(d.wmax[t]);
     const int ek = fscale_exp(d.kmax_prev[t]) - d.kback;       // (see fused_pass_kernel)
     const float sxs = ldexpf(1.f, -(eb + ew)), sk = ldexpf(1.f, ek), sp = ldexpf(1.f, -(eb + ek));
-    const float rho = prm.rho, ir = prm.irho, omc = 1.f - prm.c_coef, omr = 1.f - rho, omir = 1.f - ir;
+    // (the coefficients of the element-wise updates: admm_* of common.h, two floats each)
 
     f32x4 pr[GB][4], pi[GB][4];
 #pragma unroll
@@ -863,14 +870,14 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                 const f32x4 xv_ = __builtin_bit_cast(f32x4, rf[(((pc_) - 1) >> 2) & 1][((pc_) - 1) & 3]);                    \
                 const f32x4 vv_ = __builtin_bit_cast(f32x4, src_);                                                           \
                 _Float16 h0_, l0_, h1_, l1_;                                                                                 \
-                fsplit((xv_[0] - ir * vv_[0]) * sz, h0_, l0_); fsplit((xv_[2] - ir * vv_[2]) * sz, h1_, l1_);                \
+                fsplit(admm_z(prm, xv_[0], vv_[0]) * sz, h0_, l0_); fsplit(admm_z(prm, xv_[2], vv_[2]) * sz, h1_, l1_);      \
                 typedef _Float16 half2_ __attribute__((ext_vector_type(2)));                                                 \
                 int lz_ = l;                                                                                                 \
                 asm volatile("" : "+v"(lz_));                                                                                \
                 unsigned char *z_ = lds + ZF0 + ((kh * 2 + (nb >> 1)) * 16 + 2 * (nb & 1) + ((lz_ & 7) >> 2)) * 256 +       \
                                     (lz_ >> 3) * 16 + 4 * (lz_ & 3) + F64_J(pc_) * 128;                                      \
                 *reinterpret_cast<half2_ *>(z_) = half2_{h0_, h1_}; *reinterpret_cast<half2_ *>(z_ + 1024) = half2_{l0_, l1_}; \
-                fsplit((xv_[1] - ir * vv_[1]) * sz, h0_, l0_); fsplit((xv_[3] - ir * vv_[3]) * sz, h1_, l1_);                \
+                fsplit(admm_z(prm, xv_[1], vv_[1]) * sz, h0_, l0_); fsplit(admm_z(prm, xv_[3], vv_[3]) * sz, h1_, l1_);      \
                 *reinterpret_cast<half2_ *>(z_ + 2048) = half2_{h0_, h1_}; *reinterpret_cast<half2_ *>(z_ + 3072) = half2_{l0_, l1_}; \
             }                                                                                                                \
         }                                                                                                                    \
@@ -1022,14 +1029,16 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                 xs.x += (d0.x + d1.x) + (d2.x + d3.x); xs.y += (d0.y + d1.y) + (d2.y + d3.y);
             }
             // V2 <- (1 - cc)(V2 - rho (X - Xs))                       (:61 + :65, C == -V2)
-            const float2 v2 = make_float2(omc * (ev2[s].x - rho * (ex[s].x - xs.x)), omc * (ev2[s].y - rho * (ex[s].y - xs.y)));
+            const float2 v2 = make_float2(admm_v2(prm, ev2[s].x, ex[s].x, xs.x), admm_v2(prm, ev2[s].y, ex[s].y, xs.y));
             // X <- iK1 (V1 + rho Y + subY + V2 + rho C + rho Xs)      (:38-40)
-            const float2 x = make_float2((ev1[s].x + rho * ey[s].x + esy[s].x + omr * v2.x + rho * xs.x) * eid[s],
-                                         (ev1[s].y + rho * ey[s].y + esy[s].y + omr * v2.y + rho * xs.y) * eid[s]);
-            const float2 kk = make_float2(x.x + omir * v2.x, x.y + omir * v2.y);                  // (:43)
-            const float2 v1 = make_float2(ev1[s].x + rho * (ey[s].x - x.x), ev1[s].y + rho * (ey[s].y - x.y));   // (:64)
+            float rh = eid[s], rl = 0.f;            // 1 / (Omega + 2 rho): read (one float), or formed here from Omega (two)
+            if (d.inv_is_omega) admm_invd(prm, eid[s], rh, rl);
+            const float2 x = make_float2(admm_x2(prm, ev1[s].x, ey[s].x, esy[s].x, v2.x, xs.x, rh, rl),
+                                         admm_x2(prm, ev1[s].y, ey[s].y, esy[s].y, v2.y, xs.y, rh, rl));
+            const float2 kk = make_float2(admm_k(prm, x.x, v2.x), admm_k(prm, x.y, v2.y));        // (:43)
+            const float2 v1 = make_float2(admm_v1(prm, ev1[s].x, ey[s].x, x.x), admm_v1(prm, ev1[s].y, ey[s].y, x.y));   // (:64)
             if (!(DBG & 2)) { stg_nt2(V2t, ix, v2); stg_nt2(Xt, ix, x); stg_nt2(V1t, ix, v1); }
-            const float2 zn = make_float2(x.x - ir * v1.x, x.y - ir * v1.y);
+            const float2 zn = make_float2(admm_z(prm, x.x, v1.x), admm_z(prm, x.y, v1.y));
             if (Zot) stg_nt2(Zot, ix, zn);
             if (Yot) stg(Yot, ix, ey[s]);
             if (lead) stg(Kft, ix, kk);
@@ -1105,6 +1114,11 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                         tr = mma(bf[2], k2, tr); ti = mma(bf[2], k0, ti);
                         tr = mma(bf[2], k3, tr); ti = mma(bf[2], k1, ti);
                         tr = mma(bf[3], k2, tr); ti = mma(bf[3], k0, ti);
+                        {       // (this block's prefetch traffic is issued while the last products drain; then the sums)
+                            const int grp = 4 * gb + n2;
+                            if (grp >= 6 && grp - 6 < 12) F64_STORE(grp - 6, (i + 1) & 1, rf[((grp - 6) >> 2) & 1][(grp - 6) & 3])
+                            if (grp < 12) F64_LOAD(grp, tn, rf[(grp >> 2) & 1][grp & 3])
+                        }
                         pr[gb][n2] += tr; pi[gb][n2] += ti;
                     } else {
                         f32x4 tt = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -1117,7 +1131,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                         tu = mma(bf[2], k0, tu); tu = mma(bf[2], k1, tu); tu = mma(bf[3], k0, tu);
                         pi[gb][n2] += tu;
                     }
-                    {
+                    if constexpr (ACC != 1) {
                         const int grp = 4 * gb + n2;
                         if (grp >= 6 && grp - 6 < 12) F64_STORE(grp - 6, (i + 1) & 1, rf[((grp - 6) >> 2) & 1][(grp - 6) & 3])
                         if (grp < 12) F64_LOAD(grp, tn, rf[(grp >> 2) & 1][grp & 3])

@@ -308,11 +308,11 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
             const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
             if (EPI == EPI_UPDATE_C) {
                 // o = Xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
-                const float rho = d.prm[t].rho, omc = 1.f - d.prm[t].c_coef;
+                const TrialParams prm = d.prm[t];
                 const float2 x = d.e_r0[ix];
                 float2 v2 = d.e_rw0[ix];
-                v2.x = omc * (v2.x - rho * (x.x - o.x));
-                v2.y = omc * (v2.y - rho * (x.y - o.y));
+                v2.x = admm_v2(prm, v2.x, x.x, o.x);
+                v2.y = admm_v2(prm, v2.y, x.y, o.y);
                 d.e_rw0[ix] = v2;
                 vmax = fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y)));
             }
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
     float vmax = 0.f;
     const bool vec4 = ((d.m & 1) == 0) && ((d.ldc & 1) == 0) && ((d.sCt & 1) == 0) && (((uintptr_t)d.C & 15) == 0) &&
                       (EPI != EPI_UPDATE_C || ((((uintptr_t)d.e_r0 | (uintptr_t)d.e_rw0) & 15) == 0));
-    const float rho = (EPI == EPI_UPDATE_C) ? d.prm[t].rho : 0.f, omc = (EPI == EPI_UPDATE_C) ? 1.f - d.prm[t].c_coef : 0.f;
+    const TrialParams prm = (EPI == EPI_UPDATE_C) ? d.prm[t] : TrialParams();
     auto swap1 = [](float x) {
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
     };
@@ -562,10 +562,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
                 for (int rp = 0; rp < 8; ++rp) {
                     // Xs in xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
                     float4 v = v2[rp];
-                    v.x = omc * (v.x - rho * (x[rp].x - xs[rp].x));
-                    v.y = omc * (v.y - rho * (x[rp].y - xs[rp].y));
-                    v.z = omc * (v.z - rho * (x[rp].z - xs[rp].z));
-                    v.w = omc * (v.w - rho * (x[rp].w - xs[rp].w));
+                    v.x = admm_v2(prm, v.x, x[rp].x, xs[rp].x);
+                    v.y = admm_v2(prm, v.y, x[rp].y, xs[rp].y);
+                    v.z = admm_v2(prm, v.z, x[rp].z, xs[rp].z);
+                    v.w = admm_v2(prm, v.w, x[rp].w, xs[rp].w);
                     if (ok[rp]) {
                         *reinterpret_cast<float4 *>(d.e_rw0 + ixs[rp]) = v;
                         vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
@@ -591,8 +591,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
                 if (EPI == EPI_UPDATE_C) {
                     const float2 x = d.e_r0[ix];
                     float2 v2 = d.e_rw0[ix];
-                    v2.x = omc * (v2.x - rho * (x.x - o.x));
-                    v2.y = omc * (v2.y - rho * (x.y - o.y));
+                    v2.x = admm_v2(prm, v2.x, x.x, o.x);
+                    v2.y = admm_v2(prm, v2.y, x.y, o.y);
                     d.e_rw0[ix] = v2;
                     vmax = fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y)));
                 }
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
     const float2 *abase = Z + (long long)t * sZt;
     const float2 *pa = abase + (arow ? ai : 0) + (long long)(kbeg + 8 * akg) * rows;
     const long long off2 = Z2 ? (Z2 - Z) : 0;           // same layout: element i of Z2 sits off2 elements after element i of Z
-    const float ir2 = Z2 ? zprm[t].irho : 0.f;
+    const float ir2 = Z2 ? zprm[t].irho : 0.f, ir2l = Z2 ? zprm[t].irho_lo : 0.f;       // (1/rho as two floats: common.h)
     const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
     const int kfull = (kend - kbeg) / HBK;
 
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
 #pragma unroll
                 for (int v = 0; v < 8; ++v) {
                     const float2 y = pa[(long long)(s * HBK + v) * rows + off2];
-                    R.a[v].x -= ir2 * y.x; R.a[v].y -= ir2 * y.y;
+                    R.a[v].x = fmaf(-ir2, y.x, R.a[v].x) - ir2l * y.x; R.a[v].y = fmaf(-ir2, y.y, R.a[v].y) - ir2l * y.y;
                 }
             }
         } else {
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
                 const bool ok = kbase + v < kend;
                 const float2 *p = ok ? pa + (long long)(s * HBK + v) * rows : abase;
                 float2 x = *p;
-                if (Z2) { const float2 y = p[off2]; x.x -= ir2 * y.x; x.y -= ir2 * y.y; }
+                if (Z2) { const float2 y = p[off2]; x.x = fmaf(-ir2, y.x, x.x) - ir2l * y.x; x.y = fmaf(-ir2, y.y, x.y) - ir2l * y.y; }
                 R.a[v] = ok ? x : make_float2(0.f, 0.f);
             }
         }
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
     const int ai = tid & 63, akg = tid >> 6;
     const bool arow = ai < rows;
     const float sx = arow ? ldexpf(1.f, ex) : 0.f, sv = arow ? ldexpf(1.f, ev) : 0.f, sz = arow ? ldexpf(1.f, ez) : 0.f;
-    const float ir = prm[t].irho;
+    const float ir = prm[t].irho, irl = prm[t].irho_lo;
     const long long base = (long long)t * sZt + (arow ? ai : 0);
     const int a_slot = ((((ai >> 5) * 2 + (akg >> 1)) * 4) * 64) + (akg & 1) * 32 + (ai & 31);
 
@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
     auto store = [&](const Stg &R) {
         float2 z[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) z[u] = make_float2(R.x[u].x - ir * R.v[u].x, R.x[u].y - ir * R.v[u].y);   // (:35)
+        for (int u = 0; u < 8; ++u)                                                                            // (:35)
+            z[u] = make_float2(fmaf(-ir, R.v[u].x, R.x[u].x) - irl * R.v[u].x, fmaf(-ir, R.v[u].y, R.x[u].y) - irl * R.v[u].y);
         put(smem, R.x, sx);
         put(smem + 1024, R.v, sv);
         put(smem + 2048, z, sz);

@@ -238,14 +238,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // ---- per-problem scalars ------------------------------------------------------------------
     {
         std::vector<TrialParams> hp(batch);
-        for (int t = 0; t < batch; ++t) {
-            const double r = rho[t];
-            hp[t].rho = (float)r;
-            hp[t].irho = (float)(1.0 / r);
-            hp[t].tauY_rho = (float)(tau_Y[t] / r);
-            hp[t].tauS_rho = (float)(tau_S[t] / r);
-            hp[t].c_coef = (float)(r / (r + 1.0));
-        }
+        for (int t = 0; t < batch; ++t) hp[t] = make_trial_params(rho[t], tau_Y[t], tau_S[t]);
         JSTSP_TRY(upload(ctx, w.prm, hp.data(), batch * sizeof(TrialParams)));
     }
 
@@ -261,6 +254,8 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     JSTSP_HIP(hipMemsetAsync(w.S, 0, batch * g * sizeof(float2), st));
     JSTSP_HIP(hipMemsetAsync(w.ce, 0, (size_t)batch * 3 * std::max(Imax, 1) * sizeof(double), st));   // ce(:,3) stays 0 for 'std' (:6)
     JSTSP_TRY(launch_inv_d(ctx, (long long)nm, batch, Omega, 2.f, w.prm, w.invD));
+    // (the fused pass forms 1 / (Omega + 2 rho) itself, as two floats, when it can read Omega with its 16-byte loads)
+    const bool omega_direct = ((uintptr_t)Omega % 16 == 0) && (nm % 4 == 0) && tn.inv_two_float != 0;
     if (angles) JSTSP_TRY(launch_rank_from_index(ctx, (int)g, batch, indx_S, w.rank));
 
     const Mat Am{A, strideA, N}, Bm{B, strideB, G2};
@@ -686,14 +681,14 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_TRY(fused_pack_as(ctx, fw, w.W, sng, G2, M, batch, w.wmax));
             JSTSP_HIP(hipStreamWaitEvent(sm, ev_svt, 0));          // Y of the next iteration (side stream s1)
             FusedDesc fd{fw.Bf, strideB ? fw.sBf : 0, w.Bc.bmax, strideB ? 1 : 0, fw.ASp, fw.sAS, w.wmax, w.kmax,
-                         w.X, w.V1, w.V2, subY, w.Y, w.invD, snm, w.prm, fw.Ppart,
+                         w.X, w.V1, w.V2, subY, w.Y, omega_direct ? Omega : w.invD, snm, w.prm, fw.Ppart,
                          nx, nx + batch, nx + 2 * (size_t)batch, nx + 4 * (size_t)batch, w.nmax + 2 * (size_t)batch, fw.ovf,
                          M, G2, batch, fparts,
                          fusedy ? fw.Wqp : nullptr, Zbuf[(it + 1) & 1], w.zmax,
                          (fw.v2 && zfly) ? nullptr : Zbuf[it & 1],      // (window kernel: Z comes from the staged X, V1)
                          (fusedy && it + 2 == Imax) ? w.Y : nullptr, fused_kback,
                          fw.Ec, strideB ? fw.sEc : 0, fw.gt ? 31 - __builtin_clz((unsigned)fw.gt) : 0, fw.ecols, fw.ehalo,
-                         fw.v2, fw.XsD, fw.Kf};
+                         fw.v2, fw.XsD, fw.Kf, omega_direct ? 1 : 0};
             JSTSP_TRY(launch_fused_pass(ctx, fd));
             passed = true;
         } else

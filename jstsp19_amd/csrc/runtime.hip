@@ -43,6 +43,7 @@ void load_tuning()
     t.host_pipeline = env_int("JSTSP_HOST_PIPELINE", t.host_pipeline);
     t.host_compact = env_int("JSTSP_HOST_COMPACT", t.host_compact);
     t.pass_acc = env_int("JSTSP_PASS_ACC", t.pass_acc);
+    t.inv_two_float = env_int("JSTSP_INV2", t.inv_two_float);
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     t.rv_comp = env_int("JSTSP_RV_COMP", t.rv_comp);
@@ -268,7 +269,7 @@ int lanczos_warm_reset(jstsp_ctx *ctx, const GramWS &w)
     w.lz.mismatch = nullptr;
     if (!w.lz.x) return 0;
     if (!ctx->lz_mismatch) JSTSP_HIP(hipMalloc((void **)&ctx->lz_mismatch, 256));
-    JSTSP_HIP(hipMemsetAsync(ctx->lz_mismatch, 0, sizeof(unsigned), ctx->stream));
+    JSTSP_HIP(hipMemsetAsync(ctx->lz_mismatch, 0, 8 * sizeof(unsigned), ctx->stream));
     JSTSP_HIP(hipMemsetAsync(w.lz.state, 0, (size_t)w.batch * sizeof(int), ctx->stream));
     w.lz.mismatch = ctx->lz_mismatch;
     return 0;
@@ -583,6 +584,18 @@ int jstsp_last_conditioning(jstsp_ctx *ctx, double *rcond_min, double *ns_residu
     JSTSP_ENTER(ctx);
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     return diag_read(ctx, rcond_min, ns_residual_max);
+}
+
+// (diagnostics, not in the header: [0] verification mismatches, [1] warm attempts that did not converge, [2] verifications,
+//  [3] Lanczos steps of the converged warm attempts - of the last solve that reset the record)
+extern "C" int jstsp_debug_lanczos_counters(jstsp_ctx *ctx, unsigned *out4)
+{
+    JSTSP_REQUIRE(ctx && out4, JSTSP_E_NULL, "ctx/out is NULL");
+    JSTSP_ENTER(ctx);
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->lz_mismatch) JSTSP_HIP(hipMemcpy(out4, ctx->lz_mismatch, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int jstsp_last_lanczos_mismatches(jstsp_ctx *ctx, int *count)

@@ -199,6 +199,8 @@ struct FusedDesc {
     int kback;                                    // headroom of the predicted k scale in bits (KBACK; JSTSP_FUSED_KBACK: tests)
     const uint4 *Ec; long long sEc; int gsh, ecols, ehalo;   // compact image of a block-Toeplitz dictionary (gsh = log2 Gt; 0: none)
     int v2; const float2 *XsD; float2 *Kf;                   // fused_pass64_kernel (see FusedWS)
+    int inv_is_omega;                             // invD points at the caller's Omega (16-byte aligned): 1 / (Omega + 2 rho) is formed in the
+                                                  // pass as two floats (common.h: admm_invd) instead of read as one rounded float
 };
 bool fused_shape_ok(int N, int M, int G2, int parts);
 size_t fused_bytes(int M, int G2, int nB, int batch, int parts);

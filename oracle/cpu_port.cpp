@@ -320,7 +320,21 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
     std::vector<double> inv_d(nm), omega_s(indx_S ? g : 0, 0.0), lam;
     for (size_t i = 0; i < nm; ++i) inv_d[i] = 1.0 / (Omega[i] + 2.0 * rho);     // iK1                        (:14-20)
     std::fill(ce, ce + (size_t)3 * Imax, 0.0);
-    const double ir = 1.0 / rho, cc = rho / (rho + 1.0), tY = tau_Y / rho, tS = tau_S / rho;
+    double ir = 1.0 / rho, cc = rho / (rho + 1.0), tY = tau_Y / rho, tS = tau_S / rho;
+    if (rm & 1048576u) {        // (precision study) the per-problem scalars as the HIP path holds them: each one rounded to fp32 on its own
+        ir = (double)(float)ir; cc = (double)(float)cc; tY = (double)(float)tY; tS = (double)(float)tS;
+        rho = (double)(float)rho;
+    }
+    if (rm & 4194304u)          // (precision study) 1 / (Omega + 2 rho) stored as fp32
+        for (size_t i = 0; i < nm; ++i) inv_d[i] = (double)(float)inv_d[i];
+    if (rm & 8388608u) { tS = (double)(float)tS; tY = (double)(float)tY; }       // the two thresholds alone
+    if (rm & 16777216u) { ir = (double)(float)ir; }                               // 1 / rho alone
+    if (rm & 33554432u) { cc = (double)(float)cc; }                               // rho / (rho + 1) alone
+    if (rm & 2097152u) {        // (precision study) ... or all derived consistently from the fp32 value of rho, in float64
+        rho = (double)(float)rho;
+        ir = 1.0 / rho; cc = rho / (rho + 1.0); tY = tau_Y / rho; tS = tau_S / rho;
+        for (size_t i = 0; i < nm; ++i) inv_d[i] = 1.0 / (Omega[i] + 2.0 * rho);
+    }
     for (int it = 1; it <= Imax; ++it) {
         if (indx_S) {                                             // angles :36 (cumulative support)
             const long long cnt = std::min<long long>(10 + 5ll * it, (long long)g);
