@@ -117,8 +117,6 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *   JSTSP_LANCZOS_VERIFY=n  a warm-started lambda_max is checked against the cold run every n-th call (default 32;
  *                         0 never, 1 always - then every returned value is the cold one; jstsp_last_lanczos_mismatches)
  *   JSTSP_EIG128=0        general Jacobi kernel (basis in HBM) for Gram orders 65..128
- *   JSTSP_OMP_PERSIST=0   jstsp_omp with ONE problem: two launches per OMP iteration instead of all iterations in one
- *                         cooperative launch
  *   JSTSP_OMP_GRAM=0      jstsp_omp_kron: measurement-space OMP instead of the coefficient-domain kernel
  *   JSTSP_BJ_MASK=0       block Jacobi (orders above 128) without streams restricted to a subset of the compute units
  *   JSTSP_BJ_TRACE=1      print the block Jacobi's convergence (orders above 128) per sweep to stderr

@@ -72,7 +72,6 @@ struct Tuning {
     int lanczos_warm = 1;   // JSTSP_LANCZOS_WARM: 0 every lambda_max of an ADMM loop by the cold n-step Lanczos run (rounds 2-4)
     int lanczos_verify = 32; // JSTSP_LANCZOS_VERIFY: every this many calls a warm-started lambda_max is checked against the cold run (0: never, 1: always)
     int eig128 = 1;         // JSTSP_EIG128: 0 general Jacobi kernel for Gram orders 65..128
-    int omp_persist = 1;    // JSTSP_OMP_PERSIST: 0 a one-problem OMP call as two launches per iteration instead of one cooperative launch
     int omp_gram = 1;       // JSTSP_OMP_GRAM: 0 measurement-space OMP on a Kronecker dictionary
     int grad_head = 0;      // JSTSP_GRAD_HEAD: bit 0 - Res / P1 of the gradient step, bit 1 - the first factor of a recomputed R v, on the
                             // f16 pipe in one launch (hsmall.hip) instead of fp32-MFMA products; measured: more accurate products,

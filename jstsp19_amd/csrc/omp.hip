@@ -28,7 +28,7 @@ struct OmpState {
     int *sel;          // [batch][m]         0-based selected atom per iteration
 };
 
-__device__ __forceinline__ double2 block_sum2(double2 v, double *sh)
+__device__ __forceinline__ double2 block_sum2_4w(double2 v, double *sh)
 {
     for (int o = 32; o > 0; o >>= 1) { v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); }
     __syncthreads();
@@ -37,10 +37,13 @@ __device__ __forceinline__ double2 block_sum2(double2 v, double *sh)
     return make_double2(sh[0] + sh[2] + sh[4] + sh[6], sh[1] + sh[3] + sh[5] + sh[7]);
 }
 
+// MANY problems (more than 64 per call): one workgroup of four waves per problem, modified Gram-Schmidt with block-wide
+// reductions - at a batch that fills the chip what counts is instructions per problem, not the latency of one (batch 1024 at
+// BASELINE configs[0]: 14.8 ms per call against 21.4 for the wave-parallel form below, which is 1.9x faster for ONE problem).
 // One workgroup per problem: argmax |corr|, then append the atom.
 // Dense dictionary: atom = A[:, idx] (A + t*strideA, meas x size_d).
 // Kronecker (Bf != nullptr): atom[i + N*j] = Af[i, g] * Bf[h, j], idx = g + Gr*h.
-__global__ __launch_bounds__(256) void omp_step_kernel(int meas, int size_d, int m, int it, const float2 *corr,
+__global__ __launch_bounds__(256) void omp_step_mgs_kernel(int meas, int size_d, int m, int it, const float2 *corr,
                                                        const float2 *A, long long strideA, const float2 *Bf,
                                                        long long strideB, int N, int Gr, int G2, OmpState s)
 {
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void omp_step_kernel(int meas, int size_d, int
             nrm0 += (double)v.x * v.x + (double)v.y * v.y;
         }
     }
-    nrm0 = block_sum2(make_double2(nrm0, 0), sh).x;
+    nrm0 = block_sum2_4w(make_double2(nrm0, 0), sh).x;
     for (int j = tid; j < m; j += 256) Rc[j] = make_float2(0.f, 0.f);
     __syncthreads();
     // ---- Gram-Schmidt against the basis, twice (re-orthogonalisation) ------------------------------
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256) void omp_step_kernel(int meas, int size_d, int
                 d.x += (double)qq.x * ww.x + (double)qq.y * ww.y;       // conj(q) * w
                 d.y += (double)qq.x * ww.y - (double)qq.y * ww.x;
             }
-            d = block_sum2(d, sh);
+            d = block_sum2_4w(d, sh);
             const float hx = (float)d.x, hy = (float)d.y;
             for (int e = tid; e < meas; e += 256) {
                 const float2 qq = q[e];
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void omp_step_kernel(int meas, int size_d, int
     }
     double n2 = 0;
     for (int e = tid; e < meas; e += 256) { const float2 ww = w[e]; n2 += (double)ww.x * ww.x + (double)ww.y * ww.y; }
-    n2 = block_sum2(make_double2(n2, 0), sh).x;
+    n2 = block_sum2_4w(make_double2(n2, 0), sh).x;
     if (!(n2 > 1e-12 * nrm0)) return;              // numerically dependent on the chosen atoms: adds nothing
     const float inv = (float)(1.0 / sqrt(n2));
     // ---- q_u = w/|w|, z_u = q_u^H v = q_u^H r (r is orthogonal to the old basis), r -= z_u q_u --------
@@ -148,9 +151,166 @@ __global__ __launch_bounds__(256) void omp_step_kernel(int meas, int size_d, int
         d.x += (double)qv.x * rr.x + (double)qv.y * rr.y;
         d.y += (double)qv.x * rr.y - (double)qv.y * rr.x;
     }
-    d = block_sum2(d, sh);
+    d = block_sum2_4w(d, sh);
     const float zx = (float)d.x, zy = (float)d.y;
     for (int e = tid; e < meas; e += 256) {
+        const float2 qv = qu[e];
+        float2 rr = r[e];
+        rr.x -= zx * qv.x - zy * qv.y;
+        rr.y -= zx * qv.y + zy * qv.x;
+        r[e] = rr;
+    }
+    if (tid == 0) {
+        Rc[u] = make_float2((float)sqrt(n2), 0.f);
+        s.z[(long long)t * m + u] = make_float2(zx, zy);
+        s.uniq[(long long)t * m + u] = idx;
+        s.mult[(long long)t * m + u] = 1;
+        s.nu[t] = u + 1;
+    }
+}
+
+__device__ __forceinline__ double2 wave_sum2(double2 v)
+{
+    for (int o = 32; o > 0; o >>= 1) { v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); }
+    return v;
+}
+template <int NT> __device__ __forceinline__ double2 block_sum2(double2 v, double *sh)
+{
+    constexpr int NW = NT / 64;
+    v = wave_sum2(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[2 * (threadIdx.x >> 6)] = v.x; sh[2 * (threadIdx.x >> 6) + 1] = v.y; }
+    __syncthreads();
+    double2 r = make_double2(0, 0);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { r.x += sh[2 * k]; r.y += sh[2 * k + 1]; }
+    return r;
+}
+
+// One workgroup of NT threads per problem: argmax |corr|, then append the atom.
+// Dense dictionary: atom = A[:, idx] (A + t*strideA, meas x size_d).
+// Kronecker (Bf != nullptr): atom[i + N*j] = Af[i, g] * Bf[h, j], idx = g + Gr*h.
+// Round 5: the orthogonalisation is classical Gram-Schmidt done twice (CGS2) with the u inner products of a pass spread over
+// the NT / 64 waves (wave-local float64 reductions, no barrier per inner product) and ONE update w -= Q d per pass - rounds
+// 1-4 ran modified Gram-Schmidt, 2 u block-wide reductions with two barriers each, which was 45 of the 58 us an OMP iteration
+// took at BASELINE configs[0] (a kernel boundary is 1.5 us: the launches were never the cost).  NT = 1024 for few problems.
+template <int NT>
+__global__ __launch_bounds__(NT) void omp_step_kernel(int meas, int size_d, int m, int it, const float2 *corr,
+                                                      const float2 *A, long long strideA, const float2 *Bf,
+                                                      long long strideB, int N, int Gr, int G2, OmpState s)
+{
+    constexpr int NW = NT / 64;
+    __shared__ double sh[2 * NW];
+    __shared__ float shv[NW];
+    __shared__ int shi[NW];
+    __shared__ int s_idx, s_dup;
+    __shared__ float2 dsh[1024];                    // inner products of a pass (m <= 1024)
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- argmax of |corr| with first-index tie-break (MATLAB max) -------------------------------
+    const float2 *c = corr + (long long)t * size_d;
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < size_d; i += NT) {
+        const float2 v = c[i];
+        float a = sqrtf(v.x * v.x + v.y * v.y);
+        if (a != a) a = -1.f;                       // NaN never wins unless everything is NaN
+        if (a > best) { best = a; bi = i; }         // strided scan keeps the smallest index per thread
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { shv[wave] = best; shi[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < NW; ++k)
+            if (shv[k] > best || (shv[k] == best && shi[k] < bi)) { best = shv[k]; bi = shi[k]; }
+        if (bi == 0x7fffffff) bi = 0;
+        s_idx = bi;
+        s.sel[(long long)t * m + it] = bi;
+        int dup = -1;
+        const int nu = s.nu[t];
+        for (int j = 0; j < nu; ++j)
+            if (s.uniq[(long long)t * m + j] == bi) { dup = j; break; }
+        s_dup = dup;
+        if (dup >= 0) s.mult[(long long)t * m + dup] += 1;
+    }
+    __syncthreads();
+    if (s_dup >= 0) return;                         // re-selected atom: span (and residual) unchanged
+    const int idx = s_idx;
+    const int u = s.nu[t];
+    float2 *w = s.w + (long long)t * meas;
+    float2 *Q = s.Qb + (long long)t * meas * m;
+    float2 *Rc = s.Rm + (long long)t * m * m + (long long)u * m;       // column u of R
+    float2 *r = s.r + (long long)t * meas;
+    // ---- load the atom ----------------------------------------------------------------------------
+    double nrm0 = 0;
+    if (Bf) {
+        const int g = idx % Gr, h = idx / Gr;
+        const float2 *a = A + (long long)t * strideA + (long long)N * g;            // Af(:, g)
+        const float2 *b = Bf + (long long)t * strideB + h;                          // Bf(h, :) stride G2
+        for (int e = tid; e < meas; e += NT) {
+            const float2 x = a[e % N], y = b[(long long)G2 * (e / N)];
+            const float2 v = make_float2(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x);
+            w[e] = v;
+            nrm0 += (double)v.x * v.x + (double)v.y * v.y;
+        }
+    } else {
+        const float2 *a = A + (long long)t * strideA + (long long)meas * idx;
+        for (int e = tid; e < meas; e += NT) {
+            const float2 v = a[e];
+            w[e] = v;
+            nrm0 += (double)v.x * v.x + (double)v.y * v.y;
+        }
+    }
+    nrm0 = block_sum2<NT>(make_double2(nrm0, 0), sh).x;
+    for (int j = tid; j < m; j += NT) Rc[j] = make_float2(0.f, 0.f);
+    __syncthreads();
+    // ---- classical Gram-Schmidt against the basis, twice -----------------------------------------------
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = wave; j < u; j += NW) {            // d_j = q_j^H w, one wave per j
+            const float2 *q = Q + (long long)meas * j;
+            double2 d = make_double2(0, 0);
+            for (int e = lane; e < meas; e += 64) {
+                const float2 qq = q[e], ww = w[e];
+                d.x += (double)qq.x * ww.x + (double)qq.y * ww.y;       // conj(q) * w
+                d.y += (double)qq.x * ww.y - (double)qq.y * ww.x;
+            }
+            d = wave_sum2(d);
+            if (lane == 0) dsh[j] = make_float2((float)d.x, (float)d.y);
+        }
+        __syncthreads();
+        for (int e = tid; e < meas; e += NT) {
+            float2 ww = w[e];
+            for (int j = 0; j < u; ++j) {
+                const float2 qq = Q[(long long)meas * j + e], h = dsh[j];
+                ww.x -= h.x * qq.x - h.y * qq.y;
+                ww.y -= h.x * qq.y + h.y * qq.x;
+            }
+            w[e] = ww;
+        }
+        for (int j = tid; j < u; j += NT) { Rc[j].x += dsh[j].x; Rc[j].y += dsh[j].y; }
+        __syncthreads();
+    }
+    double n2 = 0;
+    for (int e = tid; e < meas; e += NT) { const float2 ww = w[e]; n2 += (double)ww.x * ww.x + (double)ww.y * ww.y; }
+    n2 = block_sum2<NT>(make_double2(n2, 0), sh).x;
+    if (!(n2 > 1e-12 * nrm0)) return;              // numerically dependent on the chosen atoms: adds nothing
+    const float inv = (float)(1.0 / sqrt(n2));
+    // ---- q_u = w/|w|, z_u = q_u^H v = q_u^H r (r is orthogonal to the old basis), r -= z_u q_u --------
+    float2 *qu = Q + (long long)meas * u;
+    double2 d = make_double2(0, 0);
+    for (int e = tid; e < meas; e += NT) {
+        const float2 ww = w[e], rr = r[e];
+        const float2 qv = make_float2(ww.x * inv, ww.y * inv);
+        qu[e] = qv;
+        d.x += (double)qv.x * rr.x + (double)qv.y * rr.y;
+        d.y += (double)qv.x * rr.y - (double)qv.y * rr.x;
+    }
+    d = block_sum2<NT>(d, sh);
+    const float zx = (float)d.x, zy = (float)d.y;
+    for (int e = tid; e < meas; e += NT) {
         const float2 qv = qu[e];
         float2 rr = r[e];
         rr.x -= zx * qv.x - zy * qv.y;
@@ -409,190 +569,6 @@ __global__ __launch_bounds__(256) void omp_corr_gemv_kernel(int meas, int size_d
 }
 
 
-// ---- ONE problem (the reference's own case, BASELINE configs[0]): all m iterations of OMP.m:16-24 in ONE cooperative launch.
-//      Per iteration the two-launch form above pays two kernel launches for 8 MB of dictionary traffic (58 us per iteration at
-//      configs[0], 6.5 us of it the correlation).  Here the grid stays resident: every wave owns the atoms j = wave, wave + W, ...
-//      (kept in registers when each wave has one atom of at most 1024 entries: the dictionary is then read from memory ONCE per
-//      call), computes its correlations with exactly the arithmetic of omp_corr_gemv_kernel (fp32 chains of <= 32 terms, float64
-//      wave-shuffle reduction), a grid barrier, workgroup 0 does argmax (first index on ties) + duplicate bookkeeping + the
-//      orthogonalisation + the residual update, a second grid barrier.  The orthogonalisation is classical Gram-Schmidt done
-//      twice (CGS2) with the u inner products of a pass spread over the four waves - 2 rounds of (u / 4 wave-local reductions +
-//      one update) instead of the 2 u block-wide reductions of omp_step_kernel's modified Gram-Schmidt; float64 inner products
-//      as there.  State (Q, R, z, multiplicities) as the two-launch form keeps it: omp_finish_kernel is shared.
-__device__ __forceinline__ void omp_grid_barrier(unsigned *ctr, unsigned nblocks, unsigned &gen)
-{
-    __syncthreads();
-    ++gen;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(ctr, 1u);
-        const unsigned want = gen * nblocks;
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
-        __threadfence();
-    }
-    __syncthreads();
-}
-
-template <bool REG>
-__global__ __launch_bounds__(256) void omp_persist_kernel(int meas, int size_d, int m, const float2 *A, float2 *corr, OmpState s,
-                                                          unsigned *bar)
-{
-    extern __shared__ __align__(16) unsigned char omp_lds[];
-    float2 *w = reinterpret_cast<float2 *>(omp_lds);                      // [meas]   (workgroup 0)
-    float2 *dsh = w + meas;                                               // [m]      inner products of a pass
-    __shared__ double sh[8];
-    __shared__ float shv[4];
-    __shared__ int shi[4];
-    __shared__ int s_idx, s_dup;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int gw = blockIdx.x * 4 + wave, nw = gridDim.x * 4;
-    unsigned gen = 0;
-    float2 areg[16];
-    if (REG) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = lane + 64 * k;
-            areg[k] = (gw < size_d && i < meas) ? A[(long long)gw * meas + i] : make_float2(0.f, 0.f);
-        }
-    }
-    for (int it = 0; it < m; ++it) {
-        // ---- A' * r (:17)
-        for (int j = gw; j < size_d; j += nw) {
-            const float2 *a = A + (long long)j * meas;
-            float sr = 0.f, si = 0.f;
-            double dr = 0.0, di = 0.0;
-            int cnt = 0;
-            if (REG) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < meas) {
-                        const float2 x = areg[k], y = s.r[i];
-                        sr = fmaf(x.x, y.x, fmaf(x.y, y.y, sr));
-                        si = fmaf(x.x, y.y, fmaf(-x.y, y.x, si));
-                        if (++cnt == 32) { dr += sr; di += si; sr = 0.f; si = 0.f; cnt = 0; }
-                    }
-                }
-            } else {
-                for (int i = lane; i < meas; i += 64) {
-                    const float2 x = a[i], y = s.r[i];
-                    sr = fmaf(x.x, y.x, fmaf(x.y, y.y, sr));            // conj(a) r
-                    si = fmaf(x.x, y.y, fmaf(-x.y, y.x, si));
-                    if (++cnt == 32) { dr += sr; di += si; sr = 0.f; si = 0.f; cnt = 0; }
-                }
-            }
-            dr += sr; di += si;
-            for (int o = 32; o > 0; o >>= 1) { dr += __shfl_xor(dr, o); di += __shfl_xor(di, o); }
-            if (lane == 0) corr[j] = make_float2((float)dr, (float)di);
-        }
-        omp_grid_barrier(bar, gridDim.x, gen);
-        if (blockIdx.x == 0) {
-            // ---- [~, idx] = max(abs(.)) with first-index tie-break (:17), as omp_step_kernel
-            float best = -1.f;
-            int bi = 0x7fffffff;
-            for (int i = tid; i < size_d; i += 256) {
-                const float2 v = corr[i];
-                float a = sqrtf(v.x * v.x + v.y * v.y);
-                if (a != a) a = -1.f;
-                if (a > best) { best = a; bi = i; }
-            }
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ob = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) { shv[wave] = best; shi[wave] = bi; }
-            __syncthreads();
-            if (tid == 0) {
-                for (int k = 1; k < 4; ++k)
-                    if (shv[k] > best || (shv[k] == best && shi[k] < bi)) { best = shv[k]; bi = shi[k]; }
-                if (bi == 0x7fffffff) bi = 0;
-                s_idx = bi;
-                s.sel[it] = bi;
-                int dup = -1;
-                const int nu = s.nu[0];
-                for (int j = 0; j < nu; ++j)
-                    if (s.uniq[j] == bi) { dup = j; break; }
-                s_dup = dup;
-                if (dup >= 0) s.mult[dup] += 1;
-            }
-            __syncthreads();
-            if (s_dup < 0) {                    // (a re-selected atom leaves span and residual unchanged)
-                const int idx = s_idx, u = s.nu[0];
-                float2 *Q = s.Qb, *Rc = s.Rm + (long long)u * m, *r = s.r;
-                const float2 *a = A + (long long)meas * idx;
-                double nrm0 = 0;
-                for (int e = tid; e < meas; e += 256) {
-                    const float2 v = a[e];
-                    w[e] = v;
-                    nrm0 += (double)v.x * v.x + (double)v.y * v.y;
-                }
-                nrm0 = block_sum2(make_double2(nrm0, 0), sh).x;
-                for (int j = tid; j < m; j += 256) Rc[j] = make_float2(0.f, 0.f);
-                __syncthreads();
-                for (int pass = 0; pass < 2; ++pass) {
-                    for (int j = wave; j < u; j += 4) {              // d_j = q_j^H w, one wave per j
-                        const float2 *q = Q + (long long)meas * j;
-                        double2 d = make_double2(0, 0);
-                        for (int e = lane; e < meas; e += 64) {
-                            const float2 qq = q[e], ww = w[e];
-                            d.x += (double)qq.x * ww.x + (double)qq.y * ww.y;
-                            d.y += (double)qq.x * ww.y - (double)qq.y * ww.x;
-                        }
-                        for (int o = 32; o > 0; o >>= 1) { d.x += __shfl_xor(d.x, o); d.y += __shfl_xor(d.y, o); }
-                        if (lane == 0) dsh[j] = make_float2((float)d.x, (float)d.y);
-                    }
-                    __syncthreads();
-                    for (int e = tid; e < meas; e += 256) {
-                        float2 ww = w[e];
-                        for (int j = 0; j < u; ++j) {
-                            const float2 qq = Q[(long long)meas * j + e], h = dsh[j];
-                            ww.x -= h.x * qq.x - h.y * qq.y;
-                            ww.y -= h.x * qq.y + h.y * qq.x;
-                        }
-                        w[e] = ww;
-                    }
-                    for (int j = tid; j < u; j += 256) { Rc[j].x += dsh[j].x; Rc[j].y += dsh[j].y; }
-                    __syncthreads();
-                }
-                double n2 = 0;
-                for (int e = tid; e < meas; e += 256) { const float2 ww = w[e]; n2 += (double)ww.x * ww.x + (double)ww.y * ww.y; }
-                n2 = block_sum2(make_double2(n2, 0), sh).x;
-                if (n2 > 1e-12 * nrm0) {           // (else numerically dependent on the chosen atoms: adds nothing)
-                    const float inv = (float)(1.0 / sqrt(n2));
-                    float2 *qu = Q + (long long)meas * u;
-                    double2 d = make_double2(0, 0);
-                    for (int e = tid; e < meas; e += 256) {
-                        const float2 ww = w[e], rr = r[e];
-                        const float2 qv = make_float2(ww.x * inv, ww.y * inv);
-                        qu[e] = qv;
-                        w[e] = qv;
-                        d.x += (double)qv.x * rr.x + (double)qv.y * rr.y;
-                        d.y += (double)qv.x * rr.y - (double)qv.y * rr.x;
-                    }
-                    d = block_sum2(d, sh);
-                    const float zx = (float)d.x, zy = (float)d.y;
-                    for (int e = tid; e < meas; e += 256) {
-                        const float2 qv = w[e];
-                        float2 rr = r[e];
-                        rr.x -= zx * qv.x - zy * qv.y;
-                        rr.y -= zx * qv.y + zy * qv.x;
-                        r[e] = rr;
-                    }
-                    if (tid == 0) {
-                        Rc[u] = make_float2((float)sqrt(n2), 0.f);
-                        s.z[u] = make_float2(zx, zy);
-                        s.uniq[u] = idx;
-                        s.mult[u] = 1;
-                        s.nu[0] = u + 1;
-                    }
-                }
-            }
-        }
-        omp_grid_barrier(bar, gridDim.x, gen);
-    }
-}
-
 extern "C" {
 
 int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c32 *A_, long long strideA,
@@ -608,7 +584,7 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
     JSTSP_ENTER(ctx);
     const size_t szA = strideA ? (size_t)strideA * (batch - 1) + (size_t)meas * size_d : (size_t)meas * size_d;
     size_t need = omp_bytes(meas, m, batch) + rnd256((size_t)batch * size_d * sizeof(float2)) * 2 +
-                  rnd256((size_t)batch * m * sizeof(int32_t)) + rnd256((size_t)batch * meas * m * sizeof(float2)) + 256;
+                  rnd256((size_t)batch * m * sizeof(int32_t)) + rnd256((size_t)batch * meas * m * sizeof(float2));
     if (memspace == JSTSP_HOST) need += rnd256(szA * sizeof(float2)) + rnd256((size_t)batch * meas * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
     ctx->arena.reset();
@@ -626,25 +602,7 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
     JSTSP_HIP(hipMemcpyAsync(s.r, v, (size_t)batch * meas * sizeof(float2), hipMemcpyDeviceToDevice, st));   // r = v (:10)
     JSTSP_HIP(hipMemsetAsync(s.nu, 0, batch * sizeof(int), st));
     JSTSP_HIP(hipMemsetAsync(s.Rm, 0, (size_t)batch * m * m * sizeof(float2), st));
-    // ONE problem: all iterations in one cooperative launch (omp_persist_kernel); anything else, or a runtime that refuses the
-    // cooperative launch: two launches per iteration
-    bool persisted = false;
-    if (batch == 1 && meas <= 2048 && tune().omp_persist != 0) {
-        unsigned *bar = ctx->arena.get<unsigned>(64);
-        JSTSP_REQUIRE(bar, JSTSP_E_NOMEM, "OMP: workspace exhausted");
-        JSTSP_HIP(hipMemsetAsync(bar, 0, 64 * sizeof(unsigned), st));
-        const bool reg = meas <= 1024 && size_d <= 4 * ctx->num_cus;
-        const int grid = std::max(1, std::min(ctx->num_cus, (size_d + 3) / 4));
-        const size_t lds = ((size_t)meas + m) * sizeof(float2);
-        int mi = meas, sd = size_d, mm = m;
-        const float2 *Ap = A;
-        void *args[] = {&mi, &sd, &mm, &Ap, &corr, &s, &bar};
-        const void *fn = reg ? (const void *)omp_persist_kernel<true> : (const void *)omp_persist_kernel<false>;
-        const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(grid), dim3(256), args, (unsigned)lds, st);
-        if (e == hipSuccess) persisted = true;
-        else (void)hipGetLastError();           // (not available / too many workgroups for co-residency: the two-launch form)
-    }
-    for (int it = 0; it < m && !persisted; ++it) {                                                             // :16
+    for (int it = 0; it < m; ++it) {                                                             // :16
         // A'*r (:17).  Few right-hand sides per dictionary: the matrix-vector kernel above.  Shared dictionary and many problems:
         // one GEMM with the residuals of all problems as columns.
         if (strideA != 0 || batch <= 16)
@@ -656,8 +614,12 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
         else
             JSTSP_TRY(gemm(ctx, 'C', 'N', size_d, 1, meas, batch, Mat{A, strideA, meas},
                            Mat{s.r, (long long)meas, meas}, corr, (long long)size_d, size_d));
-        hipLaunchKernelGGL(omp_step_kernel, dim3(batch), dim3(256), 0, st, meas, size_d, m, it, corr, A, strideA,
-                           (const float2 *)nullptr, 0ll, 0, 0, 0, s);
+        if (batch <= 64)        // few problems: sixteen waves per problem
+            hipLaunchKernelGGL(omp_step_kernel<1024>, dim3(batch), dim3(1024), 0, st, meas, size_d, m, it, corr, A, strideA,
+                               (const float2 *)nullptr, 0ll, 0, 0, 0, s);
+        else
+            hipLaunchKernelGGL(omp_step_mgs_kernel, dim3(batch), dim3(256), 0, st, meas, size_d, m, it, corr, A, strideA,
+                               (const float2 *)nullptr, 0ll, 0, 0, 0, s);
     }
     hipLaunchKernelGGL(omp_finish_kernel, dim3(batch), dim3(256), m * sizeof(float2), st, meas, size_d, m, A,
                        strideA, (const float2 *)nullptr, 0ll, 0, 0, 0, s, xh, io, to);
@@ -787,7 +749,11 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
                        (long long)ng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
         JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Mat{Af, strideA, N}, Mat{Tc, (long long)ng, N}, corr,
                        (long long)size_d, Gr));
-        hipLaunchKernelGGL(omp_step_kernel, dim3(batch), dim3(256), 0, st, meas, size_d, m, it, corr, Af, strideA,
+        if (batch <= 64)
+            hipLaunchKernelGGL(omp_step_kernel<1024>, dim3(batch), dim3(1024), 0, st, meas, size_d, m, it, corr, Af, strideA,
+                           Bf, strideB, N, Gr, G2, s);
+        else
+            hipLaunchKernelGGL(omp_step_mgs_kernel, dim3(batch), dim3(256), 0, st, meas, size_d, m, it, corr, Af, strideA,
                            Bf, strideB, N, Gr, G2, s);
     }
     hipLaunchKernelGGL(omp_finish_kernel, dim3(batch), dim3(256), m * sizeof(float2), st, meas, size_d, m, Af,

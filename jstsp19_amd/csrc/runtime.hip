@@ -31,7 +31,6 @@ void load_tuning()
     t.rv_refresh = env_int("JSTSP_RV_REFRESH", t.rv_refresh);
     t.overlap = env_int("JSTSP_OVERLAP", t.overlap);
     t.svt_skip = env_int("JSTSP_SVT_SKIP", t.svt_skip);
-    t.omp_persist = env_int("JSTSP_OMP_PERSIST", t.omp_persist);
     t.lanczos = env_int("JSTSP_LANCZOS", t.lanczos);
     t.lanczos_warm = env_int("JSTSP_LANCZOS_WARM", t.lanczos_warm);
     t.lanczos_verify = env_int("JSTSP_LANCZOS_VERIFY", t.lanczos_verify);

@@ -93,14 +93,12 @@ def test_omp_kron_coefficient_domain_equals_measurement_domain_and_oracle():
             os.environ["JSTSP_OMP_GRAM"] = old
 
 
-@pytest.mark.parametrize("meas,size_d,m", [(1024, 1024, 24),     # BASELINE configs[0] dense: atoms in registers, one per wave
-                                           (300, 1500, 12),      # more atoms than waves: atoms re-read per iteration
-                                           (1500, 700, 9),       # columns longer than the register form takes
-                                           (64, 40, 10)])        # a small one: fewer atoms than waves
-def test_omp_one_problem_cooperative_launch_equals_two_launch_form_and_oracle(meas, size_d, m, monkeypatch):
-    """ONE problem (the reference's own case): all iterations of OMP.m:16-24 in one cooperative launch (omp_persist_kernel)
-    against the two-launches-per-iteration form (JSTSP_OMP_PERSIST=0) and the float64 oracle: index sets equal (integer work),
-    coefficients and the selected columns to fp32."""
+@pytest.mark.parametrize("meas,size_d,m", [(1024, 1024, 24),     # BASELINE configs[0] dense
+                                           (300, 1500, 12), (1500, 700, 9), (64, 40, 10)])
+def test_omp_one_problem_sixteen_wave_step_equals_the_batched_four_wave_step_and_oracle(meas, size_d, m):
+    """ONE problem (the reference's own case) takes the 1024-thread step kernel, a batch above 64 the 256-thread one (omp.hip:
+    classical Gram-Schmidt twice with wave-parallel inner products): the same problem through both and through the float64 oracle -
+    index sets equal (integer work), coefficients and the selected columns to fp32."""
     import jstsp19_amd as J
     from oracle import solvers as O
     rng = np.random.default_rng(meas + size_d)
@@ -110,11 +108,10 @@ def test_omp_one_problem_cooperative_launch_equals_two_launch_form_and_oracle(me
     x0[rng.choice(size_d, min(6, size_d // 2), replace=False)] = c(min(6, size_d // 2))
     v = (A @ x0 + 0.01 * c(meas)).astype(np.complex64)
     x1, i1, _, T1 = J.OMP(A, v, m)
-    monkeypatch.setenv("JSTSP_OMP_PERSIST", "0")
-    x0_, i0, _, T0 = J.OMP(A, v, m)
+    xb, ib, _, _ = J.OMP(A, np.tile(v, (65, 1)), m)                  # 65 copies: the batched step kernel
     xo, io, _, To = O.omp_literal(A.astype(complex), v.astype(complex), m)
-    assert np.array_equal(i1, i0) and np.array_equal(i1, io)
-    assert rel_err(x1, x0_) < 2e-5 and rel_err(x1, xo) < 2e-4
+    assert np.array_equal(i1, io) and np.array_equal(ib[0], io) and np.array_equal(ib[64], io)
+    assert rel_err(x1, xb[0]) < 2e-5 and rel_err(x1, xo) < 2e-4
     assert rel_err(T1, To) < 1e-6
 
 
