@@ -1024,9 +1024,8 @@ int launch_lmax(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long
     if (lz) {
         // four waves per matrix (one or two measured slower: too little parallelism per matrix, round 2)
         if (n <= 64) return launch_lanczos_t<64, 4, 1>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out, lw, first);
-        // order 65..128: two workgroups per CU (256 registers per lane, a dozen spilled) or one (JSTSP_LZ128_OCC=1) - TEMPORARY switch
-        if (getenv("JSTSP_LZ128_OCC") && atoi(getenv("JSTSP_LZ128_OCC")) == 1)
-            return launch_lanczos_t<128, 4, 1>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out, lw, first);
+        // order 65..128: two workgroups per CU (256 registers per lane, a dozen spilled to scratch) - one per CU with no spills
+        // measured slower at BASELINE configs[2] (sparse_admm x 100 at batch 1024: 0.42 s against 0.31 s, profiles/r05a)
         return launch_lanczos_t<128, 4, 2>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out, lw, first);
     }
     if (n <= 32) return launch_lmax_t<32>(ctx, n, batch, Gpart, sGt, nsplit, sGs, lam_out);

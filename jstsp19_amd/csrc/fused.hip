@@ -1072,6 +1072,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
             typedef short s16x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
             auto *lbase = (__attribute__((address_space(3))) unsigned char *)lds;
+            f32x4 ptr = f32x4{0.f, 0.f, 0.f, 0.f}, pti = ptr;      // (ACC == 3 only)
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
                 // rows 16 (GB w + gb) ..: delay ld, octet pair jp of block 0; lane: window column of row 4 q + (c16 >> 2)
@@ -1120,6 +1121,17 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                             if (grp < 12) F64_LOAD(grp, tn, rf[(grp >> 2) & 1][grp & 3])
                         }
                         pr[gb][n2] += tr; pi[gb][n2] += ti;
+                    } else if constexpr (ACC == 3) {
+                        // as 1, but the sums of block b are added behind the first products of block b + 1 (experiment)
+                        f32x4 tr = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f}), ti = mma(bf[0], k2, f32x4{0.f, 0.f, 0.f, 0.f});
+                        tr = mma(bf[0], k1, tr); ti = mma(bf[0], k3, ti);
+                        if (gb + n2 > 0) { pr[n2 > 0 ? gb : gb - 1][n2 > 0 ? n2 - 1 : 3] += ptr; pi[n2 > 0 ? gb : gb - 1][n2 > 0 ? n2 - 1 : 3] += pti; }
+                        tr = mma(bf[1], k0, tr); ti = mma(bf[1], k2, ti);
+                        k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
+                        tr = mma(bf[2], k2, tr); ti = mma(bf[2], k0, ti);
+                        tr = mma(bf[2], k3, tr); ti = mma(bf[2], k1, ti);
+                        tr = mma(bf[3], k2, tr); ti = mma(bf[3], k0, ti);
+                        ptr = tr; pti = ti;
                     } else {
                         f32x4 tt = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f});
                         tt = mma(bf[0], k1, tt); tt = mma(bf[1], k0, tt);
@@ -1139,6 +1151,7 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                     __builtin_amdgcn_sched_barrier(0);      // (else the fragment reads of all four n-blocks are hoisted: spills)
                 }
             }
+            if constexpr (ACC == 3) { pr[GB - 1][3] += ptr; pi[GB - 1][3] += pti; }
         }
         {
             constexpr int NG = (DBG & 4) ? 0 : 4 * GB;      // product groups that ran; what is left of the 12 pieces:
@@ -1416,6 +1429,10 @@ template <int GB> static int launch_fused64(jstsp_ctx *ctx, const FusedDesc &d)
     case 2:
         JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 2>), dim3(grid), dim3(512), sh, ctx->stream, d);
+        break;
+    case 3:
+        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+        hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 3>), dim3(grid), dim3(512), sh, ctx->stream, d);
         break;
     default:
         JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));

@@ -87,20 +87,18 @@ def test_order_128_curves_of_sparse_admm_and_mc_admm():
     Om = (torch.rand(batch, n, n, generator=g, device=dev) < 0.125).float()
     cm = J.colmajor
     tau, rho = np.full(batch, 0.05), np.full(batch, 0.1)
-    for occ in ("2", "1"):
-        with _env(JSTSP_LZ128_OCC=occ):
-            with _env(JSTSP_LANCZOS_WARM=0):
-                S0, ce0 = J.sparse_admm(cm(H), cm(OH), cm(D), cm(D), 60)
-                X0, cm0 = J.mc_admm(cm(H), cm(Om * OH), cm(Om), 25, tau, rho)
-            S1, ce1 = J.sparse_admm(cm(H), cm(OH), cm(D), cm(D), 60)
-            m1 = J.default_context(0).last_lanczos_mismatches()
-            X1, cm1 = J.mc_admm(cm(H), cm(Om * OH), cm(Om), 25, tau, rho)
-            m2 = J.default_context(0).last_lanczos_mismatches()
-            torch.cuda.synchronize()
-            assert torch.equal(S0, S1) and torch.equal(X0, X1)
-            np.testing.assert_allclose(ce1.cpu().numpy(), ce0.cpu().numpy(), rtol=2e-5)
-            np.testing.assert_allclose(cm1.cpu().numpy(), cm0.cpu().numpy(), rtol=2e-5)
-            assert m1 == 0 and m2 == 0
+    with _env(JSTSP_LANCZOS_WARM=0):
+        S0, ce0 = J.sparse_admm(cm(H), cm(OH), cm(D), cm(D), 60)
+        X0, cm0 = J.mc_admm(cm(H), cm(Om * OH), cm(Om), 25, tau, rho)
+    S1, ce1 = J.sparse_admm(cm(H), cm(OH), cm(D), cm(D), 60)
+    m1 = J.default_context(0).last_lanczos_mismatches()
+    X1, cm1 = J.mc_admm(cm(H), cm(Om * OH), cm(Om), 25, tau, rho)
+    m2 = J.default_context(0).last_lanczos_mismatches()
+    torch.cuda.synchronize()
+    assert torch.equal(S0, S1) and torch.equal(X0, X1)
+    np.testing.assert_allclose(ce1.cpu().numpy(), ce0.cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(cm1.cpu().numpy(), cm0.cpu().numpy(), rtol=2e-5)
+    assert m1 == 0 and m2 == 0
 
 
 def _herm(U, lam):
