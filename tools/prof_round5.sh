@@ -16,3 +16,4 @@ timeout 600 bash tools/prof_cmd.sh r05_cfg3 tools/bench_cfg3.py 1024 | tail -24
 timeout 900 bash tools/prof_cmd.sh r05_cfg5_b32 tools/probe/cfg5_angles.py 32 | tail -24
 timeout 600 python3 tools/host_path_rate.py 256 c64 > gpurun_out/r05_host_path.txt 2>&1; grep -v amdgpu gpurun_out/r05_host_path.txt
 timeout 300 python3 tools/parity_fixture_check.py --n 640 --out gpurun_out/r05_rv_refresh1.json "" "JSTSP_RV_REFRESH=1" "JSTSP_RV_REFRESH=2" 2>&1 | grep -v amdgpu | cut -c1-200
+for acc in 1 3 0; do echo "PASS_ACC=$acc"; JSTSP_PASS_ACC=$acc timeout 300 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-path --no-strict-fp32 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline']['avg_launch_ms'], d['parity']['whole_batch']['max_abs_dNMSE'], d['parity']['whole_batch']['rms_dNMSE'])"; done > gpurun_out/r05_pass_acc_speed.txt 2>&1; cat gpurun_out/r05_pass_acc_speed.txt
