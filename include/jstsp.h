@@ -105,7 +105,8 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *   JSTSP_HOST_PIPELINE=0 a JSTSP_HOST proposed_algorithm call of 128 or more problems as ONE staged solve (default: its two halves on
  *                         two internal contexts, the upload of the second overlapping the solve of the first)
  *   JSTSP_PASS_ACC=0      window pass: every product of K B^H accumulates straight into the 32-tile running sums (rounds 2-4;
- *                         default 1: the six products of a tile's block are summed first, the running sum rounded once per tile)
+ *                         default 1: the six products of a tile's block are summed first, the running sum rounded once per tile:
+ *                         1.0e-7 less rms |dNMSE| for +3 % kernel time)
  *   JSTSP_INV2=0          the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (default 1: formed in the pass from
  *                         Omega as two floats)
  *   JSTSP_HOST_COMPACT=0  a JSTSP_HOST dictionary is uploaded whole (default 1: per-trial dictionaries of 64 MiB or more are tested

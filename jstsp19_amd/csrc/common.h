@@ -79,7 +79,7 @@ struct Tuning {
     int rv_comp = 0;        // JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
     int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
     int inv_two_float = 1;  // JSTSP_INV2: 0 the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (rounds 1-4)
-    int pass_acc = 1;       // JSTSP_PASS_ACC: 0 products of K B^H straight into the window pass's running sums (rounds 2-4), 1 / 2 per-tile block sums first (fused.hip)
+    int pass_acc = 1;       // JSTSP_PASS_ACC: 0 products of K B^H straight into the window pass's running sums (rounds 2-4), 1 per-tile block sums first (fused.hip)
     int host_compact = 1;   // JSTSP_HOST_COMPACT: 0 a JSTSP_HOST dictionary is uploaded whole (no host-side block-Toeplitz test / compaction)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v

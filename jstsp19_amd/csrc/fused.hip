@@ -1072,7 +1072,6 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
             typedef short s16x4 __attribute__((ext_vector_type(4)));
             typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
             auto *lbase = (__attribute__((address_space(3))) unsigned char *)lds;
-            f32x4 ptr = f32x4{0.f, 0.f, 0.f, 0.f}, pti = ptr;      // (ACC == 3 only)
 #pragma unroll
             for (int gb = 0; gb < GB; ++gb) {
                 // rows 16 (GB w + gb) ..: delay ld, octet pair jp of block 0; lane: window column of row 4 q + (c16 >> 2)
@@ -1094,11 +1093,12 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                     u32x4 k0 = *reinterpret_cast<const u32x4 *>(kp), k1 = *reinterpret_cast<const u32x4 *>(kp + 1024);
                     const u32x4 k2 = *reinterpret_cast<const u32x4 *>(kp + 2048), k3 = *reinterpret_cast<const u32x4 *>(kp + 3072);
                     // re += Br kr + Bi ki ; im += Br ki - Bi kr
-                    // ACC = 0: every product accumulates straight into the running sums (rounds 2-4).  ACC = 1 / 2 (round 5): the six
-                    // products of a tile's block are summed in fresh accumulators and added to the running sums ONCE - the running
-                    // sum, 32 tiles long, is rounded once per tile instead of six times (the fp32 accumulation noise of K B^H is the
-                    // largest single term of the parity floor); 1: real and imaginary chains interleaved (8 more
-                    // registers), 2: one after the other (4)
+                    // ACC = 0: every product accumulates straight into the running sums (rounds 2-4).  ACC = 1 (round 5, default): the
+                    // six products of a tile's block are summed in fresh accumulators and added to the running sums ONCE - the
+                    // running sum, 32 tiles long, is rounded once per tile instead of six times: 1.0e-7 of the 1.73e-7 rms dNMSE
+                    // of round 4 was this.  +3 % kernel time (the adds wait for the last product of their
+                    // chain; measured slower still: the two chains one after the other, 795 vs 798 channel-estimates/s, and the adds
+                    // deferred behind the next block's first products, 803 vs 815 with 4 more spilled registers)
                     if constexpr (ACC == 0) {
                         pr[gb][n2] = mma(bf[0], k0, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k2, pi[gb][n2]);
                         pr[gb][n2] = mma(bf[0], k1, pr[gb][n2]); pi[gb][n2] = mma(bf[0], k3, pi[gb][n2]);
@@ -1121,27 +1121,6 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                             if (grp < 12) F64_LOAD(grp, tn, rf[(grp >> 2) & 1][grp & 3])
                         }
                         pr[gb][n2] += tr; pi[gb][n2] += ti;
-                    } else if constexpr (ACC == 3) {
-                        // as 1, but the sums of block b are added behind the first products of block b + 1 (experiment)
-                        f32x4 tr = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f}), ti = mma(bf[0], k2, f32x4{0.f, 0.f, 0.f, 0.f});
-                        tr = mma(bf[0], k1, tr); ti = mma(bf[0], k3, ti);
-                        if (gb + n2 > 0) { pr[n2 > 0 ? gb : gb - 1][n2 > 0 ? n2 - 1 : 3] += ptr; pi[n2 > 0 ? gb : gb - 1][n2 > 0 ? n2 - 1 : 3] += pti; }
-                        tr = mma(bf[1], k0, tr); ti = mma(bf[1], k2, ti);
-                        k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
-                        tr = mma(bf[2], k2, tr); ti = mma(bf[2], k0, ti);
-                        tr = mma(bf[2], k3, tr); ti = mma(bf[2], k1, ti);
-                        tr = mma(bf[3], k2, tr); ti = mma(bf[3], k0, ti);
-                        ptr = tr; pti = ti;
-                    } else {
-                        f32x4 tt = mma(bf[0], k0, f32x4{0.f, 0.f, 0.f, 0.f});
-                        tt = mma(bf[0], k1, tt); tt = mma(bf[1], k0, tt);
-                        tt = mma(bf[2], k2, tt); tt = mma(bf[2], k3, tt); tt = mma(bf[3], k2, tt);
-                        k0 = *reinterpret_cast<const u32x4 *>(kp + 4096); k1 = *reinterpret_cast<const u32x4 *>(kp + 5120);   // -kr
-                        f32x4 tu = mma(bf[0], k2, f32x4{0.f, 0.f, 0.f, 0.f});
-                        pr[gb][n2] += tt;
-                        tu = mma(bf[0], k3, tu); tu = mma(bf[1], k2, tu);
-                        tu = mma(bf[2], k0, tu); tu = mma(bf[2], k1, tu); tu = mma(bf[3], k0, tu);
-                        pi[gb][n2] += tu;
                     }
                     if constexpr (ACC != 1) {
                         const int grp = 4 * gb + n2;
@@ -1151,7 +1130,6 @@ __global__ __launch_bounds__(512, 1) void fused_pass64_kernel(FusedDesc d)
                     __builtin_amdgcn_sched_barrier(0);      // (else the fragment reads of all four n-blocks are hoisted: spills)
                 }
             }
-            if constexpr (ACC == 3) { pr[GB - 1][3] += ptr; pi[GB - 1][3] += pti; }
         }
         {
             constexpr int NG = (DBG & 4) ? 0 : 4 * GB;      // product groups that ran; what is left of the 12 pieces:
@@ -1425,14 +1403,6 @@ template <int GB> static int launch_fused64(jstsp_ctx *ctx, const FusedDesc &d)
     case 1:
         JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 1>), dim3(grid), dim3(512), sh, ctx->stream, d);
-        break;
-    case 2:
-        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 2>), dim3(grid), dim3(512), sh, ctx->stream, d);
-        break;
-    case 3:
-        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 3>), dim3(grid), dim3(512), sh, ctx->stream, d);
         break;
     default:
         JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
