@@ -299,6 +299,29 @@ def test_vamp_m_greater_n_branch():
     assert rel_err(Xb[0], J.vamp_kron(g["Y"], g["Af"], g["Gb"], sig, int(g["Lk"]), nit=5)) < 1e-5
 
 
+def test_vamp_tall_dictionary_on_a_fresh_context_fits_its_workspace():
+    """A tall dense dictionary (512 x 64: M > N, the eigen-decomposition is of order min(M, N) = 64) on a context that has never
+    grown its workspace: the budget (vamp_bytes) and the allocation (vamp_run) once disagreed about the order of that
+    decomposition and the first call failed with JSTSP_E_NOMEM.  The same through per-trial dictionaries; results against the oracle's
+    first iterations."""
+    import jstsp19_amd as J
+    from oracle import vamp as OV
+    rng = np.random.default_rng(8)
+    M, N, b = 512, 64, 3
+    A = ((rng.standard_normal((b, M, N)) + 1j * rng.standard_normal((b, M, N))) / np.sqrt(M)).astype(np.complex64)
+    x0 = np.zeros((b, N), complex)
+    for t in range(b):
+        x0[t, rng.choice(N, 5, replace=False)] = rng.standard_normal(5) + 1j * rng.standard_normal(5)
+    y = (np.einsum("tmn,tn->tm", A, x0) + 0.05 * (rng.standard_normal((b, M)) + 1j * rng.standard_normal((b, M)))).astype(np.complex64)
+    ctx = J.Context(0)                                   # fresh: no workspace yet
+    x1 = J.vamp(y[0], A[0], 1.0, 5, nit=3, ctx=ctx)
+    xo = OV.vamp_literal(y[0].astype(complex), A[0].astype(complex), 1.0, 5, nit=3)
+    assert rel_err(x1, xo) < 1e-3
+    ctx2 = J.Context(0)
+    xb = J.vamp(y, A, 1.0, 5, nit=3, ctx=ctx2)           # per-trial dictionaries: the shortfall scaled with the batch
+    assert rel_err(xb[0], x1) < 1e-5
+
+
 def test_ls_baseline_matches_pinv():
     """S_ls = pinv(A)*Y*pinv(B) (plot_errorVSsnr.m:83)."""
     import jstsp19_amd as J

@@ -118,6 +118,18 @@ def test_opt_in_two_float_recurrence_on_192_trials(env, monkeypatch):
     assert np.sqrt(np.mean(d ** 2)) < TOL / 3
 
 
+def test_two_float_recurrence_with_recomputation_every_iteration_does_not_fault(monkeypatch):
+    """JSTSP_RV_COMP=1 together with JSTSP_RV_REFRESH=1 (both documented switches): the step kernel once received a NULL R v with
+    non-NULL low-order parts and faulted on the device.  64 trials: finite, inside the accuracy statement."""
+    fx = fixture()
+    monkeypatch.setenv("JSTSP_RV_COMP", "1")
+    monkeypatch.setenv("JSTSP_RV_REFRESH", "1")
+    rows = np.nonzero((fx["sweep_proposed/snr_db"] == 0.0) & (fx["sweep_proposed/trial"] < 64))[0]
+    nmse, _ = solve_group(fx, "sweep_proposed", rows, want_ce=True, angles=False, chunk=64)
+    d = nmse - fx["sweep_proposed/nmse_port"][rows]
+    assert np.all(np.isfinite(nmse)) and np.abs(d).max() < TOL
+
+
 # ---- the HELD-OUT fixture (round 5): another generator seed (20260105), 10 SNR points x 256 proposed_algorithm trials and
 #      10 x 128 proposed_algorithm_angles trials.  tests/golden/fullsize_port.npz above is the set the round-4 defaults (how often
 #      R v is recomputed, which products run in float64) were CHOSEN on; nothing was ever chosen on this one: if a numerical
