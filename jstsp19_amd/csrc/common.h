@@ -326,6 +326,10 @@ struct HGemmDesc {
     // the product is Hermitian (a Gram: b = conj(a)^T): tiles entirely below the diagonal are not computed - the caller fills the
     // lower triangle from the upper one (hermitian_fill_lower)
     int herm_upper;
+    // block -> (trial, tile) map, set by launch_hgemm.  0: all tiles of a trial on one XCD (the a panel of the trial stays in that
+    // XCD's L2; right when every trial has its own b).  map_tb > 0 (b shared by the trials, sPt == 0): the workgroups resident on
+    // one XCD at a time are map_tb trials x map_tt tiles, so a b panel fetched for one trial is an L2 hit for the other map_tb - 1
+    int map_tb, map_tt;
 };
 // G[r, c] = conj(G[c, r]) for r > c, count matrices of order n (column-major, leading dimension n, stride sGt)
 int hermitian_fill_lower(jstsp_ctx *ctx, float2 *G, long long sGt, int n, int count);

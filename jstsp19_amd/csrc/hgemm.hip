@@ -115,6 +115,28 @@ __device__ __forceinline__ half8 neg_half8(uint4 u)
     return *reinterpret_cast<half8 *>(&u);
 }
 
+// blockIdx -> (trial, tile).  Workgroups are dealt to the 8 XCDs round-robin (XCD = blockIdx & 7) and each XCD has its own L2.
+// Own b per trial: all tiles of a trial run on one XCD, so the trial's a panel is fetched once.  Shared b (d.map_tb > 0): the
+// slots of an XCD are cut into blocks of map_tb trials x map_tt tiles (trial fastest), about as many workgroups as the XCD holds
+// at a time: per k stage such a block fetches map_tb a panels and map_tt b panels instead of 1 + (all tiles) — at configs[4]
+// (32 trials x 2 GiB shared packed dictionary) the per-trial map re-read the dictionary 32 times, 64 GiB through the fabric.
+__device__ __forceinline__ bool block_to_trial_tile(const HGemmDesc &d, int tiles, int &t, int &tile)
+{
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    if (d.map_tb == 0) {
+        t = (slot / tiles) * 8 + xcd;
+        tile = slot % tiles;
+        return t < d.batch;
+    }
+    const int per = d.map_tb * d.map_tt;
+    const int nbt = (d.batch + d.map_tb - 1) / d.map_tb;
+    const int blk = (slot / per) * 8 + xcd, w = slot % per;
+    t = (blk % nbt) * d.map_tb + w % d.map_tb;
+    tile = (blk / nbt) * d.map_tt + w / d.map_tb;
+    return t < d.batch && tile < tiles;
+}
+
 // 64 x 64 output tile per 256-thread workgroup (2 x 2 waves of 32 x 32), two workgroups per CU.
 // LDS stage: a blocks [it 2][ks 2][plane 4] then b blocks [jt 2][ks 2][plane 4], 1 KiB each.
 // WJ = waves along j: 2 (64 x 64 tile, 256 threads, two workgroups per CU) or 4 (64 x 128 tile, 512 threads, one
@@ -129,11 +151,8 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
     __shared__ uint4 smem[2 * STG];
 
     const int tiles = tiles_i * tiles_j;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int t = (slot / tiles) * 8 + xcd;
-    if (t >= d.batch) return;
-    const int rem = slot % tiles;
+    int t, rem;
+    if (!block_to_trial_tile(d, tiles, t, rem)) return;
     const int ti = rem % tiles_i, tj = rem / tiles_i;
     const int i0 = ti * 64, j0 = tj * 32 * WJ;
     if (d.herm_upper && i0 >= j0 + 32 * WJ) return;     // Hermitian product: this tile lies below the diagonal
@@ -341,11 +360,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
     constexpr int NAB = 16 / NW;                  // packed a blocks per wave per stage
     __shared__ uint4 smem[2 * 1024];              // a panel, two stages: blocks [it 2][ks 2][plane 4], 1 KiB each
 
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int t = (slot / tiles_j) * 8 + xcd;
-    if (t >= d.batch) return;
-    const int tj = slot % tiles_j;
+    int t, tj;
+    if (!block_to_trial_tile(d, tiles_j, t, tj)) return;
     const int j0 = tj * 32 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -1050,17 +1066,34 @@ int hermitian_fill_lower(jstsp_ctx *ctx, float2 *G, long long sGt, int n, int co
     return 0;
 }
 
-int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
+// grid of a launch under the block map chosen for it (conc = workgroups one XCD holds at a time)
+static long long hgemm_grid(HGemmDesc &d, long long tiles, int conc)
 {
+    static const int map_on = [] { const char *e = getenv("JSTSP_HGEMM_MAP"); return e ? atoi(e) : 1; }();
+    d.map_tb = d.map_tt = 0;
+    if (map_on && d.sPt == 0 && d.batch >= 2 && tiles >= 2) {
+        // (measured at configs[4], batch 32: 2 ... 32 trials per block and half / twice as many workgroups per block are within
+        //  3 % of each other — what matters is that the trials of a tile run together at all)
+        d.map_tb = d.batch < 8 ? d.batch : 8;
+        d.map_tt = conc / d.map_tb < 1 ? 1 : conc / d.map_tb;
+        if (d.map_tt > tiles) d.map_tt = (int)tiles;
+        const long long nb = (long long)((d.batch + d.map_tb - 1) / d.map_tb) * ((tiles + d.map_tt - 1) / d.map_tt);
+        return ((nb + 7) / 8) * 8 * d.map_tb * d.map_tt;
+    }
+    return (long long)((d.batch + 7) / 8) * 8 * tiles;
+}
+
+int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d_in, const char *prof_name)
+{
+    HGemmDesc d = d_in;
     JSTSP_REQUIRE(d.m > 0 && d.n > 0 && d.k > 0 && d.batch > 0, JSTSP_E_SHAPE, "hgemm: bad shape");
     JSTSP_REQUIRE(d.KS >= 2 * ((d.k + 31) / 32) && d.JT >= 2 * ((d.n + 63) / 64), JSTSP_E_ARG,
                   "hgemm: packed operand smaller than the product");
     // 64 x 128 tiles (8 waves) for long contractions whose a operand is split in the kernel: half as many splits
     const bool wide = !d.Ap && d.epi == EPI_NONE && d.n >= 128 && d.JT * 32 >= ((d.n + 127) / 128) * 128;
     const int tiles_i = (d.m + 63) / 64, tiles_j = wide ? (d.n + 127) / 128 : (d.n + 63) / 64;
-    const long long groups = (d.batch + 7) / 8;
-    const long long grid = groups * 8 * tiles_i * tiles_j;
-    JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
+    const bool wide_even = wide && (d.k % 32) == 0 && ((d.KS / 2) % 2) == 0 && d.KS == 2 * (d.k / 32);
+    JSTSP_REQUIRE((long long)((d.batch + 7) / 8) * 8 * tiles_i * tiles_j < (1ll << 30), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
     // v2 (hgemm2_kernel): one row tile, b fragments straight to registers.  Bit 0: packed-a products (the synthesis); bit 1:
     // fp32-a products of up to 1024 terms (the G_B applies: 185 -> 135 us each, but their single-level 512-term sums feed the
     // cancellation Res = A^H Tc - G_A V G_B and triple the rounding noise in S, 1.9e-6 -> 5.9e-6 relative: not used)
@@ -1068,7 +1101,7 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
     const bool pack_ok = d.JT * 32 >= ((d.n + 127) / 128) * 128;       // j padded to 128 columns: 4 waves x 32
     if (d.m <= 64 && pack_ok && d.Ap && (v2_mask & 1) && d.aKS == d.KS && (d.KS % 4) == 0) {
         const int tj2 = (d.n + 127) / 128;
-        const long long grid2 = groups * 8 * tj2;
+        const long long grid2 = hgemm_grid(d, tj2, 64);
         if (prof_name) prof_begin(ctx, prof_name);
         if (d.epi == EPI_UPDATE_C)
             hgemm2_kernel<EPI_UPDATE_C, true, 4, 2><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
@@ -1082,15 +1115,16 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d, const char *prof_name)
     //  this kernel K B^H measured 1.13 ms against 0.98 ms, with 3x the rounding noise in S)
     if (d.m <= 64 && pack_ok && !d.Ap && (v2_mask & 2) && (d.KS % 4) == 0 && d.epi == EPI_NONE && d.k <= 1024) {
         const int tj2 = (d.n + 127) / 128;
-        const long long grid2 = groups * 8 * tj2;
+        const long long grid2 = hgemm_grid(d, tj2, 64);
         if (prof_name) prof_begin(ctx, prof_name);
         hgemm2_kernel<EPI_NONE, false, 4, 2><<<(unsigned)grid2, 256, 0, ctx->stream>>>(d, tj2);
         if (prof_name) prof_end(ctx, prof_name);
         JSTSP_HIP(hipGetLastError());
         return 0;
     }
+    const long long grid = hgemm_grid(d, (long long)tiles_i * tiles_j, wide ? 32 : 64);   // 96 KiB of LDS: one wide workgroup per CU
     if (prof_name) prof_begin(ctx, prof_name);
-    if (wide && (d.k % 32) == 0 && ((d.KS / 2) % 2) == 0 && d.KS == 2 * (d.k / 32)) {
+    if (wide_even) {
         hgemm_kernel<EPI_NONE, false, 4, true><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);
     } else if (wide) {
         hgemm_kernel<EPI_NONE, false, 4><<<(unsigned)grid, 512, 0, ctx->stream>>>(d, tiles_i, tiles_j);
