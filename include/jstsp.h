@@ -114,6 +114,8 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         leading columns - bit-identical results; 2: at any size)
  *   JSTSP_HGEMM_MAP=0     split-f16 products with one dictionary for all trials keep the per-trial workgroup order (default 1:
  *                         8 trials x 4-8 column tiles share an XCD's L2 at a time - same bits, -8 % at configs[4] batch 32)
+ *   JSTSP_OMP_REG=0       OMP of up to 64 problems keeps the candidate atom and the residual in global memory (default 1: in
+ *                         registers / LDS for measurement vectors of up to 2048 entries, with the first basis columns in LDS)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous
  *                         iteration's Ritz vector)

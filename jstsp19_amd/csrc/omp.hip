@@ -326,6 +326,256 @@ __global__ __launch_bounds__(NT) void omp_step_kernel(int meas, int size_d, int 
     }
 }
 
+// The same step with the working vector out of global memory (meas <= 1024 EPT, EPT = 1 or 2): thread tid owns elements
+// e = tid + 1024 k of the candidate w and of the residual r in registers, a copy of w sits in LDS for the wave-parallel inner
+// products, the re-selection test is one compare per thread instead of a serial scan by thread 0 (u dependent global loads of
+// ~0.7 us each), the loads of a basis column are issued eight at a time, and column u of R is written once.  Same arithmetic in
+// the same order as omp_step_kernel<1024>: the same atoms, x_hat equal to an ulp (the compiler contracts the updates differently).
+template <int EPT>
+__global__ __launch_bounds__(1024) void omp_step_reg_kernel(int meas, int size_d, int m, int it, const float2 *corr,
+                                                            const float2 *A, long long strideA, const float2 *Bf,
+                                                            long long strideB, int N, int Gr, int G2, OmpState s, int qc)
+{
+    constexpr int NT = 1024, NW = 16;
+    extern __shared__ float2 qsh[];                 // the first qc basis columns (one workgroup reads Q through one CU's 64 B per
+                                                    // clock: four sweeps over 24 columns were 5 us of an iteration)
+    __shared__ double sh[2 * NW];
+    __shared__ float shv[NW];
+    __shared__ int shi[NW];
+    __shared__ int s_dup;
+    __shared__ float2 dsh[2][1024];                 // inner products of the two passes (m <= 1024)
+    __shared__ float2 wsh[NT * EPT];
+    __shared__ double shn[NW];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u = s.nu[t];
+    float2 *r = s.r + (long long)t * meas;
+    float2 rv[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { const int e = tid + NT * k; rv[k] = e < meas ? r[e] : make_float2(0.f, 0.f); }   // used last
+    const float2 *Q = s.Qb + (long long)t * meas * m;
+    const int uc = min(u, qc);
+    // ---- argmax of |corr| with first-index tie-break (MATLAB max) -------------------------------
+    // Load order matters (loads return in order, a wait on one waits for all before it): the correlations first, then the first
+    // PRE basis columns into registers - independent of the atom chosen below, they arrive under the argmax and the atom fetch
+    // and go to LDS after that (issued as a fill loop up here they cost 2 us per 8 columns before the argmax could start).
+    const float2 *c = corr + (long long)t * size_d;
+    const float2 c0 = tid < size_d ? c[tid] : make_float2(0.f, 0.f);
+    constexpr int PRE = 16 / EPT;
+    float2 qpre[EPT][PRE];
+    if (uc > 0) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+#pragma unroll
+            for (int i = 0; i < PRE; ++i) qpre[k][i] = Q[(long long)meas * min(i, uc - 1) + min(tid + NT * k, meas - 1)];
+    }
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    if (tid < size_d) {
+        float a = sqrtf(c0.x * c0.x + c0.y * c0.y);
+        if (a != a) a = -1.f;
+        best = a; bi = tid;
+    }
+    for (int i = tid + NT; i < size_d; i += NT) {
+        const float2 v = c[i];
+        float a = sqrtf(v.x * v.x + v.y * v.y);
+        if (a != a) a = -1.f;
+        if (a > best) { best = a; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { shv[wave] = best; shi[wave] = bi; }
+    if (tid == 0) s_dup = 0x7fffffff;
+    __syncthreads();
+    best = shv[0]; bi = shi[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) {
+        const float ob = shv[k];
+        const int oi = shi[k];
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;
+    const int idx = bi;
+    for (int j = tid; j < u; j += NT)
+        if (s.uniq[(long long)t * m + j] == idx) atomicMin(&s_dup, j);
+    // ---- load the atom (whether or not it turns out to be a re-selection: the loads overlap the test) ------------------
+    float2 wv[EPT];
+    double nrm0 = 0;
+    if (Bf) {
+        const int g = idx % Gr, h = idx / Gr;
+        const float2 *a = A + (long long)t * strideA + (long long)N * g;            // Af(:, g)
+        const float2 *b = Bf + (long long)t * strideB + h;                          // Bf(h, :) stride G2
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + NT * k;
+            float2 v = make_float2(0.f, 0.f);
+            if (e < meas) {
+                const float2 x = a[e % N], y = b[(long long)G2 * (e / N)];
+                v = make_float2(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x);
+            }
+            wv[k] = v;
+        }
+    } else {
+        const float2 *a = A + (long long)t * strideA + (long long)meas * idx;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { const int e = tid + NT * k; wv[k] = e < meas ? a[e] : make_float2(0.f, 0.f); }
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        wsh[tid + NT * k] = wv[k];
+        nrm0 += (double)wv[k].x * wv[k].x + (double)wv[k].y * wv[k].y;
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + NT * k;
+        if (e < meas) {
+#pragma unroll
+            for (int i = 0; i < PRE; ++i)
+                if (i < uc) qsh[i * meas + e] = qpre[k][i];
+            for (int j0 = PRE; j0 < uc; j0 += 8) {          // (more columns than registers: short problems, meas < 1024)
+                float2 qq[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qq[i] = Q[(long long)meas * min(j0 + i, uc - 1) + e];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (j0 + i < uc) qsh[(j0 + i) * meas + e] = qq[i];
+            }
+        }
+    }
+    nrm0 = wave_sum2(make_double2(nrm0, 0)).x;
+    if (lane == 0) shn[wave] = nrm0;                // summed when it is needed (the dependence test below)
+    __syncthreads();                                // publishes wsh, s_dup, shn
+    const int dup = s_dup;
+    if (dup != 0x7fffffff) {                        // re-selected atom: span (and residual) unchanged
+        if (tid == 0) { s.sel[(long long)t * m + it] = idx; s.mult[(long long)t * m + dup] += 1; }
+        return;
+    }
+    // ---- classical Gram-Schmidt against the basis, twice -----------------------------------------------
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = wave; j < u; j += NW) {            // d_j = q_j^H w, one wave per j
+            const float2 *q = Q + (long long)meas * j;
+            double2 d = make_double2(0, 0);
+            if (j < uc) {
+                const float2 *ql = qsh + j * meas;
+                for (int e = lane; e < meas; e += 64) {
+                    const float2 qq = ql[e], ww = wsh[e];
+                    d.x += (double)qq.x * ww.x + (double)qq.y * ww.y;
+                    d.y += (double)qq.x * ww.y - (double)qq.y * ww.x;
+                }
+            } else
+            for (int e0 = lane; e0 < meas; e0 += 64 * 8) {              // eight loads in flight (the plain loop waited for each)
+                float2 qq[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qq[i] = q[min(e0 + 64 * i, meas - 1)];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = e0 + 64 * i;
+                    if (e < meas) {
+                        const float2 ww = wsh[e];
+                        d.x += (double)qq[i].x * ww.x + (double)qq[i].y * ww.y;       // conj(q) * w
+                        d.y += (double)qq[i].x * ww.y - (double)qq[i].y * ww.x;
+                    }
+                }
+            }
+            d = wave_sum2(d);
+            if (lane == 0) dsh[pass][j] = make_float2((float)d.x, (float)d.y);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + NT * k;
+            if (e < meas) {
+                float2 ww = wv[k];
+                for (int j = 0; j < uc; ++j) {
+                    const float2 qq = qsh[j * meas + e], h = dsh[pass][j];
+                    ww.x -= h.x * qq.x - h.y * qq.y;
+                    ww.y -= h.x * qq.y + h.y * qq.x;
+                }
+                for (int j0 = uc; j0 < u; j0 += 8) {
+                    float2 qq[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) qq[i] = Q[(long long)meas * min(j0 + i, u - 1) + e];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (j0 + i < u) {
+                            const float2 h = dsh[pass][j0 + i];
+                            ww.x -= h.x * qq[i].x - h.y * qq[i].y;
+                            ww.y -= h.x * qq[i].y + h.y * qq[i].x;
+                        }
+                }
+                wv[k] = ww;
+                wsh[e] = ww;
+            }
+        }
+        __syncthreads();
+    }
+    double n2 = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) n2 += (double)wv[k].x * wv[k].x + (double)wv[k].y * wv[k].y;
+    n2 = block_sum2<NT>(make_double2(n2, 0), sh).x;
+    if (tid == 0) s.sel[(long long)t * m + it] = idx;
+    nrm0 = 0;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) nrm0 += shn[k];
+    if (!(n2 > 1e-12 * nrm0)) return;              // numerically dependent on the chosen atoms: adds nothing
+    const float inv = (float)(1.0 / sqrt(n2));
+    // ---- q_u = w/|w|, z_u = q_u^H v = q_u^H r (r is orthogonal to the old basis), r -= z_u q_u --------
+    float2 *qu = s.Qb + (long long)t * meas * m + (long long)meas * u;
+    double2 d = make_double2(0, 0);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + NT * k;
+        const float2 qv = make_float2(wv[k].x * inv, wv[k].y * inv);
+        wv[k] = qv;
+        if (e < meas) qu[e] = qv;
+        d.x += (double)qv.x * rv[k].x + (double)qv.y * rv[k].y;
+        d.y += (double)qv.x * rv[k].y - (double)qv.y * rv[k].x;
+    }
+    d = block_sum2<NT>(d, sh);
+    const float zx = (float)d.x, zy = (float)d.y;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + NT * k;
+        float2 rr = rv[k];
+        rr.x -= zx * wv[k].x - zy * wv[k].y;
+        rr.y -= zx * wv[k].y + zy * wv[k].x;
+        if (e < meas) r[e] = rr;
+    }
+    float2 *Rc = s.Rm + (long long)t * m * m + (long long)u * m;       // column u of R (zero so far)
+    for (int j = tid; j < u; j += NT) {
+        float2 a = make_float2(0.f, 0.f);
+        a.x += dsh[0][j].x; a.y += dsh[0][j].y;
+        a.x += dsh[1][j].x; a.y += dsh[1][j].y;
+        Rc[j] = a;
+    }
+    if (tid == 0) {
+        Rc[u] = make_float2((float)sqrt(n2), 0.f);
+        s.z[(long long)t * m + u] = make_float2(zx, zy);
+        s.uniq[(long long)t * m + u] = idx;
+        s.mult[(long long)t * m + u] = 1;
+        s.nu[t] = u + 1;
+    }
+}
+
+// JSTSP_OMP_REG=0: the step through global memory (omp_step_kernel<1024>) also where the register form applies
+static bool omp_reg_step()
+{
+    static const bool on = [] { const char *e = getenv("JSTSP_OMP_REG"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
+// basis columns omp_step_reg_kernel keeps in LDS: what 160 KiB leave beside its static arrays (inner products 16 KiB, w 8 EPT KiB)
+static int omp_reg_qcols(int meas, int m)
+{
+    (void)hipFuncSetAttribute((const void *)omp_step_reg_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 138240);
+    (void)hipFuncSetAttribute((const void *)omp_step_reg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 130048);
+    const int budget = meas <= 1024 ? 138240 : 130048;
+    const int qc = budget / (meas * (int)sizeof(float2));
+    return qc < m ? qc : m;
+}
+
 // x_unique = R^{-1} z (back substitution), x_hat(idx) = x_unique / multiplicity, indexSet (1-based),
 // targetMatrix = the selected columns in selection order (OMP.m:18, 27-32).
 __global__ __launch_bounds__(256) void omp_finish_kernel(int meas, int size_d, int m, const float2 *A,
@@ -602,6 +852,7 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
     JSTSP_HIP(hipMemcpyAsync(s.r, v, (size_t)batch * meas * sizeof(float2), hipMemcpyDeviceToDevice, st));   // r = v (:10)
     JSTSP_HIP(hipMemsetAsync(s.nu, 0, batch * sizeof(int), st));
     JSTSP_HIP(hipMemsetAsync(s.Rm, 0, (size_t)batch * m * m * sizeof(float2), st));
+    const int qc = (batch <= 64 && meas <= 2048 && omp_reg_step()) ? omp_reg_qcols(meas, m) : 0;
     for (int it = 0; it < m; ++it) {                                                             // :16
         // A'*r (:17).  Few right-hand sides per dictionary: the matrix-vector kernel above.  Shared dictionary and many problems:
         // one GEMM with the residuals of all problems as columns.
@@ -614,7 +865,13 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
         else
             JSTSP_TRY(gemm(ctx, 'C', 'N', size_d, 1, meas, batch, Mat{A, strideA, meas},
                            Mat{s.r, (long long)meas, meas}, corr, (long long)size_d, size_d));
-        if (batch <= 64)        // few problems: sixteen waves per problem
+        if (batch <= 64 && meas <= 1024 && omp_reg_step())        // few problems: sixteen waves per problem, w and r in registers
+            hipLaunchKernelGGL(omp_step_reg_kernel<1>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, A, strideA,
+                               (const float2 *)nullptr, 0ll, 0, 0, 0, s, qc);
+        else if (batch <= 64 && meas <= 2048 && omp_reg_step())
+            hipLaunchKernelGGL(omp_step_reg_kernel<2>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, A, strideA,
+                               (const float2 *)nullptr, 0ll, 0, 0, 0, s, qc);
+        else if (batch <= 64)
             hipLaunchKernelGGL(omp_step_kernel<1024>, dim3(batch), dim3(1024), 0, st, meas, size_d, m, it, corr, A, strideA,
                                (const float2 *)nullptr, 0ll, 0, 0, 0, s);
         else
@@ -737,6 +994,7 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
         rmax = ctx->arena.get<uint32_t>(batch);
         JSTSP_REQUIRE(rmax, JSTSP_E_NOMEM, "omp_kron: workspace exhausted");
     }
+    const int qc = (batch <= 64 && meas <= 2048 && omp_reg_step()) ? omp_reg_qcols(meas, m) : 0;
     for (int it = 0; it < m; ++it) {
         // Phi'*r = vec(Af^H R Bf^H) with R = reshape(r, N, M): the correlation kernel of the hot path
         if (h2) {
@@ -749,7 +1007,13 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
                        (long long)ng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
         JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Mat{Af, strideA, N}, Mat{Tc, (long long)ng, N}, corr,
                        (long long)size_d, Gr));
-        if (batch <= 64)
+        if (batch <= 64 && meas <= 1024 && omp_reg_step())
+            hipLaunchKernelGGL(omp_step_reg_kernel<1>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, Af, strideA,
+                           Bf, strideB, N, Gr, G2, s, qc);
+        else if (batch <= 64 && meas <= 2048 && omp_reg_step())
+            hipLaunchKernelGGL(omp_step_reg_kernel<2>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, Af, strideA,
+                           Bf, strideB, N, Gr, G2, s, qc);
+        else if (batch <= 64)
             hipLaunchKernelGGL(omp_step_kernel<1024>, dim3(batch), dim3(1024), 0, st, meas, size_d, m, it, corr, Af, strideA,
                            Bf, strideB, N, Gr, G2, s);
         else

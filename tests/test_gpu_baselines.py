@@ -94,7 +94,11 @@ def test_omp_kron_coefficient_domain_equals_measurement_domain_and_oracle():
 
 
 @pytest.mark.parametrize("meas,size_d,m", [(1024, 1024, 24),     # BASELINE configs[0] dense
-                                           (300, 1500, 12), (1500, 700, 9), (64, 40, 10)])
+                                           (300, 1500, 12), (1500, 700, 9), (64, 40, 10),
+                                           # the register form of the step (omp_step_reg_kernel): two elements per thread with
+                                           # more atoms than LDS columns; more LDS columns than prefetch registers; and a
+                                           # measurement vector too long for it (the global-memory form)
+                                           (1536, 700, 20), (300, 512, 30), (2100, 300, 8)])
 def test_omp_one_problem_sixteen_wave_step_equals_the_batched_four_wave_step_and_oracle(meas, size_d, m):
     """ONE problem (the reference's own case) takes the 1024-thread step kernel, a batch above 64 the 256-thread one (omp.hip:
     classical Gram-Schmidt twice with wave-parallel inner products): the same problem through both and through the float64 oracle -
