@@ -403,6 +403,20 @@ __global__ __launch_bounds__(256) void cgemm_kernel(GemmDesc d, int tiles_m, int
                         v1max = fmaxf(v1max, fmaxf(fabsf(v1.x), fabsf(v1.y)));
                         zmax = fmaxf(zmax, fmaxf(fabsf(zn.x), fabsf(zn.y)));
                         if (d.epi_store_c) Cp[gi + (long long)gj * d.ldc] = o;
+                    } else if (EPI == EPI_SADMM) {
+                        if (d.sa_mode == 1) {
+                            const float den = sadmm_den(d.sa_lr[gi], d.sa_lt[gj], d.sa_rho);
+                            Cp[gi + (long long)gj * d.ldc] = make_float2(o.x / den, o.y / den);
+                        } else {
+                            const float rho = d.sa_rho, ir = 1.f / rho;
+                            float2 z = d.e_rw0[ix];
+                            const float2 sv = d.e_r0[ix], a = d.e_r2[ix];
+                            z = make_float2(sadmm_dual1(z.x, o.x, sv.x, rho), sadmm_dual1(z.y, o.y, sv.y, rho));
+                            d.e_rw0[ix] = z;
+                            const float2 sn = make_float2(sadmm_soft1(o.x, z.x, ir, d.sa_thr), sadmm_soft1(o.y, z.y, ir, d.sa_thr));
+                            d.e_w1[ix] = sn;
+                            d.e_w2[ix] = make_float2(sadmm_rhs1(z.x, sn.x, a.x, rho), sadmm_rhs1(z.y, sn.y, a.y, rho));
+                        }
                     } else {
                         Cp[gi + (long long)gj * d.ldc] = o;
                         tmax = fmaxf(tmax, fmaxf(fabsf(o.x), fabsf(o.y)));
@@ -486,7 +500,7 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     JSTSP_REQUIRE(!d.C_lo || (variant == 2 && d.alpha == 1.f && !d.D), JSTSP_E_ARG, "cgemm: C_lo needs the fp64-master variant, alpha = 1, no D");
     const int bn = variant == 1 ? 128 : 64;
     // 3M where it pays and was validated: the dominant contractions, the Grams, and other products of 256 terms or more
-    const int m3_mink = 256;
+    static const int m3_mink = [] { const char *e = getenv("JSTSP_M3_MINK"); return e ? atoi(e) : 256; }();
     const bool m3 = tag == GEMM_CORRELATE || tag == GEMM_SYNTH || tag == GEMM_GRAM || (tag == GEMM_MISC && kper >= m3_mink);
     const int tiles_n = (d.n + bn - 1) / bn;
     const long long groups = (d.batch + 7) / 8;
@@ -496,6 +510,7 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     if (prof_name) prof_begin(ctx, prof_name);
     if (d.epi == EPI_UPDATE_C) launch_epi<GEMM_SYNTH, EPI_UPDATE_C>(ctx, d, variant == 1, m3, grid, tiles_m, tiles_n);
     else if (d.epi == EPI_UPDATE_X) launch_epi<GEMM_MISC, EPI_UPDATE_X>(ctx, d, variant == 1, false, grid, tiles_m, tiles_n);
+    else if (d.epi == EPI_SADMM) launch_epi<GEMM_MISC, EPI_SADMM>(ctx, d, variant == 1, m3, grid, tiles_m, tiles_n);
     else
     switch (tag) {
     case GEMM_CORRELATE: launch_tagged<GEMM_CORRELATE>(ctx, d, variant, m3, grid, tiles_m, tiles_n); break;

@@ -285,7 +285,21 @@ struct GemmDesc {
     const float2 *D_lo;                     // low-order part of D (same layout): C = alpha acc + beta (D + D_lo); NULL = none
     int herm_upper;                         // the product is Hermitian (a Gram): tiles entirely below the diagonal are skipped, the caller
                                             // mirrors them (hermitian_fill_lower)
+    int sa_mode;                            // EPI_SADMM (below)
+    const float *sa_lr, *sa_lt;
+    float sa_rho, sa_thr;
 };
+// element-wise steps of sparse_admm.m, shared by the stand-alone kernels (sparse_admm.hip) and the EPI_SADMM epilogue so that both
+// round the same way (explicit fmaf: no contraction left to the context)
+__device__ __forceinline__ float sadmm_den(float lr, float lt, float rho) { return fmaf(lr, lt, -rho); }
+__device__ __forceinline__ float sadmm_dual1(float z, float r, float s, float rho) { return fmaf(rho, r - s, z); }          // :30
+__device__ __forceinline__ float sadmm_soft1(float r, float z, float ir, float thr)                                          // :21-22
+{
+    const float v = fmaf(ir, z, r);
+    const float m = fmaxf(fabsf(v) - thr, 0.f);
+    return (v > 0.f) ? m : ((v < 0.f) ? -m : 0.f);
+}
+__device__ __forceinline__ float sadmm_rhs1(float z, float s, float a, float rho) { return fmaf(-rho, s, z) + a; }           // :26
 // The N x M array C of the reference is never stored: with cc = rho/(rho+1), D = X - Xs,
 //   C   = cc (D - V2/rho)                       (proposed_algorithm.m:61)
 //   V2' = V2 + rho (C - D) = (1 - cc)(V2 - rho D) (:65)     and   -C = (cc/rho)(V2 - rho D) = (1 - cc)(V2 - rho D)
@@ -296,7 +310,11 @@ struct GemmDesc {
 //   V1 += rho (Y - X) (:64);  Znext = X - V1/rho (the next iteration's svt argument, :35).
 //   e_rw0 = V1, e_w1 = X, e_w2 = K, e_r0 = V2, e_r2 = Xs, e_r3 = subY, e_f0 = invD, e_w3 = Znext (may be NULL);
 //   Y -> d.C if epi_store_c
-enum { EPI_NONE = 0, EPI_UPDATE_C = 1, EPI_UPDATE_X = 2 };
+// EPI_SADMM (sparse_admm.m:21-30 applied to the accumulator tile; sa_mode selects the step):
+//   1: C = acc ./ (sa_lr[i] sa_lt[j] - sa_rho)                            (the diagonal solve between the two transforms, :26)
+//   2: acc = R (not stored);  Z += rho (R - S) (:30);  S' = soft(R + Z/rho, sa_thr) (:21-22 of the NEXT iteration);
+//      RHS = Z - rho S' + A'vec(OH) (:26).   e_rw0 = Z, e_r0 = S, e_w1 = S', e_r2 = A'vec(OH), e_w2 = RHS
+enum { EPI_NONE = 0, EPI_UPDATE_C = 1, EPI_UPDATE_X = 2, EPI_SADMM = 3 };
 enum { GEMM_MISC = 0, GEMM_CORRELATE = 1, GEMM_SYNTH = 2, GEMM_GRAM = 3 };
 int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag = GEMM_MISC);
 

@@ -157,6 +157,7 @@ GemmDesc make_gemm(char opA, char opB, int m, int n, int k, int batch, Mat A, Ma
     d.epi = EPI_NONE; d.prm = nullptr; d.e_rw0 = d.e_w1 = d.e_w2 = d.e_w3 = nullptr;
     d.e_r0 = d.e_r1 = d.e_r2 = d.e_r3 = nullptr; d.e_f0 = nullptr; d.epi_store_c = 1; d.amax_out = nullptr; d.amax_x = d.amax_v1 = d.amax_z = nullptr;
     d.force_m64 = 0; d.C_lo = nullptr; d.herm_upper = 0; d.D_lo = nullptr;
+    d.sa_mode = 0; d.sa_lr = d.sa_lt = nullptr; d.sa_rho = d.sa_thr = 0.f;
     return d;
 }
 

@@ -12,12 +12,6 @@
 
 namespace jstsp {
 
-__device__ __forceinline__ float soft1s(float v, float t)
-{
-    const float m = fmaxf(fabsf(v) - t, 0.f);
-    return (v > 0.f) ? m : ((v < 0.f) ? -m : 0.f);
-}
-
 // v = R + Z/rho (:21); S = soft(v, tau_s/rho) (:22); RHS = Z - rho S + A'vec(OH) (:26)
 __global__ __launch_bounds__(256) void sadmm_soft_rhs_kernel(long long n, const float2 *R, const float2 *Z,
                                                              const float2 *AhOH, float2 *S, float2 *RHS,
@@ -27,9 +21,9 @@ __global__ __launch_bounds__(256) void sadmm_soft_rhs_kernel(long long n, const 
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float2 r = R[i], z = Z[i], a = AhOH[i];
-        const float2 s = make_float2(soft1s(r.x + ir * z.x, thr), soft1s(r.y + ir * z.y, thr));
+        const float2 s = make_float2(sadmm_soft1(r.x, z.x, ir, thr), sadmm_soft1(r.y, z.y, ir, thr));
         S[i] = s;
-        RHS[i] = make_float2(z.x - rho * s.x + a.x, z.y - rho * s.y + a.y);
+        RHS[i] = make_float2(sadmm_rhs1(z.x, s.x, a.x, rho), sadmm_rhs1(z.y, s.y, a.y, rho));
     }
 }
 
@@ -41,7 +35,7 @@ __global__ __launch_bounds__(256) void sadmm_scale_kernel(long long total, int M
     const long long nm = (long long)Mr * Mt;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
         const long long e = i % nm;
-        const float den = lr[e % Mr] * lt[e / Mr] - rho;
+        const float den = sadmm_den(lr[e % Mr], lt[e / Mr], rho);
         const float2 v = T[i];
         T[i] = make_float2(v.x / den, v.y / den);
     }
@@ -55,8 +49,8 @@ __global__ __launch_bounds__(256) void sadmm_dual_kernel(long long n, float2 *Z,
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         float2 z = Z[i];
         const float2 r = R[i], s = S[i];
-        z.x += rho * (r.x - s.x);
-        z.y += rho * (r.y - s.y);
+        z.x = sadmm_dual1(z.x, r.x, s.x, rho);
+        z.y = sadmm_dual1(z.y, r.y, s.y, rho);
         Z[i] = z;
     }
 }
@@ -153,27 +147,58 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     if (want_ce) JSTSP_TRY(sigma_max_sq(ctx, wn, Htrue, den));
     if (want_ce) JSTSP_TRY(lanczos_warm_reset(ctx, wn));       // the error curve's lambda_max, warm-started from iteration to iteration
 
+    // JSTSP_SADMM_FUSE=0: every element-wise step as its own kernel.  Default: they ride on the products' epilogues (EPI_SADMM,
+    // common.h) - the diagonal solve on the second transform, the dual update AND the next iteration's soft threshold / right-hand
+    // side on the fourth (R itself is then never stored; S alternates between two buffers because convergence_error still reads
+    // this iteration's S), the difference to Htrue on the error product.  Same expressions (sadmm_*1), same bits.
+    const char *fuse_env = getenv("JSTSP_SADMM_FUSE");          // (read at every call)
+    const bool fuse = !fuse_env || atoi(fuse_env) != 0;
+    float2 *Sb[2] = {S, fuse ? R : S};
+    const float2 *Sfin = S;
     for (int it = 0; it < Imax; ++it) {                                            // :18
-        hipLaunchKernelGGL(sadmm_soft_rhs_kernel, g1(tot), dim3(256), 0, st, tot, R, Z, AhOH, S, RHS, rho,
-                           tau_s / rho);                                           // :21-23
-        // :26  R = Ur [ (Ur^H RHS conj(Ut)) ./ (lr lt^T - rho) ] Ut^T
-        JSTSP_TRY(gemm(ctx, 'C', 'N', Mr, Mt, Mr, batch, Urm, Mat{RHS, snm, Mr}, P, snm, Mr));
-        JSTSP_TRY(gemm(ctx, 'N', 'J', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, RHS, snm, Mr));
-        hipLaunchKernelGGL(sadmm_scale_kernel, g1(tot), dim3(256), 0, st, tot, Mr, Mt, RHS, lr, lt, rho);
-        JSTSP_TRY(gemm(ctx, 'N', 'N', Mr, Mt, Mr, batch, Urm, Mat{RHS, snm, Mr}, P, snm, Mr));
-        JSTSP_TRY(gemm(ctx, 'N', 'T', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, R, snm, Mr));
-        hipLaunchKernelGGL(sadmm_dual_kernel, g1(tot), dim3(256), 0, st, tot, Z, R, S, rho);   // :30
+        float2 *Sc = Sb[it & 1], *Sn = Sb[(it + 1) & 1];
+        Sfin = Sc;
+        if (!fuse || it == 0)
+            hipLaunchKernelGGL(sadmm_soft_rhs_kernel, g1(tot), dim3(256), 0, st, tot, R, Z, AhOH, Sc, RHS, rho,
+                               tau_s / rho);                                       // :21-23
+        // (the last iteration's R and Z feed nothing that is returned: S and convergence_error are complete before them)
+        if (!fuse || it + 1 < Imax) {
+            // :26  R = Ur [ (Ur^H RHS conj(Ut)) ./ (lr lt^T - rho) ] Ut^T
+            JSTSP_TRY(gemm(ctx, 'C', 'N', Mr, Mt, Mr, batch, Urm, Mat{RHS, snm, Mr}, P, snm, Mr));
+            if (fuse) {
+                GemmDesc d2 = make_gemm('N', 'J', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, RHS, snm, Mr);
+                d2.epi = EPI_SADMM; d2.sa_mode = 1; d2.sa_lr = lr; d2.sa_lt = lt; d2.sa_rho = rho;
+                JSTSP_TRY(launch_cgemm(ctx, d2, GEMM_MISC));
+            } else {
+                JSTSP_TRY(gemm(ctx, 'N', 'J', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, RHS, snm, Mr));
+                hipLaunchKernelGGL(sadmm_scale_kernel, g1(tot), dim3(256), 0, st, tot, Mr, Mt, RHS, lr, lt, rho);
+            }
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Mr, Mt, Mr, batch, Urm, Mat{RHS, snm, Mr}, P, snm, Mr));
+            if (fuse) {
+                GemmDesc d4 = make_gemm('N', 'T', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, RHS, snm, Mr);   // (C unused: R is not stored)
+                d4.epi = EPI_SADMM; d4.sa_mode = 2; d4.sa_rho = rho; d4.sa_thr = tau_s / rho;
+                d4.e_rw0 = Z; d4.e_r0 = Sc; d4.e_w1 = Sn; d4.e_r2 = AhOH; d4.e_w2 = RHS;
+                JSTSP_TRY(launch_cgemm(ctx, d4, GEMM_MISC));
+            } else {
+                JSTSP_TRY(gemm(ctx, 'N', 'T', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, R, snm, Mr));
+                hipLaunchKernelGGL(sadmm_dual_kernel, g1(tot), dim3(256), 0, st, tot, Z, R, Sc, rho);   // :30
+            }
+        }
         if (want_ce) {                                                             // :32
-            JSTSP_TRY(gemm(ctx, 'N', 'N', Mr, Mt, Mr, batch, Drm, Mat{S, snm, Mr}, P, snm, Mr));
-            JSTSP_TRY(gemm(ctx, 'N', 'C', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Dtm, Dd, snm, Mr));
-            hipLaunchKernelGGL(sadmm_diff_kernel, g1(tot), dim3(256), 0, st, tot, Dd, Htrue, Dd);
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Mr, Mt, Mr, batch, Drm, Mat{Sc, snm, Mr}, P, snm, Mr));
+            if (fuse)
+                JSTSP_TRY(gemm(ctx, 'N', 'C', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Dtm, Dd, snm, Mr, 1.f, Htrue, snm, Mr, -1.f));
+            else {
+                JSTSP_TRY(gemm(ctx, 'N', 'C', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Dtm, Dd, snm, Mr));
+                hipLaunchKernelGGL(sadmm_diff_kernel, g1(tot), dim3(256), 0, st, tot, Dd, Htrue, Dd);
+            }
             JSTSP_TRY(sigma_max_sq(ctx, wn, Dd, num, true));
             hipLaunchKernelGGL(sadmm_ratio_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, num, den, ce,
                                Imax, it);
         }
     }
     JSTSP_HIP(hipGetLastError());
-    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), S, batch * nm, memspace));
+    JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), Sfin, batch * nm, memspace));
     if (want_ce && Imax > 0) JSTSP_TRY(stage_out(ctx, ce_out, ce, (size_t)batch * Imax, memspace));
     if (memspace == JSTSP_HOST) JSTSP_HIP(hipStreamSynchronize(st));
     return 0;

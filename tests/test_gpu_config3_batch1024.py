@@ -84,3 +84,28 @@ def test_sparse_admm_1024_trials(cfg3):
         So, ceo = O.sparse_admm(_h(cfg3["H"], t), _h(cfg3["OH"], t), D, D, Imax)
         assert _rel(_h(S, t), So) < 2e-4
         np.testing.assert_allclose(ce[t].cpu().numpy(), ceo, rtol=5e-3)
+
+
+def test_sparse_admm_fused_epilogues_equal_the_separate_kernels_bit_for_bit(cfg3):
+    """The element-wise steps of sparse_admm.m:21-30 ride on the products' epilogues by default (EPI_SADMM, cgemm.hip);
+    JSTSP_SADMM_FUSE=0 runs them as their own kernels.  Same expressions, so the same bits - S and convergence_error, with an even
+    and an odd iteration count (S alternates between two buffers), with and without the error curve, and Imax = 1 (no product
+    of the last iteration is needed at all)."""
+    import os
+    import torch
+    import jstsp19_amd as J
+    H, OH, D = cfg3["H"][:48], cfg3["OH"][:48], cfg3["D"]
+    old = os.environ.get("JSTSP_SADMM_FUSE")
+    try:
+        for Imax in (1, 6, 7):
+            os.environ["JSTSP_SADMM_FUSE"] = "1"
+            S1, ce1 = J.sparse_admm(H, OH, D, D, Imax)
+            os.environ["JSTSP_SADMM_FUSE"] = "0"
+            S0, ce0 = J.sparse_admm(H, OH, D, D, Imax)
+            assert torch.equal(torch.view_as_real(S1), torch.view_as_real(S0))
+            assert torch.equal(ce1, ce0)
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_SADMM_FUSE", None)
+        else:
+            os.environ["JSTSP_SADMM_FUSE"] = old
