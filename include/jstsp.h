@@ -116,6 +116,12 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         8 trials x 4-8 column tiles share an XCD's L2 at a time - same bits, -8 % at configs[4] batch 32)
  *   JSTSP_OMP_REG=0       OMP of up to 64 problems keeps the candidate atom and the residual in global memory (default 1: in
  *                         registers / LDS for measurement vectors of up to 2048 entries, with the first basis columns in LDS)
+ *   JSTSP_SADMM_FUSE=0    sparse_admm: every element-wise step of sparse_admm.m:21-30 as its own kernel (default 1: on the products'
+ *                         epilogues - same bits)
+ *   JSTSP_SADMM_OVERLAP=0 sparse_admm: the convergence_error chain in line with the solve (default 1: on a side stream beside the
+ *                         next iteration - same bits)
+ *   JSTSP_M3_MINK=n       fp32-MFMA products of n terms or more take Gauss' three-multiplication form (default 256; 128 is 7 %
+ *                         faster for sparse_admm at 128 x 128 and 2.5 times less accurate in the worst entry)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous
  *                         iteration's Ritz vector)

@@ -96,7 +96,7 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     const float rho = 0.01f, tau_s = 0.0001f;                                 // :12-13
     const int ner = (Mr + 1) & ~1, net = (Mt + 1) & ~1;
 
-    size_t need = 7 * rnd256(batch * nm * sizeof(float2)) + 2 * rnd256((size_t)Mr * Mr * sizeof(float2)) +
+    size_t need = (want_ce ? 8 : 7) * rnd256(batch * nm * sizeof(float2)) + 2 * rnd256((size_t)Mr * Mr * sizeof(float2)) +
                   2 * rnd256((size_t)Mt * Mt * sizeof(float2)) + rnd256(Mr * sizeof(float)) +
                   rnd256(Mt * sizeof(float)) + rnd256((size_t)ner * ner * sizeof(float2)) +
                   rnd256((size_t)net * net * sizeof(float2)) + 2 * rnd256(batch * sizeof(float)) +
@@ -126,6 +126,8 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     JSTSP_REQUIRE(R && Z && S && RHS && P && AhOH && Dd && Gr_ && Ur && Gt_ && Ut && lr && lt && Vgr && Vgt &&
                       num && den && ce,
                   JSTSP_E_NOMEM, "sparse_admm: workspace exhausted");
+    float2 *P2 = want_ce ? a.get<float2>(batch * nm) : nullptr;        // the error chain's own temporary (it runs beside the solve)
+    JSTSP_REQUIRE(!want_ce || P2, JSTSP_E_NOMEM, "sparse_admm: workspace exhausted");
     GramWS wn;
     if (want_ce) JSTSP_TRY(wn.alloc(a, Mr, Mt, batch, false));
     hipStream_t st = ctx->stream;
@@ -155,12 +157,31 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     const bool fuse = !fuse_env || atoi(fuse_env) != 0;
     float2 *Sb[2] = {S, fuse ? R : S};
     const float2 *Sfin = S;
+    // convergence_error of iteration it needs S(it) only, the solve goes on from S(it) without it: with the fused epilogues (two
+    // S buffers) the error chain - two products, the Gram, lambda_max - runs on a side stream beside the next solve
+    // (JSTSP_SADMM_OVERLAP=0: in line).  ev_s[it & 1]: S(it) is complete; ev_r[it & 1]: the error chain has read S(it), whose
+    // buffer the epilogue of iteration it + 1 overwrites.
+    const char *ov_env = getenv("JSTSP_SADMM_OVERLAP");
+    const bool overlap = fuse && want_ce && (!ov_env || atoi(ov_env) != 0);
+    if (overlap) JSTSP_TRY(ensure_side_streams(ctx));
+    hipStream_t sc = overlap ? ctx->side[0] : st;
+    hipEvent_t ev_s[2] = {ctx->ev[0], ctx->ev[1]}, ev_r[2] = {ctx->ev[2], ctx->ev[3]};
     for (int it = 0; it < Imax; ++it) {                                            // :18
         float2 *Sc = Sb[it & 1], *Sn = Sb[(it + 1) & 1];
         Sfin = Sc;
         if (!fuse || it == 0)
             hipLaunchKernelGGL(sadmm_soft_rhs_kernel, g1(tot), dim3(256), 0, st, tot, R, Z, AhOH, Sc, RHS, rho,
                                tau_s / rho);                                       // :21-23
+        if (overlap) {
+            if (it == 0) JSTSP_HIP(hipEventRecord(ev_s[0], st));
+            JSTSP_HIP(hipStreamWaitEvent(sc, ev_s[it & 1], 0));
+            StreamScope scope(ctx, sc);
+            JSTSP_TRY(gemm(ctx, 'N', 'N', Mr, Mt, Mr, batch, Drm, Mat{Sc, snm, Mr}, P2, snm, Mr));
+            JSTSP_HIP(hipEventRecord(ev_r[it & 1], sc));
+            JSTSP_TRY(gemm(ctx, 'N', 'C', Mr, Mt, Mt, batch, Mat{P2, snm, Mr}, Dtm, Dd, snm, Mr, 1.f, Htrue, snm, Mr, -1.f));
+            JSTSP_TRY(sigma_max_sq(ctx, wn, Dd, num, true));
+            hipLaunchKernelGGL(sadmm_ratio_kernel, dim3((batch + 255) / 256), dim3(256), 0, sc, batch, num, den, ce, Imax, it);
+        }
         // (the last iteration's R and Z feed nothing that is returned: S and convergence_error are complete before them)
         if (!fuse || it + 1 < Imax) {
             // :26  R = Ur [ (Ur^H RHS conj(Ut)) ./ (lr lt^T - rho) ] Ut^T
@@ -178,13 +199,15 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
                 GemmDesc d4 = make_gemm('N', 'T', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, RHS, snm, Mr);   // (C unused: R is not stored)
                 d4.epi = EPI_SADMM; d4.sa_mode = 2; d4.sa_rho = rho; d4.sa_thr = tau_s / rho;
                 d4.e_rw0 = Z; d4.e_r0 = Sc; d4.e_w1 = Sn; d4.e_r2 = AhOH; d4.e_w2 = RHS;
+                if (overlap && it > 0) JSTSP_HIP(hipStreamWaitEvent(st, ev_r[(it + 1) & 1], 0));    // S(it - 1) has been read
                 JSTSP_TRY(launch_cgemm(ctx, d4, GEMM_MISC));
+                if (overlap) JSTSP_HIP(hipEventRecord(ev_s[(it + 1) & 1], st));
             } else {
                 JSTSP_TRY(gemm(ctx, 'N', 'T', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Utm, R, snm, Mr));
                 hipLaunchKernelGGL(sadmm_dual_kernel, g1(tot), dim3(256), 0, st, tot, Z, R, Sc, rho);   // :30
             }
         }
-        if (want_ce) {                                                             // :32
+        if (want_ce && !overlap) {                                                 // :32
             JSTSP_TRY(gemm(ctx, 'N', 'N', Mr, Mt, Mr, batch, Drm, Mat{Sc, snm, Mr}, P, snm, Mr));
             if (fuse)
                 JSTSP_TRY(gemm(ctx, 'N', 'C', Mr, Mt, Mt, batch, Mat{P, snm, Mr}, Dtm, Dd, snm, Mr, 1.f, Htrue, snm, Mr, -1.f));
@@ -196,6 +219,10 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
             hipLaunchKernelGGL(sadmm_ratio_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, num, den, ce,
                                Imax, it);
         }
+    }
+    if (overlap && Imax > 0) {          // the error chain joins the main stream
+        JSTSP_HIP(hipEventRecord(ev_r[0], sc));
+        JSTSP_HIP(hipStreamWaitEvent(st, ev_r[0], 0));
     }
     JSTSP_HIP(hipGetLastError());
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), Sfin, batch * nm, memspace));

@@ -99,12 +99,18 @@ def test_sparse_admm_fused_epilogues_equal_the_separate_kernels_bit_for_bit(cfg3
     try:
         for Imax in (1, 6, 7):
             os.environ["JSTSP_SADMM_FUSE"] = "1"
-            S1, ce1 = J.sparse_admm(H, OH, D, D, Imax)
+            S1, ce1 = J.sparse_admm(H, OH, D, D, Imax)                      # (error chain on the side stream: the default)
+            os.environ["JSTSP_SADMM_OVERLAP"] = "0"
+            S2, ce2 = J.sparse_admm(H, OH, D, D, Imax)
+            os.environ.pop("JSTSP_SADMM_OVERLAP")
+            S3, _ = J.sparse_admm(None, OH, D, D, Imax, want_ce=False)
             os.environ["JSTSP_SADMM_FUSE"] = "0"
             S0, ce0 = J.sparse_admm(H, OH, D, D, Imax)
-            assert torch.equal(torch.view_as_real(S1), torch.view_as_real(S0))
-            assert torch.equal(ce1, ce0)
+            for S in (S1, S2, S3):
+                assert torch.equal(torch.view_as_real(S), torch.view_as_real(S0))
+            assert torch.equal(ce1, ce0) and torch.equal(ce2, ce0)
     finally:
+        os.environ.pop("JSTSP_SADMM_OVERLAP", None)
         if old is None:
             os.environ.pop("JSTSP_SADMM_FUSE", None)
         else:
