@@ -393,7 +393,7 @@ int launch_eig_fast(jstsp_ctx *ctx, int mode, int n, int batch, const float2 *Gp
 // Orders 65..128 (eig3.hip): G in LDS, eigenvector basis in registers as a systolic array; SVT projector only.
 int launch_eig128(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
                   const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm = nullptr, int warm = 0,
-                  int max_sweeps = 16);
+                  int max_sweeps = 16, float stop_level = 0.f);     // stop_level: see GramWS::eig_stop
 int eig_fast_ne(int n);           // padded order (32 or 64) of the warm-start basis
 // Warm-start record of the Lanczos lambda_max kernel (eig2.hip): per matrix the Ritz vector of the previous call.
 struct LanczosWarm {

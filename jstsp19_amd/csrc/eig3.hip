@@ -36,7 +36,7 @@ template <int CTRL> __device__ __forceinline__ float dpp(float x)
 
 __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
                                                         const TrialParams *prm, const float *tau, float2 *Q, float conv_tol,
-                                                        int max_sweeps, int *sweep_stat, float2 *Uwarm, int warm)
+                                                        int max_sweeps, int *sweep_stat, float2 *Uwarm, int warm, float pre_tol)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float2 *G = reinterpret_cast<float2 *>(smem_raw);           // [NE][LD] column-major; later U [NE][NE]
@@ -110,6 +110,31 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
 
     int sweeps_done = 0;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        // The rule at the end of a sweep knows the level the sweep STARTED from, so it confirms convergence with one sweep more
+        // than the result needs (a sweep that starts below 1e-4 leaves 1e-8).  One pass over the off-diagonal entries (a
+        // hundredth of a sweep) measures the matrix AS IT STANDS: below pre_tol no further sweep is run (GramWS::eig_stop: the
+        // warm-started calls of mc_svt / mc_admm, one sweep instead of two).
+        if (pre_tol > 0.f) {
+            if (tid == 0) red[0] = 0.f;
+            __syncthreads();
+            float cw = 0.f;
+            for (int e = tid; e < NE * NE; e += NT) {
+                const int p = e % NE, q = e / NE;
+                if (p >= q) continue;
+                const float a = G[p + LD * p].x, dd = G[q + LD * q].x;
+                const float2 bq = G[p + LD * q];
+                const float ab = sqrtf(bq.x * bq.x + bq.y * bq.y);
+                const float scale = sqrtf(fabsf(a) * fabsf(dd));
+                if (ab > 0.f && ab > 1e-8f * scale) cw = fmaxf(cw, ab / fmaxf(scale, 1e-3f * dmax));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cw = fmaxf(cw, __shfl_xor(cw, o));
+            if ((tid & 63) == 0) atomicMax(reinterpret_cast<int *>(&red[0]), __float_as_int(cw));
+            __syncthreads();
+            const float w0 = red[0];
+            __syncthreads();
+            if (w0 < pre_tol) break;
+        }
         ++sweeps_done;
         if (tid == 0) red[0] = 0.f;
         float worst = 0.f;
@@ -265,16 +290,17 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
 // Q: nullptr = basis only (Uwarm required).  Uwarm: nullptr, or batch * n*n float2 that receives the eigenvector basis; warm != 0: Uwarm holds the basis of the
 // previous call AND the caller has already transformed the Gram to that basis (G <- Uw^H G Uw).
 int launch_eig128(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs,
-                  const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm, int warm, int max_sweeps)
+                  const TrialParams *prm, const float *tau, float2 *Q, float2 *Uwarm, int warm, int max_sweeps, float stop_level)
 {
     JSTSP_REQUIRE(n > 64 && n <= 128, JSTSP_E_UNSUPPORTED, "launch_eig128: n = %d outside (64, 128]", n);
     JSTSP_REQUIRE(Q || Uwarm, JSTSP_E_ARG, "launch_eig128: neither a projector nor a basis requested");
     const size_t sh = (size_t)NE * LD * sizeof(float2) + (size_t)(4 * H + 24 + NE) * sizeof(float);
     JSTSP_HIP(hipFuncSetAttribute((const void *)jacobi128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
     const float tol = 1e-4f;
+    const float pre_tol = stop_level;       // level of the matrix as it stands below which no further sweep is run (0: off)
     const int maxsw = max_sweeps < 1 ? 1 : (max_sweeps > 16 ? 16 : max_sweeps);
     hipLaunchKernelGGL(jacobi128_kernel, dim3(batch), dim3(NT), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs, prm, tau, Q,
-                       tol, maxsw, (int *)nullptr, Uwarm, warm);
+                       tol, maxsw, (int *)nullptr, Uwarm, warm, pre_tol);
     JSTSP_HIP(hipGetLastError());
     return 0;
 }

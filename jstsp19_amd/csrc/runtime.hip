@@ -318,7 +318,7 @@ int svt_prepare(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, const TrialPar
             JSTSP_TRY(gemm(ctx, 'C', 'N', w.n, w.n, w.n, w.batch, Um, Mat{w.Twarm, sG, w.n}, w.Gpart, sG, w.n));
         }
         JSTSP_TRY(launch_eig128(ctx, w.n, w.batch, w.Gpart, sG * w.nsplit, w.nsplit, sG, prm, tau, w.Q,
-                                sequence ? w.Uwarm : nullptr, warm));
+                                sequence ? w.Uwarm : nullptr, warm, 16, warm ? w.eig_stop : 0.f));
         w.warm = sequence ? 1 : 0;
         return 0;
     }

@@ -49,6 +49,10 @@ struct GramWS {
     float2 *Uwarm = nullptr;   // eigenvector basis of the previous call (warm start): NE x NE padded for n <= 64, n x n above
     float2 *Twarm = nullptr;   // n > 64: temporary of the warm-start transform G <- Uw^H (G Uw)
     mutable int warm = 0;      // 1 once Uwarm holds a basis
+    // Orders 65..128, warm-started sequences only: no (further) Jacobi sweep is run once the Gram in the previous basis has all
+    // relative off-diagonals |g_pq| / sqrt(g_pp g_qq) below this level (0: the end-of-sweep rule alone, which confirms convergence
+    // with a sweep that starts below 1e-4).  An inexact inner solve for the fixed-point loops that can take it (mc_svt, mc_admm).
+    float eig_stop = 0.f;
     mutable LanczosWarm lz;    // norm workspaces (need_q == false, n <= 128): warm-start record of the Lanczos lambda_max kernel
     static size_t bytes(int rows, int cols, int batch, bool need_q, int force_nsplit = 0);
     int alloc(Arena &a, int rows, int cols, int batch, bool need_q, int force_nsplit = 0);

@@ -115,3 +115,37 @@ def test_sparse_admm_fused_epilogues_equal_the_separate_kernels_bit_for_bit(cfg3
             os.environ.pop("JSTSP_SADMM_FUSE", None)
         else:
             os.environ["JSTSP_SADMM_FUSE"] = old
+
+
+def test_mc_svt_and_mc_admm_inexact_inner_eigensolve_against_the_converged_one(cfg3):
+    """mc_svt / mc_admm stop the warm-started eigen-decomposition of an iteration once the Gram in the previous iteration's basis
+    has relative off-diagonals below 1e-4 (JSTSP_MC_EIG_STOP, api_misc.hip); 0 converges every call.  Both against the float64
+    oracle on the same trials, and against each other."""
+    import os
+    import torch
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    tau, rho = np.full(64, 0.05), np.full(64, 0.1)
+    OmOH, Om, H = cfg3["OmOH"][:64], cfg3["Om"][:64], cfg3["H"][:64]
+    old = os.environ.get("JSTSP_MC_EIG_STOP")
+    try:
+        res = {}
+        for lvl in ("0", "1e-4"):
+            os.environ["JSTSP_MC_EIG_STOP"] = lvl
+            res[lvl] = (J.mc_svt(OmOH, Om, 20, tau, rho), J.mc_admm(H, OmOH, Om, 20, tau, rho))
+        for t in (0, 17, 63):
+            oh, om = _h(OmOH, t), _h(Om, t, np.float64)
+            sc = float(np.max(np.abs(oh)))
+            Xs = O.mc_svt(oh, om, 20, 0.05, 0.1)
+            Xo, ceo = O.mc_admm(_h(H, t), oh, om, 20, 0.05, 0.1)
+            for lvl in res:
+                assert _rel(_h(res[lvl][0], t), Xs, sc) < 2e-4
+                assert _rel(_h(res[lvl][1][0], t), Xo, sc) < 2e-4
+                np.testing.assert_allclose(res[lvl][1][1][t].cpu().numpy(), ceo, rtol=5e-3)
+        d = torch.max(torch.abs(res["0"][0] - res["1e-4"][0])) / torch.max(torch.abs(OmOH))
+        assert float(d) < 1e-4
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_MC_EIG_STOP", None)
+        else:
+            os.environ["JSTSP_MC_EIG_STOP"] = old

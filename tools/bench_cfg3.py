@@ -19,6 +19,7 @@ Om = (torch.rand(batch, n, n, generator=g, device=dev) < 0.125).float()
 cm = J.colmajor
 for name, fn in [("svt", lambda: J.svt(cm(OH), np.full(batch, 1.0))),
                  ("mc_svt x20", lambda: J.mc_svt(cm(Om * OH), cm(Om), 20, np.full(batch, 0.5), np.full(batch, 0.1))),
+                 ("mc_admm x20", lambda: J.mc_admm(cm(H), cm(Om * OH), cm(Om), 20, np.full(batch, 0.5), np.full(batch, 0.1))),
                  ("sparse_admm x100", lambda: J.sparse_admm(cm(H), cm(OH), cm(D), cm(D), 100))]:
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0

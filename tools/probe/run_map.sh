@@ -1,5 +1,4 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-python3 -m pytest tests -m gpu -q -x -k "sparse_admm or config3" 2>&1 | tail -5
-for f in 0 1; do echo "== OVERLAP=$f"; JSTSP_SADMM_OVERLAP=$f python3 tools/bench_cfg3.py 1024 2>&1 | tail -1; JSTSP_SADMM_OVERLAP=$f python3 tools/bench_cfg3.py 256 2>&1 | tail -1;  done
+for k in 1 0; do echo "== J128_ORDER=$k"; JSTSP_J128_ORDER=$k python3 tools/probe/svt128_err.py 2>&1 | tail -1; JSTSP_J128_ORDER=$k python3 tools/bench_cfg3.py 1024 2>&1 | tail -4 | head -3; done
