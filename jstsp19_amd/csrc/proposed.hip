@@ -8,9 +8,21 @@
 // All problems of the batch advance together; every step below is one kernel launch over
 // the whole batch on the context's stream.
 #include "solver_common.h"
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <algorithm>
+
+// JSTSP_HOST_TRACE=1: wall-clock marks of the JSTSP_HOST path on stderr (ms since the first mark of the process)
+static void host_trace(const char *what, int k = -1)
+{
+    static const bool on = [] { const char *e = getenv("JSTSP_HOST_TRACE"); return e && atoi(e) != 0; }();
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[jstsp host] %9.2f ms  %s%s\n", ms, what, k == 0 ? " (half 0)" : (k == 1 ? " (half 1)" : ""));
+}
 
 namespace jstsp {
 
@@ -214,9 +226,11 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const float2 *subY, *A, *B;
     const float *Omega;
     const int32_t *indx_S = nullptr;
+    if (memspace == JSTSP_HOST) host_trace("stage: begin");
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(subY_), batch * nm, memspace, &subY));
     JSTSP_TRY(stage_in(ctx, Omega_, batch * nm, memspace, &Omega));
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(A_), szA, memspace, &A));
+    if (memspace == JSTSP_HOST) host_trace("stage: subY, Omega, A issued");
     int known_gt = ctx->dict_block_hint;        // (a caller that expanded a block-Toeplitz dictionary itself: c64.hip)
     ctx->dict_block_hint = 0;
     if (host_compact) {
@@ -228,6 +242,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     } else
     JSTSP_TRY(stage_in(ctx, reinterpret_cast<const float2 *>(B_), szB, memspace, &B));
     if (angles) JSTSP_TRY(stage_in(ctx, indx_S_, batch * g, memspace, &indx_S));
+    if (memspace == JSTSP_HOST) host_trace("stage: dictionary issued");
     if (memspace == JSTSP_DEVICE)
         JSTSP_REQUIRE(((uintptr_t)subY % 16 == 0) && ((uintptr_t)Omega % 8 == 0), JSTSP_E_ARG,
                       "device arrays must be 16-byte aligned");
@@ -781,12 +796,15 @@ static int resolve_overflowed(jstsp_ctx *ctx, const std::vector<int> &ovf, int N
 static int proposed_finish(jstsp_ctx *ctx, const PendingSolve &p, jstsp_c32 *S_out, jstsp_c32 *Y_out, double *ce_out, std::vector<int> *ovf)
 {
     JSTSP_ENTER(ctx);
+    host_trace("finish: begin");
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(S_out), p.dS, p.batch * p.g, JSTSP_HOST));
     JSTSP_TRY(stage_out(ctx, reinterpret_cast<float2 *>(Y_out), p.dY, p.batch * p.nm, JSTSP_HOST));
     if (p.want_ce) JSTSP_TRY(stage_out(ctx, ce_out, p.dce, (size_t)p.batch * 3 * p.Imax, JSTSP_HOST));
     std::vector<uint32_t> flags(p.ovf ? p.batch : 0);
     if (p.ovf) JSTSP_HIP(hipMemcpyAsync(flags.data(), p.ovf, (size_t)p.batch * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    host_trace("finish: copies issued");
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    host_trace("finish: synchronised");
     for (int t = 0; t < (int)flags.size(); ++t)
         if (flags[t]) ovf->push_back(t);
     return 0;
@@ -825,12 +843,14 @@ extern "C" int jstsp_proposed_algorithm_c32(jstsp_ctx *ctx, int N, int M, int Gr
         };
 #define JSTSP_TRY_PIPE(expr) do { int rc_ = drained(expr); if (rc_ != 0) return rc_; } while (0)
         for (int k = 0; k < 2; ++k) {
+            host_trace("enqueue", k);
             cx[k]->fused_fallbacks = 0; cx[k]->last_dict_block = 0;
             JSTSP_TRY_PIPE(proposed_impl(cx[k], N, M, Gr, G2, cnt[k], subY + t0[k] * nm, Omega + t0[k] * nm, A + (size_t)t0[k] * strideA, strideA,
                                     B + (size_t)t0[k] * strideB, strideB, Imax, tau_Y + t0[k], tau_S + t0[k], rho + t0[k], type,
                                     indx_S ? indx_S + t0[k] * g : nullptr, S_out + t0[k] * g, Y_out + t0[k] * nm,
                                     ce_out ? ce_out + (size_t)t0[k] * 3 * Imax : nullptr, JSTSP_HOST, true, nullptr, &pend[k]));
         }
+        host_trace("both halves enqueued");
         int fallbacks = 0;
         for (int k = 0; k < 2; ++k) {
             std::vector<int> o;
@@ -951,7 +971,9 @@ int proposed_pending_flags(jstsp_ctx *ctx, const PendingSolve &p, std::vector<in
     JSTSP_ENTER(ctx);
     std::vector<uint32_t> flags(p.ovf ? p.batch : 0);
     if (p.ovf) JSTSP_HIP(hipMemcpyAsync(flags.data(), p.ovf, (size_t)p.batch * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    host_trace("finish: copies issued");
     JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    host_trace("finish: synchronised");
     for (int t = 0; t < (int)flags.size(); ++t)
         if (flags[t]) ovf->push_back(t);
     return 0;
