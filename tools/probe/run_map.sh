@@ -1,4 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-for k in 1 0; do echo "== J128_ORDER=$k"; JSTSP_J128_ORDER=$k python3 tools/probe/svt128_err.py 2>&1 | tail -1; JSTSP_J128_ORDER=$k python3 tools/bench_cfg3.py 1024 2>&1 | tail -4 | head -3; done
+python3 tools/parity_fixture_check.py --group sweep_proposed "" "JSTSP_RV_COMP=1,JSTSP_RV_REFRESH=1000" "JSTSP_RV_COMP=1" "JSTSP_RV_COMP=1,JSTSP_RV_REFRESH=8" 2>&1 | grep -v amdgpu | cut -c1-330
+python3 tools/parity_fixture_check.py --group bench_proposed "" "JSTSP_RV_COMP=1,JSTSP_RV_REFRESH=1000" 2>&1 | grep -v amdgpu | cut -c1-330
+for v in "" "JSTSP_RV_COMP=1 JSTSP_RV_REFRESH=1000"; do env $v python3 bench.py --steps 3 --warmup 1 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['parity'].get('whole_batch'))"; done
