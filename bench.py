@@ -35,6 +35,11 @@ if ROOT not in sys.path:
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 HBM_PEAK_GBS = 8000.0              # same guide: HBM3E peak (6.3 TB/s measured achievable)
 MFMA_F16_PEAK_TFLOPS = 2500.0      # same guide: dense BF16/FP16 MFMA peak (2495 TF measured with 32x32x16)
+# What the f16 pipe SUSTAINS with nothing but MFMAs in flight and uniform-random operands in registers (tools/ubench/mfma_f16_rate.cpp,
+# profiles/r05b_mfma_f16_rate.txt: v_mfma_f32_16x16x32_f16, 8 accumulators, two waves per SIMD on all 256 CUs): 1592 TFLOP/s -
+# 1996 on zero operands, 2476 for 32x32x16 on zeros (the nominal peak), 1635 for 32x32x16 on random data.  Reported beside the
+# nominal roof, never instead of it.
+MFMA_F16_SUSTAINED_TFLOPS = 1592.0
 IMAX = 100
 
 
@@ -398,6 +403,10 @@ def main():
         mfma_flop = 3.0 * (2 * flops_per_launch + 8.0 * N * N * M * a.batch)
         mfma = {"executed_tflops": round(mfma_flop / (avg_f * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TFLOPS,
                 "frac": round(mfma_flop / (avg_f * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                "sustained_on_random_operands": {"tflops": MFMA_F16_SUSTAINED_TFLOPS,
+                                                 "frac": round(mfma_flop / (avg_f * 1e-3) / 1e12 / MFMA_F16_SUSTAINED_TFLOPS, 4),
+                                                 "source": "tools/ubench/mfma_f16_rate.cpp (profiles/r05b_mfma_f16_rate.txt): the same "
+                                                           "instruction alone, operands in registers, uniform-random f16 data; 1996 on zeros"},
                 "note": "v_mfma_f32_16x16x32_f16, split-f16 (three products per fp32-equivalent one); dense f16 peak of "
                         "MI355X_MICROARCH.md"}
         # what the reference's algorithm moves per iteration in this formulation: the whole dictionary once (8 B per complex
@@ -422,7 +431,8 @@ def main():
             # the kernel sits between its two roofs (both within a factor 3): report the nearer one as `bound`, the other beside it
             if mfma["frac"] >= hbm["frac"]:
                 roofline = {"bound": "mfma", "kernel": kname, "achieved": mfma["executed_tflops"], "peak": MFMA_F16_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": mfma["frac"], "hbm": hbm}
+                            "unit": "TFLOP/s", "frac": mfma["frac"], "sustained_on_random_operands": mfma["sustained_on_random_operands"],
+                            "hbm": hbm}
             else:
                 roofline = {"bound": "hbm", "kernel": kname, **hbm, "mfma": mfma}
             roofline.update({"traffic": traffic_of("fused_pass64"), "avg_launch_ms": round(avg_f, 4), "launches": n_f,
