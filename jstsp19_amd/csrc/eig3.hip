@@ -108,6 +108,20 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
         bot[k] = (warm && Uw && ur < n && cb < n) ? Uw[ur + (size_t)n * cb] : make_float2(ur == cb ? 1.f : 0.f, 0.f);
     }
 
+    // this thread's blocks (a <= b) of the G update: item k of the 2080 upper-triangle slot pairs, k = tid, tid + 1024, tid + 2048
+    int wa[3], wb[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int k = tid + NT * it;
+        wa[it] = -1; wb[it] = -1;
+        if (k < H * (H + 1) / 2) {
+            // column b holds b + 1 items (a = 0..b): the largest b with b (b + 1) / 2 <= k
+            int b = (int)((sqrtf(8.f * (float)k + 1.f) - 1.f) * 0.5f);
+            while (b * (b + 1) / 2 > k) --b;
+            while ((b + 1) * (b + 2) / 2 <= k) ++b;
+            wa[it] = k - b * (b + 1) / 2; wb[it] = b;
+        }
+    }
     int sweeps_done = 0;
     for (int sweep = 0; sweep < max_sweeps; ++sweep) {
         // The rule at the end of a sweep knows the level the sweep STARTED from, so it confirms convergence with one sweep more
@@ -161,38 +175,44 @@ __global__ __launch_bounds__(NT) void jacobi128_kernel(int n, const float2 *Gpar
                 rot[4 * tid + 3] = __int_as_float(p | (q << 8) | ((a0 < b0 ? 1 : 0) << 16));
             }
             __syncthreads();
-            // -- G <- J^H G J on 2x2 blocks (pair a rows, pair b columns), four blocks per thread
+            // -- G <- J^H G J on 2x2 blocks (pair a rows, pair b columns).  G stays Hermitian, so only the blocks with a <= b are
+            //    computed (2080 of 4096: two or three per thread, their slot pairs fixed for the whole kernel: wa[], wb[]) and
+            //    block (b, a) is written as the conjugate transpose of block (a, b) - half the rotation arithmetic of a round
+            //    (the kernel is bound by VALU issue, HISTORY.md round 5) and G exactly Hermitian at every step.
 #pragma unroll
-            for (int it = 0; it < (H * H) / NT; ++it) {
-                const int blk = tid + NT * it;
-                const int a = blk % H, b = blk / H;
+            for (int it = 0; it < 3; ++it) {
+                const int a = wa[it], b = wb[it];
+                if (a < 0) continue;
                 const float4 ra = *reinterpret_cast<const float4 *>(&rot[4 * a]);
                 const float4 rb = *reinterpret_cast<const float4 *>(&rot[4 * b]);
                 const int pa = __float_as_int(ra.w) & 0xff, qa = (__float_as_int(ra.w) >> 8) & 0xff;
                 const int pb = __float_as_int(rb.w) & 0xff, qb = (__float_as_int(rb.w) >> 8) & 0xff;
                 const float ca = ra.x, cb = rb.x;
-                const float2 wa = make_float2(ra.y, ra.z), wb = make_float2(rb.y, rb.z);
+                const float2 wa_ = make_float2(ra.y, ra.z), wb_ = make_float2(rb.y, rb.z);
                 const bool ida = (ra.y == 0.f && ra.z == 0.f), idb = (rb.y == 0.f && rb.z == 0.f);
                 if (ida && idb) continue;
                 float2 gpp = G[pa + LD * pb], gpq = G[pa + LD * qb];
                 float2 gqp = G[qa + LD * pb], gqq = G[qa + LD * qb];
                 // right: [x_p, x_q] -> [c x_p - conj(w) x_q, w x_p + c x_q]   (columns pb, qb)
-                float2 t0 = cmulc(wb, gpq), t1 = cmul(wb, gpp);
+                float2 t0 = cmulc(wb_, gpq), t1 = cmul(wb_, gpp);
                 float2 n_pp = make_float2(cb * gpp.x - t0.x, cb * gpp.y - t0.y);
                 float2 n_pq = make_float2(t1.x + cb * gpq.x, t1.y + cb * gpq.y);
-                t0 = cmulc(wb, gqq); t1 = cmul(wb, gqp);
+                t0 = cmulc(wb_, gqq); t1 = cmul(wb_, gqp);
                 float2 n_qp = make_float2(cb * gqp.x - t0.x, cb * gqp.y - t0.y);
                 float2 n_qq = make_float2(t1.x + cb * gqq.x, t1.y + cb * gqq.y);
                 // left: [y_p; y_q] -> [c y_p - w y_q; conj(w) y_p + c y_q]     (rows pa, qa)
-                t0 = cmul(wa, n_qp); t1 = cmulc(wa, n_pp);
+                t0 = cmul(wa_, n_qp); t1 = cmulc(wa_, n_pp);
                 gpp = make_float2(ca * n_pp.x - t0.x, ca * n_pp.y - t0.y);
                 gqp = make_float2(t1.x + ca * n_qp.x, t1.y + ca * n_qp.y);
-                t0 = cmul(wa, n_qq); t1 = cmulc(wa, n_pq);
+                t0 = cmul(wa_, n_qq); t1 = cmulc(wa_, n_pq);
                 gpq = make_float2(ca * n_pq.x - t0.x, ca * n_pq.y - t0.y);
                 gqq = make_float2(t1.x + ca * n_qq.x, t1.y + ca * n_qq.y);
                 if (a == b) {           // the annihilated block: exact zeros off the diagonal, real diagonal
                     gpq = make_float2(0.f, 0.f); gqp = make_float2(0.f, 0.f);
                     gpp.y = 0.f; gqq.y = 0.f;
+                } else {                // block (b, a) = (block (a, b))^H
+                    G[pb + LD * pa] = make_float2(gpp.x, -gpp.y); G[qb + LD * pa] = make_float2(gpq.x, -gpq.y);
+                    G[pb + LD * qa] = make_float2(gqp.x, -gqp.y); G[qb + LD * qa] = make_float2(gqq.x, -gqq.y);
                 }
                 G[pa + LD * pb] = gpp; G[pa + LD * qb] = gpq;
                 G[qa + LD * pb] = gqp; G[qa + LD * qb] = gqq;

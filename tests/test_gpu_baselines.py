@@ -275,7 +275,10 @@ def test_vamp_dense_at_the_drivers_size_is_the_unchanged_call():
         assert e_lit < tol and e_kron < 2 * tol, (nit, t, e_lit, e_kron)
     # single (2-D) call == the batched call's first problem; 100 iterations: finite, same quality as the factored form
     x1 = np.asarray(J.vamp(y[0], Phi[0], 1.0, numOfnz, nit=5))
-    assert rel_err(x1, np.asarray(J.vamp(y, Phi, 1.0, numOfnz, nit=5))[0]) < 1e-5
+    # (not bit-equal: in a batch the order-512 block Jacobi groups its 128-column panels over the problems, so all but the last
+    #  problem of a batch see another order of fp32 rotations than the same problem alone - measured 6e-6 ... 1.1e-5 after
+    #  five VAMP iterations, 0 for the last problem; both are deterministic)
+    assert rel_err(x1, np.asarray(J.vamp(y, Phi, 1.0, numOfnz, nit=5))[0]) < 3e-5
     xd = np.asarray(J.vamp(y, Phi, 1.0, numOfnz))
     assert np.all(np.isfinite(xd))
     zb = inp["Zbar"].cpu().numpy()
