@@ -1069,7 +1069,8 @@ int hermitian_fill_lower(jstsp_ctx *ctx, float2 *G, long long sGt, int n, int co
 // grid of a launch under the block map chosen for it (conc = workgroups one XCD holds at a time)
 static long long hgemm_grid(HGemmDesc &d, long long tiles, int conc)
 {
-    static const int map_on = [] { const char *e = getenv("JSTSP_HGEMM_MAP"); return e ? atoi(e) : 1; }();
+    const char *map_env = getenv("JSTSP_HGEMM_MAP");       // (read at every launch: the tests switch it)
+    const int map_on = map_env ? atoi(map_env) : 1;
     d.map_tb = d.map_tt = 0;
     if (map_on && d.sPt == 0 && d.batch >= 2 && tiles >= 2) {
         // (measured at configs[4], batch 32: 2 ... 32 trials per block and half / twice as many workgroups per block are within

@@ -471,3 +471,37 @@ def test_baselines2_fixture_through_the_c_abi():
                             int(g["K_t"]))
     assert rel_err(Ysvt, g["Y_svt"]) < 2e-4 and rel_err(St, g["S_tssr"]) < 2e-3 and rel_err(Ssvt, g["S_svt"]) < 2e-3
     assert abs(J.rate(g["S_r"], g["Zbar_r"], float(g["noise_var"])) - float(g["rate"])) < 2e-4
+
+
+def test_sparse_admm_rectangular_fused_epilogues_and_oracle():
+    """sparse_admm with Mr != Mt (the diagonal solve indexes lr by row and lt by column in the EPI_SADMM epilogue) and an odd
+    batch: fused epilogues + side-stream error chain == separate kernels bit for bit, and both against the float64 oracle."""
+    import os
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(404)
+    Mr, Mt, batch, Imax = 96, 40, 5, 9
+    c = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    dft = lambda n: np.exp(-2j * np.pi * np.outer(np.arange(n), np.arange(n)) / n) / np.sqrt(n)
+    Dr, Dt = dft(Mr), dft(Mt)                                   # (unitary dictionaries: the iteration is stable)
+    S0 = np.zeros((batch, Mr, Mt), complex)
+    for t in range(batch):
+        S0[t].reshape(-1)[rng.choice(Mr * Mt, 12, replace=False)] = c(12)
+    H = np.stack([Dr @ S0[t] @ Dt.conj().T for t in range(batch)])
+    OH = H + 0.02 * c(batch, Mr, Mt)
+    old = os.environ.get("JSTSP_SADMM_FUSE")
+    try:
+        os.environ["JSTSP_SADMM_FUSE"] = "1"
+        S1, ce1 = J.sparse_admm(H, OH, Dr, Dt, Imax)
+        os.environ["JSTSP_SADMM_FUSE"] = "0"
+        S0_, ce0 = J.sparse_admm(H, OH, Dr, Dt, Imax)
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_SADMM_FUSE", None)
+        else:
+            os.environ["JSTSP_SADMM_FUSE"] = old
+    assert np.asarray(S1).tobytes() == np.asarray(S0_).tobytes() and np.asarray(ce1).tobytes() == np.asarray(ce0).tobytes()
+    for t in range(batch):
+        So, ceo = O.sparse_admm(H[t], OH[t], Dr, Dt, Imax)
+        assert rel_err(np.asarray(S1)[t], So) < 2e-4
+        np.testing.assert_allclose(np.asarray(ce1)[t], ceo, rtol=5e-3)

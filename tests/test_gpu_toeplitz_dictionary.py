@@ -280,3 +280,19 @@ def test_host_side_compaction_is_bit_identical_and_falls_back_on_the_first_misma
     r3, gt3 = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "0"}, B=B2, c64=c64)
     assert gt2 == 0 and gt3 == 0
     _same(r2, r3)
+
+
+@pytest.mark.parametrize("Nt,L,T,batch", [(64, 8, 16, 5),     # G2 = 512, M = 1024: 8 / 16 column tiles, 5 trials (one ragged block)
+                                          (64, 8, 16, 13),    # 13 trials: two blocks of 8, the second ragged
+                                          (32, 12, 24, 3)])   # G2 = 384: fewer tiles than a block holds
+def test_shared_dictionary_block_map_of_the_split_f16_products_is_bit_identical(Nt, L, T, batch):
+    """One dictionary for all trials: the split-f16 products (hgemm.hip) hand an XCD blocks of 8 trials x 4-8 column tiles at a
+    time, so that the trials of a tile share the dictionary panel in L2 (block_to_trial_tile); JSTSP_HGEMM_MAP=0 keeps the
+    per-trial order.  Only the order of the workgroups differs: the same bits, on the three-kernel iteration (JSTSP_FUSED=0)
+    and on the default path, at batch sizes that leave ragged blocks."""
+    from jstsp19_amd.system_model import build_trials
+    sh = build_trials(_params(Nt, L, T), 0, batch, seed=11, shared_pilots=True)
+    for extra in ({"JSTSP_FUSED": "0"}, {}):
+        r1, _, _ = _solve(sh, 6, dict(extra), B=sh["B"][0])
+        r0, _, _ = _solve(sh, 6, dict(extra, JSTSP_HGEMM_MAP="0"), B=sh["B"][0])
+        _same(r1, r0)
