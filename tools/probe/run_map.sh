@@ -1,5 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-python3 -m pytest tests -m gpu -q -k "config3 or mc_ or svt or large_orders or kernels or vamp or eig or mex" 2>&1 | tail -4
-bash tools/prof_cmd.sh r05b_cfg3 tools/bench_cfg3.py 1024 | tail -12
+JSTSP_KPACK=0 python3 tools/probe/cfg5_angles.py 32 2>&1 | tail -2
+JSTSP_KPACK=1 python3 tools/probe/cfg5_angles.py 32 2>&1 | tail -2
+JSTSP_KPACK=1 bash tools/prof_cmd.sh r05c_cfg5_kpack tools/probe/cfg5_angles.py 32 | tail -7 | cut -c1-150
