@@ -120,13 +120,13 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         epilogues - same bits)
  *   JSTSP_SADMM_OVERLAP=0 sparse_admm: the convergence_error chain in line with the solve (default 1: on a side stream beside the
  *                         next iteration - same bits)
- *   JSTSP_M3_MINK=n       fp32-MFMA products of n terms or more take Gauss' three-multiplication form (default 256; 128 is 7 %
+ *   JSTSP_M3_MINK=n       (read once per process) fp32-MFMA products of n terms or more take Gauss' three-multiplication form (default 256; 128 is 7 %
  *                         faster for sparse_admm at 128 x 128 and 2.5 times less accurate in the worst entry)
  *   JSTSP_MC_EIG_STOP=x   mc_svt / mc_admm, matrices of order 65..128: the eigen-decomposition of iteration i starts from the basis of
  *                         iteration i - 1 and runs no further Jacobi sweep once the Gram in that basis has relative off-diagonals
  *                         below x (default 1e-4: an inexact inner solve, error against the float64 oracle unchanged at 5e-5 /
  *                         9e-5 after 20 iterations, mc_svt 1.7 times faster; 0: every call converged)
- *   JSTSP_HOST_TRACE=1    wall-clock marks of a JSTSP_HOST proposed_algorithm call on stderr (staging, enqueue, copies back)
+ *   JSTSP_HOST_TRACE=1    (read once per process) wall-clock marks of a JSTSP_HOST proposed_algorithm call on stderr (staging, enqueue, copies back)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous
  *                         iteration's Ritz vector)

@@ -562,8 +562,8 @@ __global__ __launch_bounds__(1024) void omp_step_reg_kernel(int meas, int size_d
 // JSTSP_OMP_REG=0: the step through global memory (omp_step_kernel<1024>) also where the register form applies
 static bool omp_reg_step()
 {
-    static const bool on = [] { const char *e = getenv("JSTSP_OMP_REG"); return !e || atoi(e) != 0; }();
-    return on;
+    const char *e = getenv("JSTSP_OMP_REG");        // (read at every call)
+    return !e || atoi(e) != 0;
 }
 
 // basis columns omp_step_reg_kernel keeps in LDS: what 160 KiB leave beside its static arrays (inner products 16 KiB, w 8 EPT KiB)
@@ -852,7 +852,8 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
     JSTSP_HIP(hipMemcpyAsync(s.r, v, (size_t)batch * meas * sizeof(float2), hipMemcpyDeviceToDevice, st));   // r = v (:10)
     JSTSP_HIP(hipMemsetAsync(s.nu, 0, batch * sizeof(int), st));
     JSTSP_HIP(hipMemsetAsync(s.Rm, 0, (size_t)batch * m * m * sizeof(float2), st));
-    const int qc = (batch <= 64 && meas <= 2048 && omp_reg_step()) ? omp_reg_qcols(meas, m) : 0;
+    const bool reg_step = batch <= 64 && meas <= 2048 && omp_reg_step();
+    const int qc = reg_step ? omp_reg_qcols(meas, m) : 0;
     for (int it = 0; it < m; ++it) {                                                             // :16
         // A'*r (:17).  Few right-hand sides per dictionary: the matrix-vector kernel above.  Shared dictionary and many problems:
         // one GEMM with the residuals of all problems as columns.
@@ -865,10 +866,10 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
         else
             JSTSP_TRY(gemm(ctx, 'C', 'N', size_d, 1, meas, batch, Mat{A, strideA, meas},
                            Mat{s.r, (long long)meas, meas}, corr, (long long)size_d, size_d));
-        if (batch <= 64 && meas <= 1024 && omp_reg_step())        // few problems: sixteen waves per problem, w and r in registers
+        if (reg_step && meas <= 1024)        // few problems: sixteen waves per problem, w and r in registers
             hipLaunchKernelGGL(omp_step_reg_kernel<1>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, A, strideA,
                                (const float2 *)nullptr, 0ll, 0, 0, 0, s, qc);
-        else if (batch <= 64 && meas <= 2048 && omp_reg_step())
+        else if (reg_step)
             hipLaunchKernelGGL(omp_step_reg_kernel<2>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, A, strideA,
                                (const float2 *)nullptr, 0ll, 0, 0, 0, s, qc);
         else if (batch <= 64)
@@ -994,7 +995,8 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
         rmax = ctx->arena.get<uint32_t>(batch);
         JSTSP_REQUIRE(rmax, JSTSP_E_NOMEM, "omp_kron: workspace exhausted");
     }
-    const int qc = (batch <= 64 && meas <= 2048 && omp_reg_step()) ? omp_reg_qcols(meas, m) : 0;
+    const bool reg_step = batch <= 64 && meas <= 2048 && omp_reg_step();
+    const int qc = reg_step ? omp_reg_qcols(meas, m) : 0;
     for (int it = 0; it < m; ++it) {
         // Phi'*r = vec(Af^H R Bf^H) with R = reshape(r, N, M): the correlation kernel of the hot path
         if (h2) {
@@ -1007,10 +1009,10 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
                        (long long)ng, N, 1.f, nullptr, 0, 0, 0.f, GEMM_CORRELATE));
         JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, N, batch, Mat{Af, strideA, N}, Mat{Tc, (long long)ng, N}, corr,
                        (long long)size_d, Gr));
-        if (batch <= 64 && meas <= 1024 && omp_reg_step())
+        if (reg_step && meas <= 1024)
             hipLaunchKernelGGL(omp_step_reg_kernel<1>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, Af, strideA,
                            Bf, strideB, N, Gr, G2, s, qc);
-        else if (batch <= 64 && meas <= 2048 && omp_reg_step())
+        else if (reg_step)
             hipLaunchKernelGGL(omp_step_reg_kernel<2>, dim3(batch), dim3(1024), (size_t)qc * meas * sizeof(float2), st, meas, size_d, m, it, corr, Af, strideA,
                            Bf, strideB, N, Gr, G2, s, qc);
         else if (batch <= 64)

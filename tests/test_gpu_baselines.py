@@ -505,3 +505,32 @@ def test_sparse_admm_rectangular_fused_epilogues_and_oracle():
         So, ceo = O.sparse_admm(H[t], OH[t], Dr, Dt, Imax)
         assert rel_err(np.asarray(S1)[t], So) < 2e-4
         np.testing.assert_allclose(np.asarray(ce1)[t], ceo, rtol=5e-3)
+
+
+@pytest.mark.parametrize("meas,size_d,m,batch", [(1024, 1024, 24, 1), (1536, 700, 20, 3), (300, 512, 30, 5)])
+def test_omp_register_step_against_the_global_memory_step(meas, size_d, m, batch):
+    """JSTSP_OMP_REG=0 runs the Gram-Schmidt step of few problems through global memory (omp_step_kernel<1024>), the default keeps
+    the candidate atom and the residual in registers and the first basis columns in LDS (omp_step_reg_kernel): the same atoms in
+    the same order, coefficients equal to fp32 rounding (the compiler contracts the two updates differently)."""
+    import os
+    import jstsp19_amd as J
+    rng = np.random.default_rng(meas + m)
+    c = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    A = (c(meas, size_d) / np.sqrt(meas)).astype(np.complex64)
+    x0 = np.zeros((batch, size_d), complex)
+    for t in range(batch):
+        x0[t, rng.choice(size_d, 6, replace=False)] = c(6)
+    v = (x0 @ A.T + 0.01 * c(batch, meas)).astype(np.complex64)
+    old = os.environ.get("JSTSP_OMP_REG")
+    try:
+        os.environ["JSTSP_OMP_REG"] = "1"
+        x1, i1, _, T1 = J.OMP(A, v, m)
+        os.environ["JSTSP_OMP_REG"] = "0"
+        x0_, i0, _, T0 = J.OMP(A, v, m)
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_OMP_REG", None)
+        else:
+            os.environ["JSTSP_OMP_REG"] = old
+    assert np.array_equal(i1, i0) and np.asarray(T1).tobytes() == np.asarray(T0).tobytes()
+    assert rel_err(x1, x0_) < 2e-6
