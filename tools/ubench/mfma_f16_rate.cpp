@@ -47,6 +47,27 @@ __global__ __launch_bounds__(256) void k(const half8 *ops, float *out, int iters
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// 16x16x32 with 16 accumulators (is the one-wave-per-SIMD rate of VAR 1 a dependency limit?)
+__global__ __launch_bounds__(256) void k16(const half8 *ops, float *out, int iters)
+{
+    const int tid = threadIdx.x;
+    half8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = ops[(i * 256 + tid) % 2048]; b[i] = ops[((i + 4) * 256 + tid) % 2048]; }
+    f32x4 c[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c[q] = f32x4{0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) c[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[(u + q) & 3], a[q & 3], c[q], 0, 0, 0);
+    }
+    float s = 0;
+    for (int q = 0; q < 16; ++q) s += c[q][0] + c[q][1] + c[q][2] + c[q][3];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int VAR> void run(const char *name, const half8 *ops, int blocks, double flop_per_iter)
 {
     float *out;
@@ -82,6 +103,16 @@ int main()
         for (int blocks : {256, 512}) {
             run<0>("v_mfma_f32_32x32x16_f16, 4 acc", ops, blocks, 16.0 * 2 * 32 * 32 * 16);
             run<1>("v_mfma_f32_16x16x32_f16, 8 acc", ops, blocks, 32.0 * 2 * 16 * 16 * 32);
+            {
+                float *out; hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                k16<<<blocks, 256>>>(ops, out, 100); hipDeviceSynchronize();
+                hipEventRecord(e0); k16<<<blocks, 256>>>(ops, out, 20000); hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                printf("  %-34s %d waves/SIMD  %8.3f ms  %7.1f TFLOP/s\n", "v_mfma_f32_16x16x32_f16, 16 acc", blocks / 256, ms,
+                       (double)blocks * 4 * 20000 * 32.0 * 2 * 16 * 16 * 32 / ms / 1e9);
+                hipFree(out);
+            }
         }
     }
     return 0;
