@@ -126,6 +126,8 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         iteration i - 1 and runs no further Jacobi sweep once the Gram in that basis has relative off-diagonals
  *                         below x (default 1e-4: an inexact inner solve, error against the float64 oracle unchanged at 5e-5 /
  *                         9e-5 after 20 iterations, mc_svt 1.7 times faster; 0: every call converged)
+ *   JSTSP_HOST_THREADS=n  host threads of the block-Toeplitz test of a JSTSP_HOST dictionary (default: half the hardware threads within the
+ *                         cgroup quota, at most 16)
  *   JSTSP_HOST_TRACE=1    (read once per process) wall-clock marks of a JSTSP_HOST proposed_algorithm call on stderr (staging, enqueue, copies back)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous

@@ -78,3 +78,17 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
         for op in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
             assert op not in asm, "%s found in %s" % (op, f)
     assert mfma >= 5        # the disassembly really is the kernels'
+
+
+def test_every_environment_switch_the_library_reads_is_documented_in_the_header():
+    """include/jstsp.h lists the JSTSP_* switches (tuning knobs and A/B switches of the kernels): every name that appears in a
+    getenv / env_int call of jstsp19_amd/csrc must appear there (JSTSP_FUSED_DBG exists in debug builds of fused.hip only)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "jstsp19_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "jstsp19_amd", "csrc", "*.h")):
+        names |= set(re.findall(r'(?:getenv|env_int|env_flt)\("(JSTSP_[A-Z0-9_]+)"', open(f).read()))
+    header = open(os.path.join(root, "include", "jstsp.h")).read()
+    missing = sorted(n for n in names if n not in header and n != "JSTSP_FUSED_DBG")
+    assert len(names) > 20 and not missing, missing
