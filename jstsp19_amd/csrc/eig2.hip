@@ -551,6 +551,10 @@ __global__ __launch_bounds__(256) void lmax_kernel(int n, const float2 *Gpart, l
 // NW waves per matrix (4: lowest latency - the default of rounds 1-2; 1: no exchange, no barrier, no redundant reductions -
 // a quarter of the instructions per matrix at four times the latency)
 constexpr int LZ_KMAX = 12, LZ_KMIN = 3;
+// Order 128 (sparse_admm's and mc_admm's error curves): 4 % of the warm attempts did not reach the residual in 12 steps and
+// fell back to the cold 128-step run - 40 of the 1024 workgroups of a launch, which then lasts as long as they do (0.60 ms
+// against 4.0 steps per matrix on average).  More room for the warm attempt there.
+template <int NE> struct LzKmax { static constexpr int value = NE > 64 ? 32 : LZ_KMAX; };
 
 __device__ __forceinline__ float lz_guard(float d) { return fabsf(d) < 1e-30f ? (d < 0.f ? -1e-30f : 1e-30f) : d; }
 
@@ -720,7 +724,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void lanczos_lmax_kernel(int n, const
         }
         float beta = 0.f, scale = 0.f;
         m = 0;
-        const int jmax = (phase == 0) ? min(LZ_KMAX, n) : (phase == 2 ? mcold : n);
+        const int jmax = (phase == 0) ? min(LzKmax<NE>::value, n) : (phase == 2 ? mcold : n);
         __syncthreads();                    // the LDS words of the previous phase are free (and sy of phase 1 is visible)
         for (int j = 0; j < jmax; ++j) {
             if (phase == 0 && wave == 0) {
@@ -999,7 +1003,7 @@ static int launch_lanczos_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpar
 {
     // exchange, flags, T, firsts, y + the two pivot arrays of the twisted factorisation, 4 scalars, start-up vectors
     const size_t sh = (size_t)2 * NW * NE * sizeof(float2) + 16 + (size_t)2 * NE * sizeof(float) + 12 * sizeof(int) +
-                      (size_t)3 * NE * sizeof(float) + 16 + (size_t)LZ_KMAX * NE * sizeof(float2);
+                      (size_t)3 * NE * sizeof(float) + 16 + (size_t)LzKmax<NE>::value * NE * sizeof(float2);
     JSTSP_HIP(hipFuncSetAttribute((const void *)lanczos_lmax_kernel<NE, NW, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh));
     const bool warm = lw && lw->x && lw->ne == NE && tune().lanczos_warm != 0;
