@@ -305,20 +305,36 @@ def main():
     import jstsp19_amd as J
     ctx = J.default_context(local)
     extra = {}
-    # Informational, NOT the headline: the same step with the opt-in short-cut JSTSP_SVT_SKIP=1 (a trial whose svt threshold
-    # is below 2^-27 max|Z| - every entry of Z - svt(Z, tau) is bounded by tau, so Y = Z is the fp32 answer - skips its
-    # eigen-decomposition; at this workload that is every trial from the second iteration on).  The headline keeps the full
-    # SVT work of the reference algorithm.
-    if not a.small and world == 1:
-        os.environ["JSTSP_SVT_SKIP"] = "1"
-        try:
-            step(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            step(); torch.cuda.synchronize()
-            extra["opt_in_svt_shortcut"] = {"value": round(a.batch / (time.perf_counter() - t1), 1), "unit": "channel-estimates/s",
-                                            "env": "JSTSP_SVT_SKIP=1", "note": "informational; not used for any other field"}
-        finally:
-            os.environ.pop("JSTSP_SVT_SKIP", None)
+    # ---- the metric as SURVEY section 8(d) / BASELINE.md section 3 item 4 define it: solves / wall time of the WHOLE Monte-Carlo
+    # step - fresh trials built on the device every step (plot_errorVSsnr.m:57-136: channel, pilots, measurement, hyper-
+    # parameters), the solve (:137), the spectral NMSE (:138-141) and the estimate S copied to the host.  The headline `value`
+    # above re-solves resident inputs (the contract of this file: inputs in HBM when the timed region starts); `host_path`
+    # below is the third variant (host arrays in and out through PCIe, what a MEX call pays).
+    e2e_steps = max(1, min(a.steps, 5))
+    def e2e_step(k):
+        ids_k = list(range((world * (1 + k) + rank) * a.batch, (world * (1 + k) + rank + 1) * a.batch))      # never the resident batch's ids
+        inp_k = hooks.make_inputs(p, ids_k, device, a.shared_pilots)
+        S_k, _, _ = hooks.solve(inp_k, IMAX, want_ce)
+        nm_k = hooks.nmse(S_k, inp_k)
+        return S_k.cpu(), float(nm_k.sum().item())          # D2H of S (and of the NMSE sum): both synchronise
+    e2e_step(0)                                              # (first build: its kernels and workspace)
+    hooks.sync(); barrier(); hooks.sync()
+    t1 = time.perf_counter()
+    e2e_nmse = 0.0
+    for k in range(e2e_steps):
+        e2e_nmse += e2e_step(1 + k)[1]
+    hooks.sync(); barrier(); hooks.sync()
+    e2e_dt = time.perf_counter() - t1
+    tm2 = torch.tensor([e2e_dt], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+    e2e_dt = float(tm2.item())
+    extra["end_to_end"] = {"value": round(a.batch * world * e2e_steps / e2e_dt, 3), "unit": "channel-estimates/s", "steps": e2e_steps,
+                           "ms_per_step": round(e2e_dt / e2e_steps * 1e3, 3), "mean_nmse_rank0": e2e_nmse / (a.batch * e2e_steps),
+                           "includes": "jstsp_build_trials_c32 (fresh trial ids every step) + proposed_algorithm (Imax=%d, %s) + "
+                                       "nmse_spectral + D2H of S" % (IMAX, "three outputs" if want_ce else "two outputs"),
+                           "note": "SURVEY section 8(d)'s definition of the metric (the whole Monte-Carlo step); the headline `value` "
+                                   "re-solves inputs that are already resident in HBM"}
 
     # Informational: the same step on the strict complex-fp32 MFMA path (v_mfma_f32_32x32x2_f32 everywhere, JSTSP_H2=0) - what
     # BASELINE.json's north_star literally names.  The headline runs the big contractions as split-f16 MFMA with fp32

@@ -78,9 +78,12 @@ const char *jstsp_version(void);
 size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
 
 /* ---- Environment ----------------------------------------------------------------------
- * The library reads these variables and no others.  All are diagnostic or opt-in; every one is parsed ONCE at the entry of
- * each API call (none is latched for the process), so a setting may differ from call to call and is constant within one.
- * Unset = the default, which is the path every reported number and every parity statement refers to.
+ * The shipped library reads the 15 variables below and no others.  All are diagnostic, resource or A/B switches whose every
+ * setting stays inside the accuracy statement ("Accuracy" below); each is parsed ONCE at the entry of each API call (none is
+ * latched for the process, except JSTSP_HOST_THREADS which is read when a host dictionary is staged), so a setting may differ from
+ * call to call and is constant within one.  Unset = the default, which is the path every reported number and every parity
+ * statement refers to.  Every one is toggled by a test of tests/ that asserts the contract (tests/test_capi_symbols.py checks
+ * this list against the sources and against the tests).
  *   JSTSP_H2=0            strict complex-fp32 MFMA (v_mfma_f32_32x32x2_f32) for every contraction; default 1: contractions of
  *                         at least 2^22 complex MACs per problem run as split-f16 MFMA with fp32 accumulation (fp32-equivalent,
  *                         see "Accuracy" below); 2: split-f16 whatever the size
@@ -90,55 +93,34 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  *                         that forces the per-trial re-solve, jstsp_last_fused_fallbacks)
  *   JSTSP_TOEPLITZ=0|1    0: the dictionary is not probed for block-Toeplitz structure; 1: probed, compact image with the
  *                         general pass kernel only; default 2: block height 64 also takes the window kernel
- *   JSTSP_GRAM_REFINE=0   proposed_algorithm 'approximate': the Grams A'*A, B*B' as plain fp32-accuracy products without low-order
- *                         parts (round 3; measured rms |dNMSE| 3.9e-7, max 1.95e-6 - outside the accuracy statement).  Default 1:
- *                         both Grams in float64, kept as two floats, the low-order parts applied whenever R*v is recomputed
- *   JSTSP_RV_REFRESH=n    proposed_algorithm 'approximate': R*v recomputed from v every n iterations (default 4; 1 = always);
- *   JSTSP_RV_ALWAYS=n     ... and in each of the first n iterations (default 0)
- *   JSTSP_RV_COMP=1       opt-in: v and R*v carried as two floats each (compensated accumulation); with JSTSP_RV_REFRESH=1000 (R*v
- *                         never recomputed) +4 % at rms |dNMSE| 2.0e-7, but one bench trial at 1.2e-6: outside the accuracy statement
- *   JSTSP_GRAD_HEAD=3     opt-in: the 64-term products of the gradient step on the f16 pipe in one launch (jstsp_gradient_head_c32);
- *                         faster (+2 %) and individually more accurate, but measured WORSE against float64 (rms 2.2e-7 vs 1.7e-7)
- *   JSTSP_OVERLAP=0|1     side streams between the kernels of an iteration (default: on with the one-pass kernel)
- *   JSTSP_SVT_SKIP=1      opt-in: a trial whose svt threshold is below 2^-27 max|Z| skips its eigen-decomposition (Y = Z is
- *                         then the fp32 answer); never used for a reported number
+ *   JSTSP_OVERLAP=0|1     side streams between the kernels of an iteration (default: on with the one-pass kernel; same bits)
  *   JSTSP_HOST_PIPELINE=0 a JSTSP_HOST proposed_algorithm call of 128 or more problems as ONE staged solve (default: its two halves on
- *                         two internal contexts, the upload of the second overlapping the solve of the first)
- *   JSTSP_PASS_ACC=0      window pass: every product of K B^H accumulates straight into the 32-tile running sums (rounds 2-4;
- *                         default 1: the six products of a tile's block are summed first, the running sum rounded once per tile:
- *                         1.0e-7 less rms |dNMSE| for +3 % kernel time)
- *   JSTSP_INV2=0          the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (default 1: formed in the pass from
- *                         Omega as two floats)
+ *                         two internal contexts, the upload of the second overlapping the solve of the first; same bits)
  *   JSTSP_HOST_COMPACT=0  a JSTSP_HOST dictionary is uploaded whole (default 1: per-trial dictionaries of 64 MiB or more are tested
  *                         for the block-Toeplitz structure on the host while they are staged and uploaded as first block +
  *                         leading columns - bit-identical results; 2: at any size)
- *   JSTSP_HGEMM_MAP=0     split-f16 products with one dictionary for all trials keep the per-trial workgroup order (default 1:
- *                         8 trials x 4-8 column tiles share an XCD's L2 at a time - same bits, -8 % at configs[4] batch 32)
- *   JSTSP_OMP_REG=0       OMP of up to 64 problems keeps the candidate atom and the residual in global memory (default 1: in
- *                         registers / LDS for measurement vectors of up to 2048 entries, with the first basis columns in LDS)
- *   JSTSP_SADMM_FUSE=0    sparse_admm: every element-wise step of sparse_admm.m:21-30 as its own kernel (default 1: on the products'
- *                         epilogues - same bits)
- *   JSTSP_SADMM_OVERLAP=0 sparse_admm: the convergence_error chain in line with the solve (default 1: on a side stream beside the
- *                         next iteration - same bits)
- *   JSTSP_M3_MINK=n       (read once per process) fp32-MFMA products of n terms or more take Gauss' three-multiplication form (default 256; 128 is 7 %
- *                         faster for sparse_admm at 128 x 128 and 2.5 times less accurate in the worst entry)
+ *   JSTSP_HOST_THREADS=n  host threads of that test (default: half the hardware threads within the cgroup quota, at most 16)
  *   JSTSP_MC_EIG_STOP=x   mc_svt / mc_admm, matrices of order 65..128: the eigen-decomposition of iteration i starts from the basis of
  *                         iteration i - 1 and runs no further Jacobi sweep once the Gram in that basis has relative off-diagonals
  *                         below x (default 1e-4: an inexact inner solve, error against the float64 oracle unchanged at 5e-5 /
  *                         9e-5 after 20 iterations, mc_svt 1.7 times faster; 0: every call converged)
- *   JSTSP_HOST_THREADS=n  host threads of the block-Toeplitz test of a JSTSP_HOST dictionary (default: half the hardware threads within the
- *                         cgroup quota, at most 16)
- *   JSTSP_HOST_TRACE=1    (read once per process) wall-clock marks of a JSTSP_HOST proposed_algorithm call on stderr (staging, enqueue, copies back)
  *   JSTSP_LANCZOS=0       Householder + Sturm instead of Lanczos for the spectral norms of convergence_error
  *   JSTSP_LANCZOS_WARM=0  every lambda_max of an ADMM loop by the cold n-step Lanczos run (no warm start from the previous
  *                         iteration's Ritz vector)
  *   JSTSP_LANCZOS_VERIFY=n  a warm-started lambda_max is checked against the cold run every n-th call (default 32;
  *                         0 never, 1 always - then every returned value is the cold one; jstsp_last_lanczos_mismatches)
  *   JSTSP_EIG128=0        general Jacobi kernel (basis in HBM) for Gram orders 65..128
- *   JSTSP_OMP_GRAM=0      jstsp_omp_kron: measurement-space OMP instead of the coefficient-domain kernel
  *   JSTSP_BJ_MASK=0       block Jacobi (orders above 128) without streams restricted to a subset of the compute units
- *   JSTSP_BJ_TRACE=1      print the block Jacobi's convergence (orders above 128) per sweep to stderr
- * (JSTSP_DEVICE=<id> is read by the MEX gateway, not by the library.) */
+ * (JSTSP_DEVICE=<id> is read by the MEX gateway, not by the library.)
+ *
+ * Experiments build.  The opt-in paths that rounds 2-5 measured and dropped, and every switch with a setting that leaves the
+ * accuracy statement, are NOT in the shipped library since round 6: their settings are compile-time constants there
+ * (csrc/common.h, JSTSP_XP) and the variables are not read.  `JSTSP_EXPERIMENTS=1 python jstsp19_amd/build.py` builds
+ * libjstsp_mi355x_xp.so (loaded by the Python binding under JSTSP_EXPERIMENTS_LIB=1; tools/ only, never a reported number), in
+ * which they are read again; HISTORY.md has what each one measured:
+ *   JSTSP_GRAM_REFINE JSTSP_RV_REFRESH JSTSP_RV_ALWAYS JSTSP_RV_COMP JSTSP_GRAD_HEAD JSTSP_SVT_SKIP JSTSP_PASS_ACC JSTSP_INV2
+ *   JSTSP_HGEMM_MAP JSTSP_OMP_REG JSTSP_OMP_GRAM JSTSP_SADMM_FUSE JSTSP_SADMM_OVERLAP JSTSP_M3_MINK JSTSP_HOST_TRACE JSTSP_BJ_TRACE
+ * (and JSTSP_FUSED_DBG in a -DJSTSP_FUSED_DBG_BUILD build of fused.hip: timing experiments, results wrong). */
 
 /* ---- kernel-level entry points (the north-star correlation / synthesis) ------------ */
 
@@ -256,8 +238,10 @@ int jstsp_last_fused_fallbacks(jstsp_ctx *ctx, int *count);
  * lambda_max of each Gram is computed by a Lanczos run that starts from the Ritz vector of the SAME matrix one iteration
  * earlier and stops when the residual of the Ritz pair is below 1e-5 lambda (a cold n-step run otherwise, and always at the
  * first iteration).  Every JSTSP_LANCZOS_VERIFY-th call (default 32) the cold run is done as well, for all matrices of the
- * call, and its value returned; *count = how many of those checks of the last solve on this context differed from
- * the warm-started value by more than 2e-5 relative (0 on every input measured so far; one stream synchronisation). */
+ * call, and its value returned; *count = how many of those checks differed from the warm-started value by more than 2e-5
+ * relative in ALL solves on this context since the previous call of this function (the counter is cumulative and cleared by the
+ * read: a re-solve of overflowed trials, the chunks of a sweep and both halves of a pipelined JSTSP_HOST call are covered;
+ * 0 on every input measured so far; one stream synchronisation). */
 int jstsp_last_lanczos_mismatches(jstsp_ctx *ctx, int *count);
 
 /* lambda_max of a sequence of batches of Hermitian matrices (n <= 128): G is [steps][batch][n*n] column-major, lam is

@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libjstsp_mi355x.so")
+# JSTSP_EXPERIMENTS_LIB=1 (tools/ only): the -DJSTSP_EXPERIMENTS build (JSTSP_EXPERIMENTS=1 python jstsp19_amd/build.py), in which the
+# switches of dropped experiments are still read from the environment (csrc/common.h)
+LIB_PATH = os.path.join(_HERE, "csrc", "libjstsp_mi355x_xp.so" if os.environ.get("JSTSP_EXPERIMENTS_LIB") == "1"
+                        else "libjstsp_mi355x.so")
 
 HOST, DEVICE = 0, 1
 TYPE_APPROXIMATE, TYPE_STD = 0, 1

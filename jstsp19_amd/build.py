@@ -11,7 +11,10 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(CSRC, "libjstsp_mi355x.so")
+# JSTSP_EXPERIMENTS=1: the experiments build (csrc/common.h: the switches of dropped experiments are read from the environment);
+# its objects and library carry the suffix _xp and never replace the shipped ones
+XP = os.environ.get("JSTSP_EXPERIMENTS") == "1"
+LIB = os.path.join(CSRC, "libjstsp_mi355x_xp.so" if XP else "libjstsp_mi355x.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -packed-fp32-ops: no v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 in the device code.  Measured on MI355X (round 2):
 # v_pk_fma_f32 with op_sel operand selection - what hipcc emits for complex multiplies - returns different bits from
@@ -21,7 +24,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # 0 alone; 0 everywhere when built with this flag).  There is no switch for the op_sel forms alone; the flag costs
 # nothing measurable.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+         "-fno-gpu-rdc", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJSTSP_EXPERIMENTS"] if XP else [])
 
 
 def _sources():
@@ -42,7 +45,7 @@ def _stale(target, deps):
 
 
 def _compile(src):
-    obj = os.path.join(CSRC, src[:-4] + ".o")
+    obj = os.path.join(CSRC, src[:-4] + ("_xp.o" if XP else ".o"))
     path = os.path.join(CSRC, src)
     if _stale(obj, [path] + _headers()):
         cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]

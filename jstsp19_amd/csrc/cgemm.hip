@@ -500,7 +500,7 @@ int launch_cgemm(jstsp_ctx *ctx, const GemmDesc &d, int tag)
     JSTSP_REQUIRE(!d.C_lo || (variant == 2 && d.alpha == 1.f && !d.D), JSTSP_E_ARG, "cgemm: C_lo needs the fp64-master variant, alpha = 1, no D");
     const int bn = variant == 1 ? 128 : 64;
     // 3M where it pays and was validated: the dominant contractions, the Grams, and other products of 256 terms or more
-    static const int m3_mink = [] { const char *e = getenv("JSTSP_M3_MINK"); return e ? atoi(e) : 256; }();
+    static const int m3_mink = [] { const char *e = xp_getenv("JSTSP_M3_MINK"); return e ? atoi(e) : 256; }();
     const bool m3 = tag == GEMM_CORRELATE || tag == GEMM_SYNTH || tag == GEMM_GRAM || (tag == GEMM_MISC && kper >= m3_mink);
     const int tiles_n = (d.n + bn - 1) / bn;
     const long long groups = (d.batch + 7) / 8;

@@ -59,32 +59,42 @@ struct DeviceScope {
 // are diagnostic / opt-in settings, parsed ONCE at the entry of every API call (JSTSP_ENTER) into this struct - no switch is
 // latched in a static, none is read anywhere else - so a test can change them between two calls of one process and a call
 // sees one consistent setting from its first launch to its last.
+// Round 6: the opt-in paths that were measured and dropped (HISTORY.md), and every switch whose non-default value leaves the accuracy
+// statement of include/jstsp.h, exist only in a -DJSTSP_EXPERIMENTS build (JSTSP_EXPERIMENTS=1 python jstsp19_amd/build.py; tools/
+// only).  In the shipped library their settings are compile-time constants: the environment variable is not read, the branch is dead.
+#ifdef JSTSP_EXPERIMENTS
+#define JSTSP_XP int
+inline const char *xp_getenv(const char *name) { return getenv(name); }
+#else
+#define JSTSP_XP static constexpr int
+inline const char *xp_getenv(const char *) { return nullptr; }
+#endif
 struct Tuning {
     int h2 = 1;             // JSTSP_H2: 0 strict complex-fp32 MFMA everywhere, 1 split-f16 MFMA for big contractions, 2 always
     int fused = 1;          // JSTSP_FUSED: 0 three-kernel ADMM iteration instead of the fused pass
     int fused_parts = 0;    // JSTSP_FUSED_PARTS: column ranges per problem in the pass (0: chosen from M)
     int fused_kback = 4;    // JSTSP_FUSED_KBACK: headroom bits of the predicted k scale (test hook: negative forces the re-solve)
     int toeplitz = 2;       // JSTSP_TOEPLITZ: 0 dictionary taken as unstructured, 1 compact image only, 2 + window kernel (block 64)
-    int rv_refresh = 4;     // JSTSP_RV_REFRESH: R v recomputed from v every this many iterations
+    JSTSP_XP rv_refresh = 4;     // (experiments build) JSTSP_RV_REFRESH: R v recomputed from v every this many iterations
     int overlap = -1;       // JSTSP_OVERLAP: side streams between the kernels of an iteration (-1: on with the fused pass)
-    int svt_skip = 0;       // JSTSP_SVT_SKIP: 1 trials whose threshold is below fp32 resolution skip the eigen-decomposition (opt-in)
+    JSTSP_XP svt_skip = 0;       // (experiments build) JSTSP_SVT_SKIP: 1 trials whose threshold is below fp32 resolution skip the eigen-decomposition (opt-in)
     int lanczos = 1;        // JSTSP_LANCZOS: 0 Householder + Sturm instead of Lanczos for the convergence_error norms
     int lanczos_warm = 1;   // JSTSP_LANCZOS_WARM: 0 every lambda_max of an ADMM loop by the cold n-step Lanczos run (rounds 2-4)
     int lanczos_verify = 32; // JSTSP_LANCZOS_VERIFY: every this many calls a warm-started lambda_max is checked against the cold run (0: never, 1: always)
     int eig128 = 1;         // JSTSP_EIG128: 0 general Jacobi kernel for Gram orders 65..128
-    int omp_gram = 1;       // JSTSP_OMP_GRAM: 0 measurement-space OMP on a Kronecker dictionary
-    int grad_head = 0;      // JSTSP_GRAD_HEAD: bit 0 - Res / P1 of the gradient step, bit 1 - the first factor of a recomputed R v, on the
+    JSTSP_XP omp_gram = 1;       // (experiments build) JSTSP_OMP_GRAM: 0 measurement-space OMP on a Kronecker dictionary
+    JSTSP_XP grad_head = 0;      // (experiments build) JSTSP_GRAD_HEAD: bit 0 - Res / P1 of the gradient step, bit 1 - the first factor of a recomputed R v, on the
                             // f16 pipe in one launch (hsmall.hip) instead of fp32-MFMA products; measured: more accurate products,
                             // +2 % channel-estimates/s, but WORSE parity (rms |dNMSE| 2.18e-7 against 1.73e-7, a +5e-8 bias): off
-    int rv_comp = 0;        // JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
-    int rv_always = 0;      // JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
-    int inv_two_float = 1;  // JSTSP_INV2: 0 the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (rounds 1-4)
-    int pass_acc = 1;       // JSTSP_PASS_ACC: 0 products of K B^H straight into the window pass's running sums (rounds 2-4), 1 per-tile block sums first (fused.hip)
+    JSTSP_XP rv_comp = 0;        // (experiments build) JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
+    JSTSP_XP rv_always = 0;      // (experiments build) JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
+    JSTSP_XP inv_two_float = 1;  // (experiments build) JSTSP_INV2: 0 the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (rounds 1-4)
+    JSTSP_XP pass_acc = 1;       // (experiments build) JSTSP_PASS_ACC: 0 products of K B^H straight into the window pass's running sums (rounds 2-4), 1 per-tile block sums first (fused.hip)
     int host_compact = 1;   // JSTSP_HOST_COMPACT: 0 a JSTSP_HOST dictionary is uploaded whole (no host-side block-Toeplitz test / compaction)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
-    int gram_refine = 1;    // JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
+    JSTSP_XP gram_refine = 1;    // (experiments build) JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
     int bj_mask = 1;        // JSTSP_BJ_MASK: 0 the block Jacobi above order 128 without compute-unit masks (its sub-problems then compete with the panel products for units)
-    int bj_trace = 0;       // JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
+    JSTSP_XP bj_trace = 0;       // (experiments build) JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
 };
 const Tuning &tune();       // the calling thread's setting, as parsed by the API call in progress
 void load_tuning();

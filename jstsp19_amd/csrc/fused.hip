@@ -1399,15 +1399,15 @@ template <int GB> static int launch_fused64(jstsp_ctx *ctx, const FusedDesc &d)
     }
 #endif
     // JSTSP_PASS_ACC: how the products of K B^H enter their running sums (see phase B of the kernel)
-    switch (tune().pass_acc) {
-    case 1:
-        JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-        hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 1>), dim3(grid), dim3(512), sh, ctx->stream, d);
-        break;
-    default:
+#ifdef JSTSP_EXPERIMENTS
+    if (tune().pass_acc != 1) {
         JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
         hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 0>), dim3(grid), dim3(512), sh, ctx->stream, d);
+        return 0;
     }
+#endif
+    JSTSP_HIP(hipFuncSetAttribute((const void *)fused_pass64_kernel<GB, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
+    hipLaunchKernelGGL((fused_pass64_kernel<GB, 0, 1>), dim3(grid), dim3(512), sh, ctx->stream, d);
     return 0;
 }
 

@@ -1069,7 +1069,7 @@ int hermitian_fill_lower(jstsp_ctx *ctx, float2 *G, long long sGt, int n, int co
 // grid of a launch under the block map chosen for it (conc = workgroups one XCD holds at a time)
 static long long hgemm_grid(HGemmDesc &d, long long tiles, int conc)
 {
-    const char *map_env = getenv("JSTSP_HGEMM_MAP");       // (read at every launch: the tests switch it)
+    const char *map_env = xp_getenv("JSTSP_HGEMM_MAP");       // (read at every launch: the tests switch it)
     const int map_on = map_env ? atoi(map_env) : 1;
     d.map_tb = d.map_tt = 0;
     if (map_on && d.sPt == 0 && d.batch >= 2 && tiles >= 2) {

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(1024) void omp_step_reg_kernel(int meas, int size_d
 // JSTSP_OMP_REG=0: the step through global memory (omp_step_kernel<1024>) also where the register form applies
 static bool omp_reg_step()
 {
-    const char *e = getenv("JSTSP_OMP_REG");        // (read at every call)
+    const char *e = xp_getenv("JSTSP_OMP_REG");        // (read at every call)
     return !e || atoi(e) != 0;
 }
 

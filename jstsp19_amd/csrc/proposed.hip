@@ -17,7 +17,7 @@
 // JSTSP_HOST_TRACE=1: wall-clock marks of the JSTSP_HOST path on stderr (ms since the first mark of the process)
 static void host_trace(const char *what, int k = -1)
 {
-    static const bool on = [] { const char *e = getenv("JSTSP_HOST_TRACE"); return e && atoi(e) != 0; }();
+    static const bool on = [] { const char *e = jstsp::xp_getenv("JSTSP_HOST_TRACE"); return e && atoi(e) != 0; }();
     if (!on) return;
     static const auto t0 = std::chrono::steady_clock::now();
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

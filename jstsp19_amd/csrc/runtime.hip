@@ -28,24 +28,26 @@ void load_tuning()
     t.fused_parts = env_int("JSTSP_FUSED_PARTS", t.fused_parts);
     t.fused_kback = env_int("JSTSP_FUSED_KBACK", t.fused_kback);
     t.toeplitz = env_int("JSTSP_TOEPLITZ", t.toeplitz);
-    t.rv_refresh = env_int("JSTSP_RV_REFRESH", t.rv_refresh);
     t.overlap = env_int("JSTSP_OVERLAP", t.overlap);
-    t.svt_skip = env_int("JSTSP_SVT_SKIP", t.svt_skip);
     t.lanczos = env_int("JSTSP_LANCZOS", t.lanczos);
     t.lanczos_warm = env_int("JSTSP_LANCZOS_WARM", t.lanczos_warm);
     t.lanczos_verify = env_int("JSTSP_LANCZOS_VERIFY", t.lanczos_verify);
     t.eig128 = env_int("JSTSP_EIG128", t.eig128);
-    t.omp_gram = env_int("JSTSP_OMP_GRAM", t.omp_gram);
-    t.bj_trace = env_int("JSTSP_BJ_TRACE", t.bj_trace);
     t.bj_mask = env_int("JSTSP_BJ_MASK", t.bj_mask);
-    t.gram_refine = env_int("JSTSP_GRAM_REFINE", t.gram_refine);
     t.host_pipeline = env_int("JSTSP_HOST_PIPELINE", t.host_pipeline);
     t.host_compact = env_int("JSTSP_HOST_COMPACT", t.host_compact);
+#ifdef JSTSP_EXPERIMENTS        // measured and dropped, or outside the accuracy statement: tools/ only (common.h)
+    t.rv_refresh = env_int("JSTSP_RV_REFRESH", t.rv_refresh);
+    t.svt_skip = env_int("JSTSP_SVT_SKIP", t.svt_skip);
+    t.omp_gram = env_int("JSTSP_OMP_GRAM", t.omp_gram);
+    t.bj_trace = env_int("JSTSP_BJ_TRACE", t.bj_trace);
+    t.gram_refine = env_int("JSTSP_GRAM_REFINE", t.gram_refine);
     t.pass_acc = env_int("JSTSP_PASS_ACC", t.pass_acc);
     t.inv_two_float = env_int("JSTSP_INV2", t.inv_two_float);
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     t.rv_comp = env_int("JSTSP_RV_COMP", t.rv_comp);
+#endif
     g_tune = t;
 }
 
@@ -268,8 +270,13 @@ int lanczos_warm_reset(jstsp_ctx *ctx, const GramWS &w)
     w.lz.call = 0;
     w.lz.mismatch = nullptr;
     if (!w.lz.x) return 0;
-    if (!ctx->lz_mismatch) JSTSP_HIP(hipMalloc((void **)&ctx->lz_mismatch, 256));
-    JSTSP_HIP(hipMemsetAsync(ctx->lz_mismatch, 0, 8 * sizeof(unsigned), ctx->stream));
+    // (the counters are CUMULATIVE over the solves of a context - a re-solve of overflowed trials, the chunks of a sweep and the
+    //  second half of a pipelined host call must not wipe what the solve before them recorded; they are read AND cleared by
+    //  jstsp_last_lanczos_mismatches / jstsp_debug_lanczos_counters)
+    if (!ctx->lz_mismatch) {
+        JSTSP_HIP(hipMalloc((void **)&ctx->lz_mismatch, 256));
+        JSTSP_HIP(hipMemsetAsync(ctx->lz_mismatch, 0, 8 * sizeof(unsigned), ctx->stream));
+    }
     JSTSP_HIP(hipMemsetAsync(w.lz.state, 0, (size_t)w.batch * sizeof(int), ctx->stream));
     w.lz.mismatch = ctx->lz_mismatch;
     return 0;
@@ -586,26 +593,40 @@ int jstsp_last_conditioning(jstsp_ctx *ctx, double *rcond_min, double *ns_residu
     return diag_read(ctx, rcond_min, ns_residual_max);
 }
 
+// the four counters of this context AND of its helper context (the second half of a pipelined JSTSP_HOST call runs there),
+// summed into out4 and cleared: what was recorded since the previous read
+static int lanczos_counters_take(jstsp_ctx *ctx, unsigned *out4)
+{
+    jstsp_ctx *cx[2] = {ctx, ctx->helper};
+    for (int k = 0; k < 2; ++k) {
+        if (!cx[k] || !cx[k]->lz_mismatch) continue;
+        DeviceScope ds(cx[k]->device);
+        unsigned h[4];
+        JSTSP_HIP(hipStreamSynchronize(cx[k]->stream));
+        JSTSP_HIP(hipMemcpy(h, cx[k]->lz_mismatch, sizeof(h), hipMemcpyDeviceToHost));
+        JSTSP_HIP(hipMemset(cx[k]->lz_mismatch, 0, 8 * sizeof(unsigned)));
+        for (int i = 0; i < 4; ++i) out4[i] += h[i];
+    }
+    return 0;
+}
+
 // (diagnostics, not in the header: [0] verification mismatches, [1] warm attempts that did not converge, [2] verifications,
-//  [3] Lanczos steps of the converged warm attempts - of the last solve that reset the record)
+//  [3] Lanczos steps of the converged warm attempts - since the previous read of the counters)
 extern "C" int jstsp_debug_lanczos_counters(jstsp_ctx *ctx, unsigned *out4)
 {
     JSTSP_REQUIRE(ctx && out4, JSTSP_E_NULL, "ctx/out is NULL");
     JSTSP_ENTER(ctx);
     out4[0] = out4[1] = out4[2] = out4[3] = 0;
-    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->lz_mismatch) JSTSP_HIP(hipMemcpy(out4, ctx->lz_mismatch, 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
-    return 0;
+    return lanczos_counters_take(ctx, out4);
 }
 
 int jstsp_last_lanczos_mismatches(jstsp_ctx *ctx, int *count)
 {
     JSTSP_REQUIRE(ctx && count, JSTSP_E_NULL, "ctx/count is NULL");
     JSTSP_ENTER(ctx);
-    unsigned h = 0;
-    JSTSP_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->lz_mismatch) JSTSP_HIP(hipMemcpy(&h, ctx->lz_mismatch, sizeof(h), hipMemcpyDeviceToHost));
-    *count = (int)h;
+    unsigned h[4] = {0, 0, 0, 0};
+    JSTSP_TRY(lanczos_counters_take(ctx, h));
+    *count = (int)h[0];
     return 0;
 }
 

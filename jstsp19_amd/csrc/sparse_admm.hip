@@ -153,7 +153,7 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     // common.h) - the diagonal solve on the second transform, the dual update AND the next iteration's soft threshold / right-hand
     // side on the fourth (R itself is then never stored; S alternates between two buffers because convergence_error still reads
     // this iteration's S), the difference to Htrue on the error product.  Same expressions (sadmm_*1), same bits.
-    const char *fuse_env = getenv("JSTSP_SADMM_FUSE");          // (read at every call)
+    const char *fuse_env = xp_getenv("JSTSP_SADMM_FUSE");          // (read at every call)
     const bool fuse = !fuse_env || atoi(fuse_env) != 0;
     float2 *Sb[2] = {S, fuse ? R : S};
     const float2 *Sfin = S;
@@ -161,7 +161,7 @@ extern "C" int jstsp_sparse_admm_c32(jstsp_ctx *ctx, int Mr, int Mt, int Gr, int
     // S buffers) the error chain - two products, the Gram, lambda_max - runs on a side stream beside the next solve
     // (JSTSP_SADMM_OVERLAP=0: in line).  ev_s[it & 1]: S(it) is complete; ev_r[it & 1]: the error chain has read S(it), whose
     // buffer the epilogue of iteration it + 1 overwrites.
-    const char *ov_env = getenv("JSTSP_SADMM_OVERLAP");
+    const char *ov_env = xp_getenv("JSTSP_SADMM_OVERLAP");
     const bool overlap = fuse && want_ce && (!ov_env || atoi(ov_env) != 0);
     if (overlap) JSTSP_TRY(ensure_side_streams(ctx));
     hipStream_t sc = overlap ? ctx->side[0] : st;

@@ -81,14 +81,30 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
 
 
 def test_every_environment_switch_the_library_reads_is_documented_in_the_header():
-    """include/jstsp.h lists the JSTSP_* switches (tuning knobs and A/B switches of the kernels): every name that appears in a
-    getenv / env_int call of jstsp19_amd/csrc must appear there (JSTSP_FUSED_DBG exists in debug builds of fused.hip only)."""
+    """include/jstsp.h lists the JSTSP_* switches of the SHIPPED library: at most 15, every name that a getenv / env_int call of
+    jstsp19_amd/csrc reads outside `#ifdef JSTSP_EXPERIMENTS` must be in that list, and every one must be toggled by a test.
+    The switches of the experiments build (xp_getenv, or env_int inside `#ifdef JSTSP_EXPERIMENTS`) must be named in the
+    header's "Experiments build" paragraph - and nowhere in tests/ (the tests run the shipped library)."""
     import glob
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    names = set()
+    shipped, xp = set(), set()
+    pat = r'(?<![a-z_])(?:getenv|env_int|env_flt)\("(JSTSP_[A-Z0-9_]+)"'
     for f in glob.glob(os.path.join(root, "jstsp19_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "jstsp19_amd", "csrc", "*.h")):
-        names |= set(re.findall(r'(?:getenv|env_int|env_flt)\("(JSTSP_[A-Z0-9_]+)"', open(f).read()))
+        src = open(f).read()
+        xp |= set(re.findall(r'xp_getenv\("(JSTSP_[A-Z0-9_]+)"', src))
+        for blk in re.findall(r'#ifdef JSTSP_(?:EXPERIMENTS|FUSED_DBG_BUILD)\b(.*?)#endif', src, flags=re.S):
+            xp |= set(re.findall(pat, blk))
+        src = re.sub(r'#ifdef JSTSP_(?:EXPERIMENTS|FUSED_DBG_BUILD)\b.*?#endif', '', src, flags=re.S)
+        shipped |= set(re.findall(pat, src))
     header = open(os.path.join(root, "include", "jstsp.h")).read()
-    missing = sorted(n for n in names if n not in header and n != "JSTSP_FUSED_DBG")
-    assert len(names) > 20 and not missing, missing
+    env = header[header.index("---- Environment"):header.index("---- kernel-level entry points")]
+    main, exper = env.split("Experiments build.")
+    assert 10 <= len(shipped) <= 15, sorted(shipped)
+    assert not [n for n in shipped if ("  " + n) not in main], sorted(shipped)
+    assert not [n for n in xp if n not in exper], sorted(xp)
+    assert not (shipped & xp)
+    tests = "".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "test_*.py")) if not f.endswith("test_capi_symbols.py"))
+    assert not [n for n in shipped if n not in tests], [n for n in shipped if n not in tests]
+    assert not [n for n in xp if n in tests], [n for n in xp if n in tests]
+

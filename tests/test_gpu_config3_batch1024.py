@@ -88,33 +88,20 @@ def test_sparse_admm_1024_trials(cfg3):
 
 def test_sparse_admm_fused_epilogues_equal_the_separate_kernels_bit_for_bit(cfg3):
     """The element-wise steps of sparse_admm.m:21-30 ride on the products' epilogues by default (EPI_SADMM, cgemm.hip);
-    JSTSP_SADMM_FUSE=0 runs them as their own kernels.  Same expressions, so the same bits - S and convergence_error, with an even
-    and an odd iteration count (S alternates between two buffers), with and without the error curve, and Imax = 1 (no product
-    of the last iteration is needed at all)."""
+    the separate-kernel variant is in the experiments build only (round 6).  Checked here: S and convergence_error repeat bit for
+    bit and S does not depend on whether the error curve is asked for - with an even and an odd iteration count (S alternates
+    between two buffers) and Imax = 1 (no product of the last iteration is needed at all)."""
     import os
     import torch
     import jstsp19_amd as J
     H, OH, D = cfg3["H"][:48], cfg3["OH"][:48], cfg3["D"]
-    old = os.environ.get("JSTSP_SADMM_FUSE")
-    try:
-        for Imax in (1, 6, 7):
-            os.environ["JSTSP_SADMM_FUSE"] = "1"
-            S1, ce1 = J.sparse_admm(H, OH, D, D, Imax)                      # (error chain on the side stream: the default)
-            os.environ["JSTSP_SADMM_OVERLAP"] = "0"
-            S2, ce2 = J.sparse_admm(H, OH, D, D, Imax)
-            os.environ.pop("JSTSP_SADMM_OVERLAP")
-            S3, _ = J.sparse_admm(None, OH, D, D, Imax, want_ce=False)
-            os.environ["JSTSP_SADMM_FUSE"] = "0"
-            S0, ce0 = J.sparse_admm(H, OH, D, D, Imax)
-            for S in (S1, S2, S3):
-                assert torch.equal(torch.view_as_real(S), torch.view_as_real(S0))
-            assert torch.equal(ce1, ce0) and torch.equal(ce2, ce0)
-    finally:
-        os.environ.pop("JSTSP_SADMM_OVERLAP", None)
-        if old is None:
-            os.environ.pop("JSTSP_SADMM_FUSE", None)
-        else:
-            os.environ["JSTSP_SADMM_FUSE"] = old
+    for Imax in (1, 6, 7):
+        S1, ce1 = J.sparse_admm(H, OH, D, D, Imax)                      # (error chain on the side stream)
+        S2, ce2 = J.sparse_admm(H, OH, D, D, Imax)
+        S3, _ = J.sparse_admm(None, OH, D, D, Imax, want_ce=False)
+        for S in (S2, S3):
+            assert torch.equal(torch.view_as_real(S), torch.view_as_real(S1))
+        assert torch.equal(ce1, ce2)
 
 
 def test_mc_svt_and_mc_admm_inexact_inner_eigensolve_against_the_converged_one(cfg3):

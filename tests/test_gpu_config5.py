@@ -11,6 +11,8 @@ M = 65 536: size-independent properties (adjointness, batched == single, support
 import numpy as np
 import pytest
 
+from conftest import check_below, ce_rel, TOL_S, TOL_CE, TOL_NMSE  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -25,7 +27,7 @@ def _np(x, t, dt=np.complex128):
 
 def test_cfg5_small_frame_proposed_and_angles_against_the_oracle():
     """N=64, M=256, Gr=64, G2=4096: inputs from the library's own builder, 12 iterations, 2 trials against the float64
-    oracle (S to 2e-4 of max|S|, |dNMSE| <= 1e-6), convergence_error to 2e-3, support of _angles inside indx_S."""
+    oracle (S to 2e-5 of max|S|, |dNMSE| <= 1e-6), convergence_error to 5e-4, support of _angles inside indx_S."""
     import torch
     import jstsp19_amd as J
     from jstsp19_amd.system_model import build_trials
@@ -51,13 +53,13 @@ def test_cfg5_small_frame_proposed_and_angles_against_the_oracle():
         for (Sg, Yg, cg), idx in (((S, Y, ce), None), ((Sa, Ya, cea), inp["indx_S"][t].cpu().numpy())):
             So, Yo, co = O.proposed_algorithm(*args, indx_S=idx)
             sg = _np(Sg, t)
-            assert np.max(np.abs(sg - So)) / np.max(np.abs(So)) < 2e-4
-            assert np.max(np.abs(_np(Yg, t) - Yo)) / np.max(np.abs(Yo)) < 2e-4
-            assert abs(O.nmse_capped(sg, zb) - O.nmse_capped(So, zb)) < 1e-6
+            check_below("cfg5.S", np.max(np.abs(sg - So)) / np.max(np.abs(So)), TOL_S)
+            check_below("cfg5.Y", np.max(np.abs(_np(Yg, t) - Yo)) / np.max(np.abs(Yo)), TOL_S)
+            check_below("cfg5.nmse", abs(O.nmse_capped(sg, zb) - O.nmse_capped(So, zb)), TOL_NMSE)
             c = cg[t].cpu().numpy()
             fin = np.isfinite(co)
             assert np.array_equal(np.isfinite(c), fin)
-            assert np.max(np.abs(c[fin] - co[fin]) / np.abs(co[fin])) < 2e-3
+            check_below("cfg5.ce", np.max(np.abs(c[fin] - co[fin]) / np.abs(co[fin])), TOL_CE)
     for t in range(nb):
         allowed = set((inp["indx_S"][t, :10 + 5 * Imax] - 1).cpu().numpy().tolist())
         nz = set(np.flatnonzero(Sa[t].cpu().numpy().reshape(-1, order="F")).tolist())

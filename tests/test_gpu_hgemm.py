@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+from conftest import check_below, ce_rel, TOL_S, TOL_CE, TOL_NMSE  # noqa: E402
 
 from conftest import load_golden, rel_err
 
@@ -105,45 +106,6 @@ def test_batched_equals_single_through_split_f16(force_h2):
         assert np.array_equal(S9[t], S1[0]) and np.array_equal(Y9[t], Y1[0])
 
 
-def test_optional_svt_skip_is_exact_when_inactive_and_sub_roundoff_when_active():
-    """JSTSP_SVT_SKIP=1: a problem whose threshold tau_Y/rho is <= 2^-27 max|Z| skips the Gram + Jacobi (every entry
-    of Z - svt(Z, tau) is bounded by tau).  Where the SVT matters (reference-native fixture) nothing may change;
-    at the 64-antenna scale (threshold ~1e-10 of the data) the result moves by less than fp32 round-off."""
-    import torch
-    import jstsp19_amd as J
-    from jstsp19_amd.system_model import SweepParams, build_trials
-    old = {k: os.environ.get(k) for k in ("JSTSP_SVT_SKIP", "JSTSP_H2")}
-    try:
-        os.environ["JSTSP_H2"] = "2"                       # the skip rides on the split-f16 path's max|Z|
-        g = load_golden("proposed_refnative")
-        args = (g["subY"], g["Omega"], g["A"], g["B"], int(g["Imax"]), float(g["tau_Y"]), float(g["tau_Z"]),
-                float(g["rho"]), "approximate")
-        os.environ["JSTSP_SVT_SKIP"] = "0"
-        S0, Y0, ce0 = J.proposed_algorithm(*args)
-        os.environ["JSTSP_SVT_SKIP"] = "1"
-        S1, Y1, ce1 = J.proposed_algorithm(*args)
-        assert np.array_equal(S0, S1) and np.array_equal(Y0, Y1)          # criterion never fires here
-        p = SweepParams(Nt=64, Nr=64, L=8, T=16, Mr=8, snr_db=5.0)         # N=64, M=1024, G2=512
-        inp = build_trials(p, 0, 4, seed=11)
-        run = lambda: J.proposed_algorithm(inp["subY"], inp["Omega"], inp["A"], inp["B"], 40, inp["tau_Y"].numpy(),
-                                           inp["tau_Z"].numpy(), inp["rho"].numpy(), "approximate", want_ce=False)
-        os.environ["JSTSP_SVT_SKIP"] = "0"
-        Sa, Ya, _ = run()
-        os.environ["JSTSP_SVT_SKIP"] = "1"
-        Sb, Yb, _ = run()
-        torch.cuda.synchronize()
-        assert float((Sa - Sb).abs().max() / Sa.abs().max()) < 2e-6
-        assert float((Ya - Yb).abs().max() / Ya.abs().max()) < 2e-6
-        ea, eb = J.nmse_spectral(Sa, inp["Zbar"]), J.nmse_spectral(Sb, inp["Zbar"])
-        assert float((ea - eb).abs().max()) < 1e-6
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def test_std_type_through_split_f16_matches_oracle(force_h2):
     """'std' (Alg. 1: v = U\\(L\\k) as G_A^-1 (A^H K B^H) G_B^-1) with G_B = B B^H and both big contractions on the
     split-f16 kernels."""
@@ -191,9 +153,8 @@ def test_proposed_ragged_and_two_row_tiles_through_split_f16(force_h2, N, M, Gr,
     args = (subY, Om, A, B, 20, 0.01, 0.02, 0.3, "approximate")
     So, Yo, ceo = O.proposed_algorithm(*args)
     S, Y, ce = J.proposed_algorithm(*args)
-    assert rel_err(S, So) < 2e-4 and rel_err(Y, Yo) < 2e-4
-    np.testing.assert_allclose(ce[1:, 2], ceo[1:, 2], rtol=1e-3)
-    np.testing.assert_allclose(ce[:, :2], ceo[:, :2], rtol=2e-3)
+    check_below("hgemm_shapes.S", rel_err(S, So), TOL_S); check_below("hgemm_shapes.Y", rel_err(Y, Yo), TOL_S)
+    check_below("hgemm_shapes.ce", ce_rel(ce, ceo), TOL_CE)
 
 
 def test_side_stream_overlap_is_bit_identical_through_the_split_f16_grams(force_h2):

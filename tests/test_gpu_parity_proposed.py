@@ -1,34 +1,33 @@
 """HIP path vs the float64 oracle / golden fixtures — proposed_algorithm(_angles).
 
 Tolerances (fp32 device arithmetic vs float64 reference restatement):
-  S, Y   : max|d| / max|ref| <= 2e-4
-  NMSE   : |d| <= 1e-6 (BASELINE.json north_star) at the reference-native shape and above
-  ce     : relative 2e-3 on convergence_error columns 1-2 (ratios of fp32 lambda_max), 1e-3 on column 3
+  S, Y   : max|d| / max|ref| <= 2e-5   (conftest.TOL_S: about 4x the largest error measured, round 6)
+  NMSE   : |d| <= 1e-6 (BASELINE.json north_star), every fixture
+  ce     : relative 5e-4 on every finite entry of convergence_error (conftest.TOL_CE)
 """
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, rel_err, check_below, ce_rel, TOL_S, TOL_CE, TOL_NMSE
 
 pytestmark = pytest.mark.gpu
 
-TOL_S = 2e-4
 
 
 def _check(out, g, key, nmse_tol=1e-6, check_ce=True):
     import jstsp19_amd as J
     from oracle import solvers as O
     S, Y, ce = out
-    assert rel_err(S, g["S_" + key]) < TOL_S
-    assert rel_err(Y, g["Y_" + key]) < TOL_S
+    check_below("golden.S", rel_err(S, g["S_" + key]), TOL_S)
+    check_below("golden.Y", rel_err(Y, g["Y_" + key]), TOL_S)
     nm = O.nmse_capped(np.asarray(S, dtype=np.complex128), g["Zbar"])
-    assert abs(nm - float(g["nmse_" + key])) < nmse_tol
+    check_below("golden.nmse", abs(nm - float(g["nmse_" + key])), nmse_tol)
     if check_ce:
         ref = g["ce_" + key]
         assert ce.shape == ref.shape
         assert np.isinf(ce[0, 2]) and np.isinf(ref[0, 2])          # 0-divide at i = 1 (proposed_algorithm.m:51)
-        np.testing.assert_allclose(ce[1:, 2], ref[1:, 2], rtol=1e-3)
-        np.testing.assert_allclose(ce[:, :2], ref[:, :2], rtol=2e-3)
+        check_below("golden.ce3", ce_rel(ce[1:, 2], ref[1:, 2]), TOL_CE)
+        check_below("golden.ce12", ce_rel(ce[:, :2], ref[:, :2]), TOL_CE)
 
 
 @pytest.mark.parametrize("name", ["proposed_small", "proposed_small_lowsnr", "proposed_refnative"])
@@ -37,7 +36,7 @@ def test_proposed_host_path_matches_golden(name):
     g = load_golden(name)
     out = J.proposed_algorithm(g["subY"], g["Omega"], g["A"], g["B"], int(g["Imax"]), float(g["tau_Y"]),
                                float(g["tau_Z"]), float(g["rho"]), "approximate")
-    _check(out, g, "approximate", nmse_tol=1e-6 if name == "proposed_refnative" else 2e-6)
+    _check(out, g, "approximate", nmse_tol=TOL_NMSE)
 
 
 @pytest.mark.parametrize("name", ["proposed_small", "proposed_refnative"])
@@ -46,7 +45,7 @@ def test_proposed_angles_matches_golden(name):
     g = load_golden(name)
     out = J.proposed_algorithm_angles(g["subY"], g["Omega"], g["indx_S"], g["A"], g["B"], int(g["Imax"]),
                                       float(g["tau_Y"]), float(g["tau_Z"]), float(g["rho"]), "approximate", 100)
-    _check(out, g, "angles", nmse_tol=1e-6 if name == "proposed_refnative" else 2e-6)
+    _check(out, g, "angles", nmse_tol=TOL_NMSE)
 
 
 def test_first_iteration_invariants():
@@ -89,10 +88,10 @@ def test_batched_device_path_per_trial_and_shared_dictionaries():
     for t, tr in enumerate(trials):
         So, Yo, ceo = O.proposed_algorithm(tr["subY"], tr["Omega"], tr["A"], tr["B"], 100, tr["tau_Y"],
                                            tr["tau_Z"], tr["rho"], "approximate")
-        assert rel_err(S[t], So) < TOL_S
-        assert rel_err(Y[t], Yo) < TOL_S
-        assert abs(O.nmse_capped(S[t].astype(complex), tr["Zbar"]) - O.nmse_capped(So, tr["Zbar"])) < 1e-6
-        np.testing.assert_allclose(ce[t, :, :2], ceo[:, :2], rtol=2e-3)
+        check_below("batched.S", rel_err(S[t], So), TOL_S)
+        check_below("batched.Y", rel_err(Y[t], Yo), TOL_S)
+        check_below("batched.nmse", abs(O.nmse_capped(S[t].astype(complex), tr["Zbar"]) - O.nmse_capped(So, tr["Zbar"])), TOL_NMSE)
+        check_below("batched.ce", ce_rel(ce[t], ceo), TOL_CE)
         S1, Y1, _ = J.proposed_algorithm(tr["subY"], tr["Omega"], tr["A"], tr["B"], 100, tr["tau_Y"],
                                          tr["tau_Z"], tr["rho"], "approximate", want_ce=False)
         assert rel_err(S[t], S1) < 1e-5
@@ -112,9 +111,8 @@ def test_ragged_shapes_not_multiples_of_the_tile():
     args = (subY, Om, A, B, 25, 0.01, 0.02, 0.3, "approximate")
     So, Yo, ceo = O.proposed_algorithm(*args)
     S, Y, ce = J.proposed_algorithm(*args)
-    assert rel_err(S, So) < TOL_S and rel_err(Y, Yo) < TOL_S
-    np.testing.assert_allclose(ce[1:, 2], ceo[1:, 2], rtol=1e-3)
-    np.testing.assert_allclose(ce[:, :2], ceo[:, :2], rtol=2e-3)
+    check_below("ragged.S", rel_err(S, So), TOL_S); check_below("ragged.Y", rel_err(Y, Yo), TOL_S)
+    check_below("ragged.ce", ce_rel(ce, ceo), TOL_CE)
 
 
 def test_bad_arguments_are_rejected_not_crashed():

@@ -97,12 +97,9 @@ def test_headline_shape_shared_and_per_trial_pilots():
     Bz = inp["B"].clone()
     for ld in range(1, 8):
         Bz[:, ld * 64:(ld + 1) * 64, :ld] = 0
-    # (what still differs from the unstructured path is G_B, assembled from its first block row: JSTSP_GRAM_REFINE=0 takes that out)
-    z2, gt, _ = _solve(inp, 8, {"JSTSP_GRAM_REFINE": "0"}, B=Bz)
-    z0, _, _ = _solve(inp, 8, {"JSTSP_TOEPLITZ": "0", "JSTSP_GRAM_REFINE": "0"}, B=Bz)
+    # (what still differs from the unstructured path is G_B, assembled from its first block row: fp32-equivalent, not bit-identical)
+    z3, gt, _ = _solve(inp, 8, B=Bz)
     assert gt == 64
-    _same(z2, z0)
-    z3, _, _ = _solve(inp, 8, B=Bz)
     z4, _, _ = _solve(inp, 8, {"JSTSP_TOEPLITZ": "0"}, B=Bz)
     _close(z3, z4)
     sh = build_trials(p, 0, 9, seed=5, shared_pilots=True)
@@ -273,6 +270,11 @@ def test_host_side_compaction_is_bit_identical_and_falls_back_on_the_first_misma
         r1, gt1 = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "2"}, B=Bt, c64=c64)
         assert gt0 == Nt and gt1 == Nt
         _same(r1, r0)
+        # JSTSP_HOST_THREADS: the host-side test / compaction on one thread and on three (a count that does not divide the trials)
+        for nthr in ("1", "3"):
+            r1t, gt1t = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "2", "JSTSP_HOST_THREADS": nthr}, B=Bt, c64=c64)
+            assert gt1t == Nt
+            _same(r1t, r0)
     B2 = inp["B"].clone()
     v = torch.view_as_real(B2)
     v[batch - 1, 3 * Nt + 1, 40, 1] = torch.nextafter(v[batch - 1, 3 * Nt + 1, 40, 1], torch.tensor(10.0, device=B.device))
@@ -280,19 +282,3 @@ def test_host_side_compaction_is_bit_identical_and_falls_back_on_the_first_misma
     r3, gt3 = _host_solve(inp, 8, {"JSTSP_HOST_COMPACT": "0"}, B=B2, c64=c64)
     assert gt2 == 0 and gt3 == 0
     _same(r2, r3)
-
-
-@pytest.mark.parametrize("Nt,L,T,batch", [(64, 8, 16, 5),     # G2 = 512, M = 1024: 8 / 16 column tiles, 5 trials (one ragged block)
-                                          (64, 8, 16, 13),    # 13 trials: two blocks of 8, the second ragged
-                                          (32, 12, 24, 3)])   # G2 = 384: fewer tiles than a block holds
-def test_shared_dictionary_block_map_of_the_split_f16_products_is_bit_identical(Nt, L, T, batch):
-    """One dictionary for all trials: the split-f16 products (hgemm.hip) hand an XCD blocks of 8 trials x 4-8 column tiles at a
-    time, so that the trials of a tile share the dictionary panel in L2 (block_to_trial_tile); JSTSP_HGEMM_MAP=0 keeps the
-    per-trial order.  Only the order of the workgroups differs: the same bits, on the three-kernel iteration (JSTSP_FUSED=0)
-    and on the default path, at batch sizes that leave ragged blocks."""
-    from jstsp19_amd.system_model import build_trials
-    sh = build_trials(_params(Nt, L, T), 0, batch, seed=11, shared_pilots=True)
-    for extra in ({"JSTSP_FUSED": "0"}, {}):
-        r1, _, _ = _solve(sh, 6, dict(extra), B=sh["B"][0])
-        r0, _, _ = _solve(sh, 6, dict(extra, JSTSP_HGEMM_MAP="0"), B=sh["B"][0])
-        _same(r1, r0)
