@@ -376,18 +376,6 @@ int jstsp_mc_admm_c64(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c64
     return cv.finish();
 }
 
-int jstsp_vamp_c64(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c64 *y, const jstsp_c64 *A, long long strideA,
-                   double sigma, double L, int nit, jstsp_c64 *x_out, int memspace)
-{
-    C64_BEGIN(M > 0 && N > 0 && batch > 0 && strideA >= 0, "vamp");
-    JSTSP_REQUIRE(y && A && x_out, JSTSP_E_NULL, "vamp: NULL argument");
-    const jstsp_c32 *yy = cv.in(y, (size_t)M * batch), *a = cv.in_dict(A, (size_t)M * N, strideA, batch);
-    jstsp_c32 *x = cv.out(x_out, (size_t)N * batch);
-    JSTSP_TRY(cv.rc);
-    JSTSP_TRY(jstsp_vamp_c32(ctx, M, N, batch, yy, a, strideA, sigma, L, nit, x, JSTSP_DEVICE));
-    return cv.finish();
-}
-
 int jstsp_ls_c64(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c64 *Y, const jstsp_c64 *A,
                  long long strideA, const jstsp_c64 *B, long long strideB, jstsp_c64 *S_out, int memspace)
 {
@@ -426,20 +414,6 @@ int jstsp_mmv_omp_c64(jstsp_ctx *ctx, int N, int Gr, int S, int batch, const jst
     int32_t *ix = cv.out_raw(index_out, (size_t)K * batch), *cn = cv.out_raw(count_out, (size_t)batch);
     JSTSP_TRY(cv.rc);
     JSTSP_TRY(jstsp_mmv_omp_c32(ctx, N, Gr, S, batch, a, strideA, y, K, pnorm, z, ix, cn, JSTSP_DEVICE));
-    return cv.finish();
-}
-
-int jstsp_vamp_kron_c64(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const jstsp_c64 *Y, const jstsp_c64 *Af,
-                        long long strideA, const jstsp_c64 *Gb, long long strideG, double sigma, double L, int nit,
-                        jstsp_c64 *X_out, int memspace)
-{
-    C64_BEGIN(Na > 0 && Gr > 0 && G2 > 0 && batch > 0 && strideA >= 0 && strideG >= 0, "vamp_kron");
-    JSTSP_REQUIRE(Y && Af && Gb && X_out, JSTSP_E_NULL, "vamp_kron: NULL argument");
-    const jstsp_c32 *y = cv.in(Y, (size_t)Na * G2 * batch), *a = cv.in_dict(Af, (size_t)Na * Gr, strideA, batch),
-                    *g = cv.in_dict(Gb, (size_t)G2 * G2, strideG, batch);
-    jstsp_c32 *x = cv.out(X_out, (size_t)Gr * G2 * batch);
-    JSTSP_TRY(cv.rc);
-    JSTSP_TRY(jstsp_vamp_kron_c32(ctx, Na, Gr, G2, batch, y, a, strideA, g, strideG, sigma, L, nit, x, JSTSP_DEVICE));
     return cv.finish();
 }
 

@@ -247,6 +247,7 @@ struct jstsp_ctx {
     int last_dict_block = 0;     // block height of the block-Toeplitz structure the last fused solve found in its dictionary (0: none)
     int fused_fallbacks = 0;     // trials of the last proposed_algorithm call re-solved after a k-scale overflow in the fused pass
     float2 *unit = nullptr;      // device copy of the 1 x 1 identity factor (vamp.hip: the dense call is the Kronecker call with it)
+    double2 *unit64 = nullptr;   // the same for the float64 path (vamp64.hip)
     jstsp_ctx *helper = nullptr; // second context of the same device (own stream, own workspace): the other half of a pipelined JSTSP_HOST solve (proposed.hip)
     hipStream_t side[2] = {nullptr, nullptr};
     // streams with a compute-unit mask (runtime.hip: ensure_cu_streams): [0..2] everything but 32 reserved units, [3] the

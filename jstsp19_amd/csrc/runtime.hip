@@ -545,6 +545,7 @@ int jstsp_destroy(jstsp_ctx *ctx)
     if (ctx->hpin_done) { (void)hipEventSynchronize(ctx->hpin_done); (void)hipEventDestroy(ctx->hpin_done); }
     if (ctx->hpin) (void)hipHostFree(ctx->hpin);
     if (ctx->unit) (void)hipFree(ctx->unit);
+    if (ctx->unit64) (void)hipFree(ctx->unit64);
     ctx->arena.release();
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -16,191 +16,10 @@
 // NOTE: with sigma fixed at 1 the reference iteration does not converge and amplifies
 // rounding differences ~1e9 over 100 iterations; fp32 results agree with float64 per iteration for the
 // first tens of iterations and statistically (NMSE) thereafter.
-#include "solver_common.h"
+#include "vamp_kernels.h"
 #include <algorithm>
-#include <cfloat>
 
 namespace jstsp {
-
-struct VampScal {
-    double gam1x, gam1z, gam2x, gam2z, alf;
-    double pad[3];
-};
-
-__device__ __forceinline__ double bsum(double v, double *sh)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-// Bernoulli-Gaussian posterior of one real coordinate with the complex-branch likelihoods.
-__device__ __forceinline__ void bg_denoise(double r, double rvar, double var0, double p1, double &xhat, double &xvar)
-{
-    const double PI = 3.14159265358979323846;
-    const double r2 = r * r;
-    const double ll1 = -(log(PI) + log(var0 + rvar) + r2 / (var0 + rvar));     // CAwgnEstimIn.m:181-184
-    const double rv = fmax(rvar, DBL_EPSILON);                                  // SparseScaEstim.m:96
-    const double ll0 = -(log(PI) + log(rv) + r2 / rv);                          // :100-103
-    double ex = ll0 - ll1 + log(1.0 - p1) - log(p1);                            // :107
-    ex = fmax(fmin(ex, 500.0), -500.0);                                         // :108-109
-    const double py1 = 1.0 / (1.0 + exp(ex));                                   // :110
-    const double gain = var0 / (var0 + rv);                                     // CAwgnEstimIn.m:100-102
-    const double xh1 = gain * r, xv1 = gain * rv;
-    xhat = py1 * xh1;                                                           // :160
-    xvar = py1 * (xh1 * xh1 - xhat * xhat) + py1 * xv1 + (1.0 - py1) * (0.0 - xhat * xhat);   // :163-165
-}
-
-__device__ __forceinline__ double clipg(double g) { return fmin(fmax(g, 1e-8), 1e14); }   // VampGlmOpt.m:7-8
-
-// First half of an iteration (VampGlmEst.m:354-398): one workgroup per problem.
-// Dc, Da: number of entries of d and the order of its A-side factor - (Mc, Na) with d = eig(A A') for M <= N (:402-406),
-// (Nc, Gr) with d = eig(A'A) for M > N (:407-411; vamp.m passes no opt.V, so VampGlmEst.m:196-218 recomputes V and d)
-__global__ __launch_bounds__(256) void vamp_first_half_kernel(int Nc, int Mc, int Dc, int Da, int G2, int it, double damp,
-                                                              double sigma, double Lnz, const float2 *y,
-                                                              const float2 *r1, const float2 *p1, float2 *x1,
-                                                              float2 *r2, float2 *p2, const float *lamA,
-                                                              long long sLa, const float *lamB, long long sLb,
-                                                              float *q, float *dq, VampScal *sc)
-{
-    __shared__ double sh[4];
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const long long bn = (long long)t * Nc, bm = (long long)t * Mc;
-    VampScal s = sc[t];
-    const double N = 2.0 * Nc;
-    const double beta = Lnz / N, var0 = 1.0 / beta;                              // vamp.m:23-24 (xvar0 = 1)
-    // ---- denoiser (:361) + damping (:363-365)
-    double sv = 0;
-    for (int e = tid; e < Nc; e += 256) {
-        const float2 r = r1[bn + e];
-        double xr, vr, xi, vi;
-        bg_denoise((double)r.x, 1.0 / s.gam1x, var0, beta, xr, vr);
-        bg_denoise((double)r.y, 1.0 / s.gam1x, var0, beta, xi, vi);
-        sv += vr + vi;
-        if (it > 0) {
-            const float2 xo = x1[bn + e];
-            xr = damp * xr + (1.0 - damp) * xo.x;
-            xi = damp * xi + (1.0 - damp) * xo.y;
-        }
-        x1[bn + e] = make_float2((float)xr, (float)xi);
-    }
-    sv = bsum(sv, sh);
-    const double eta1x = 1.0 / (sv / N);                                         // :362
-    const double g2x = eta1x - s.gam1x;                                          // :366
-    for (int e = tid; e < Nc; e += 256) {                                        // :367 (unclipped gam2x)
-        const float2 x = x1[bn + e], r = r1[bn + e];
-        r2[bn + e] = make_float2((float)((x.x * eta1x - r.x * s.gam1x) / g2x), (float)((x.y * eta1x - r.y * s.gam1x) / g2x));
-    }
-    const double gam2x = clipg(g2x);                                             // :376
-    // ---- likelihood (:378-393): CAwgnEstimOut with scale 1
-    const double pvar = 1.0 / s.gam1z, gain = pvar / (pvar + sigma);
-    const double eta1z = 1.0 / (sigma * gain);
-    const double g2z = eta1z - s.gam1z;
-    for (int e = tid; e < Mc; e += 256) {
-        const float2 p = p1[bm + e], yy = y[bm + e];
-        const double zr = gain * (yy.x - p.x) + p.x, zi = gain * (yy.y - p.y) + p.y;
-        p2[bm + e] = make_float2((float)((zr * eta1z - p.x * s.gam1z) / g2z), (float)((zi * eta1z - p.y * s.gam1z) / g2z));
-    }
-    double gam2z = clipg(g2z);
-    if (it > 0) gam2z = damp * gam2z + (1.0 - damp) * s.gam2z;                   // :391-393
-    // ---- q = 1/(d + gam2x/gam2z), alf = (1/N) d'q - eps (:397-398); d_ij = sa_i^2 lb_j^2, each counted twice
-    const double ratio = gam2x / gam2z;
-    double acc = 0;
-    const long long bd = (long long)t * Dc;
-    for (int e = tid; e < Dc; e += 256) {
-        const int i = e % Da, j = e / Da;
-        const double lb = lamB[(long long)t * sLb + j];
-        const double d = fmax((double)lamA[(long long)t * sLa + i], 0.0) * lb * lb;
-        const double qq = 1.0 / (d + ratio);
-        q[bd + e] = (float)qq;
-        dq[bd + e] = (float)(d * qq);
-        acc += d * qq;
-    }
-    acc = bsum(acc, sh);
-    if (tid == 0) {
-        s.gam2x = gam2x; s.gam2z = gam2z;
-        s.alf = (2.0 / N) * acc - DBL_EPSILON;
-        sc[t] = s;
-    }
-}
-
-// t = Tm .* q ; dt = Tm .* (d q)
-__global__ __launch_bounds__(256) void vamp_scale_kernel(long long n, const float2 *Tm, const float *q, const float *dq,
-                                                         float2 *tq, float2 *tdq)
-{
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float2 v = Tm[i];
-        tq[i] = make_float2(v.x * q[i], v.y * q[i]);
-        tdq[i] = make_float2(v.x * dq[i], v.y * dq[i]);
-    }
-}
-
-// W += (gam2x / gam2z) r2   (the argument of V' in VampGlmEst.m:408; the ratio is a per-problem device scalar)
-__global__ __launch_bounds__(256) void vamp_add_ratio_kernel(int Nc, float2 *W, const float2 *r2, const VampScal *sc)
-{
-    const int t = blockIdx.y;
-    const float ratio = (float)(sc[t].gam2x / sc[t].gam2z);
-    const long long b = (long long)t * Nc;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < Nc; e += gridDim.x * 256) {
-        const float2 r = r2[b + e];
-        float2 w = W[b + e];
-        w.x += ratio * r.x; w.y += ratio * r.y;
-        W[b + e] = w;
-    }
-}
-
-__global__ __launch_bounds__(256) void vamp_sub_kernel(long long n, const float2 *a, const float2 *b, float2 *o)
-{
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-        o[i] = make_float2(a[i].x - b[i].x, a[i].y - b[i].y);
-}
-
-// Second half (:411-413, :464-492): damping of z2, new r1, p1, gam1x, gam1z.
-__global__ __launch_bounds__(256) void vamp_second_half_kernel(int Nc, int Mc, int it, double damp, const float2 *x2,
-                                                               const float2 *r2, float2 *z2, float2 *z2old,
-                                                               const float2 *p2, float2 *r1, float2 *p1, VampScal *sc)
-{
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const long long bn = (long long)t * Nc, bm = (long long)t * Mc;
-    VampScal s = sc[t];
-    const double alf = s.alf, dl = (double)Mc / (double)Nc;                      // del = M/N (:257)
-    for (int e = tid; e < Nc; e += 256) {                                        // :464
-        const float2 a = x2[bn + e], b = r2[bn + e];
-        r1[bn + e] = make_float2((float)((a.x - b.x * (1.0 - alf)) / alf), (float)((a.y - b.y * (1.0 - alf)) / alf));
-    }
-    for (int e = tid; e < Mc; e += 256) {
-        float2 z = z2[bm + e];
-        if (it > 0) {                                                            // :411-413
-            const float2 zo = z2old[bm + e];
-            z = make_float2((float)(damp * z.x + (1.0 - damp) * zo.x), (float)(damp * z.y + (1.0 - damp) * zo.y));
-        }
-        z2old[bm + e] = z;
-        const float2 pp = p2[bm + e];                                            // :465
-        p1[bm + e] = make_float2((float)((dl * z.x - pp.x * alf) / (dl - alf)), (float)((dl * z.y - pp.y * alf) / (dl - alf)));
-    }
-    if (tid == 0) {
-        double g1x = clipg(s.gam2x * alf / (1.0 - alf));                         // :469,:479
-        const double g1z = clipg(s.gam2z * (dl - alf) / alf);                    // :480,:489
-        if (it > 0) g1x = damp * g1x + (1.0 - damp) * s.gam1x;                   // :490-492
-        s.gam1x = g1x; s.gam1z = g1z;
-        sc[t] = s;
-    }
-}
-
-__global__ void vamp_init_kernel(int batch, VampScal *sc)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < batch) {
-        VampScal s;
-        s.gam1x = 1e-8; s.gam1z = 1e-8;            // VampGlmOpt.m:25,27
-        s.gam2x = 0; s.gam2z = 0; s.alf = 0;
-        sc[t] = s;
-    }
-}
 
 static inline dim3 gsz(long long n) { return dim3((unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096))); }
 
@@ -244,26 +63,26 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
     JSTSP_HIP(hipMemsetAsync(p1, 0, bM * sizeof(float2), st));            // VampGlmEst.m:331
     JSTSP_HIP(hipMemsetAsync(x1, 0, bN * sizeof(float2), st));
     JSTSP_HIP(hipMemsetAsync(z2o, 0, bM * sizeof(float2), st));
-    hipLaunchKernelGGL(vamp_init_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, sc);
+    hipLaunchKernelGGL((vamp_init_kernel<0>), dim3((batch + 255) / 256), dim3(256), 0, st, batch, sc);
     const long long sN = Nc, sM = Mc;
     for (int it = 0; it < nit; ++it) {
-        hipLaunchKernelGGL(vamp_first_half_kernel, dim3(batch), dim3(256), 0, st, Nc, Mc, Dc, Da, G2, it, damp, sigma, Lnz, Y,
+        hipLaunchKernelGGL((vamp_first_half_kernel<float2, float>), dim3(batch), dim3(256), 0, st, Nc, Mc, Dc, Da, G2, it, damp, sigma, Lnz, Y,
                            r1, p1, x1, r2, p2, lamA, sA ? (long long)Da : 0, lamB, sG ? (long long)G2 : 0, q, dq, sc);
         if (tall) {
             // Vr2Ap2 = V'(r2 gam2x/gam2z + A'p2);  x2 = V(Vr2Ap2 .* q);  z2 = A x2                 (:408-410)
             // with Phi^H vec(Z) = vec(Af^H Z Gb),  V^H vec(X) = vec(Va^H X Ub),  V vec(T) = vec(Va T Ub^H)
             JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, Na, batch, Am, Mat{p2, sM, Na}, u3, sN, Gr));
             JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{u3, sN, Gr}, Gm, x2, sN, Gr));
-            hipLaunchKernelGGL(vamp_add_ratio_kernel, dim3((unsigned)std::min(64, (Nc + 255) / 256), batch), dim3(256), 0, st, Nc,
+            hipLaunchKernelGGL((vamp_add_ratio_kernel<float2, float>), dim3((unsigned)std::min(64, (Nc + 255) / 256), batch), dim3(256), 0, st, Nc,
                                x2, r2, sc);
             JSTSP_TRY(gemm(ctx, 'C', 'N', Gr, G2, Gr, batch, Uam, Mat{x2, sN, Gr}, u3, sN, Gr));
             JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, G2, batch, Mat{u3, sN, Gr}, Ubm, x2, sN, Gr));
-            hipLaunchKernelGGL(vamp_scale_kernel, gsz((long long)bN), dim3(256), 0, st, (long long)bN, x2, q, dq, u3, tdq);
+            hipLaunchKernelGGL((vamp_scale_kernel<float2, float>), gsz((long long)bN), dim3(256), 0, st, (long long)bN, x2, q, dq, u3, tdq);
             JSTSP_TRY(gemm(ctx, 'N', 'N', Gr, G2, Gr, batch, Uam, Mat{u3, sN, Gr}, T2, sN, Gr));
             JSTSP_TRY(gemm(ctx, 'N', 'C', Gr, G2, G2, batch, Mat{T2, sN, Gr}, Ubm, x2, sN, Gr));
             JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, Gr, batch, Am, Mat{x2, sN, Gr}, T1, sM, Na));
             JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, G2, batch, Mat{T1, sM, Na}, Gm, z2, sM, Na));
-            hipLaunchKernelGGL(vamp_second_half_kernel, dim3(batch), dim3(256), 0, st, Nc, Mc, it, damp, x2, r2, z2, z2o, p2,
+            hipLaunchKernelGGL((vamp_second_half_kernel<float2, float>), dim3(batch), dim3(256), 0, st, Nc, Mc, it, damp, x2, r2, z2, z2o, p2,
                                r1, p1, sc);
             continue;
         }
@@ -271,10 +90,10 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
         JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, Gr, batch, Am, Mat{r2, sN, Gr}, T1, sM, Na));
         JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, G2, batch, Mat{T1, sM, Na}, Gm, Ar2, sM, Na));
         // t = (U^H (p2 - Ar2)) .* q,  U^H vec(Z) = vec(Ua^H Z Ub)                      (:401)
-        hipLaunchKernelGGL(vamp_sub_kernel, gsz((long long)bM), dim3(256), 0, st, (long long)bM, p2, Ar2, E);
+        hipLaunchKernelGGL((vamp_sub_kernel<float2, float>), gsz((long long)bM), dim3(256), 0, st, (long long)bM, p2, Ar2, E);
         JSTSP_TRY(gemm(ctx, 'C', 'N', Na, G2, Na, batch, Uam, Mat{E, sM, Na}, T1, sM, Na));
         JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, G2, batch, Mat{T1, sM, Na}, Ubm, T2, sM, Na));
-        hipLaunchKernelGGL(vamp_scale_kernel, gsz((long long)bM), dim3(256), 0, st, (long long)bM, T2, q, dq, tq, tdq);
+        hipLaunchKernelGGL((vamp_scale_kernel<float2, float>), gsz((long long)bM), dim3(256), 0, st, (long long)bM, T2, q, dq, tq, tdq);
         // x2 = r2 + Phi^H U t,  U vec(T) = vec(Ua T Ub^H),  Phi^H vec(Z) = vec(Af^H Z Gb)   (:402)
         JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, Na, batch, Uam, Mat{tq, sM, Na}, T1, sM, Na));
         JSTSP_TRY(gemm(ctx, 'N', 'C', Na, G2, G2, batch, Mat{T1, sM, Na}, Ubm, T2, sM, Na));
@@ -283,7 +102,7 @@ static int vamp_run(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const flo
         // z2 = Ar2 + U (d .* t)                                                       (:403)
         JSTSP_TRY(gemm(ctx, 'N', 'N', Na, G2, Na, batch, Uam, Mat{tdq, sM, Na}, T1, sM, Na));
         JSTSP_TRY(gemm(ctx, 'N', 'C', Na, G2, G2, batch, Mat{T1, sM, Na}, Ubm, z2, sM, Na, 1.f, Ar2, sM, Na, 1.f));
-        hipLaunchKernelGGL(vamp_second_half_kernel, dim3(batch), dim3(256), 0, st, Nc, Mc, it, damp, x2, r2, z2, z2o, p2,
+        hipLaunchKernelGGL((vamp_second_half_kernel<float2, float>), dim3(batch), dim3(256), 0, st, Nc, Mc, it, damp, x2, r2, z2, z2o, p2,
                            r1, p1, sc);
     }
     JSTSP_HIP(hipGetLastError());

@@ -64,7 +64,7 @@ class _Arg:
             raise ValueError("%s must be 2-D or 3-D (batch first), got shape %s" % (name, tuple(x.shape)))
         if self.torch:
             import torch
-            want = {np.complex64: torch.complex64, np.float32: torch.float32, np.int32: torch.int32}[np_dtype]
+            want = {np.complex64: torch.complex64, np.complex128: torch.complex128, np.float32: torch.float32, np.int32: torch.int32}[np_dtype]
             if not x.is_cuda:
                 raise ValueError("%s: torch tensors must live on the GPU (numpy arrays use the host path)" % name)
             if x.dtype != want:
@@ -93,7 +93,7 @@ def _out(kind_torch, batch, R, Cc, np_dtype, device=None):
     gives the user-facing (batch, R, C) (or (R, C)) array."""
     if kind_torch:
         import torch
-        td = {np.complex64: torch.complex64, np.float32: torch.float32, np.float64: torch.float64,
+        td = {np.complex64: torch.complex64, np.complex128: torch.complex128, np.float32: torch.float32, np.float64: torch.float64,
               np.int32: torch.int32}[np_dtype]
         buf = torch.empty((batch, Cc, R), dtype=td, device=device)
         return buf.data_ptr(), (lambda sq: (buf.transpose(1, 2)[0] if sq else buf.transpose(1, 2)))
@@ -523,38 +523,51 @@ def omp_kron(Af, Bf, y, m, *, ctx=None):
     return fx(single)[..., 0], fi(single)[..., 0]
 
 
+def _is_c128(x):
+    return str(getattr(x, "dtype", "")) in ("complex128", "torch.complex128")
+
+
 def vamp(y, A, sigma, L, *, nit=100, ctx=None):
     """benchmark_algorithms/vamp.m:1 — ``x = vamp(y, A, sigma, L)`` (dense dictionary, min(M, N) <= 2048:
     the drivers' 512 x 512 ``kron((B*B').', A)`` included).
-    ``y``: (M,) or (batch, M).  ``nit`` = 100 is what the reference always runs."""
-    a_A = _Arg(A, np.complex64, "A")
+    ``y``: (M,) or (batch, M).  ``nit`` = 100 is what the reference always runs.
+
+    complex128 inputs (``y`` and ``A``) take ``jstsp_vamp_c64``: float64 storage and arithmetic on the device, which
+    reproduces the reference's output at nit = 100 per trial (csrc/vamp64.hip); complex64 inputs the fp32-storage path."""
+    f64 = _is_c128(A) and _is_c128(y)
+    cdt = np.complex128 if f64 else np.complex64
+    a_A = _Arg(A, cdt, "A")
     tor = _is_torch(y)
     single = y.ndim == 1
     y3 = (y.reshape(1, -1, 1) if single else y.reshape(y.shape[0], -1, 1))
     if tor:
         y3 = colmajor(y3)
-    a_y = _Arg(y3, np.complex64, "y")
+    a_y = _Arg(y3, cdt, "y")
     batch, M, N = a_y.batch, a_A.R, a_A.C
     if a_y.R != M:
         raise ValueError("length(y) must equal size(A,1)")
     c, mem, dev = _ctx_for([a_A, a_y], ctx)
-    px, fx = _out(mem == DEVICE, batch, N, 1, np.complex64, dev)
-    check(c._lib.jstsp_vamp_c32(c.handle, M, N, batch, a_y.ptr, a_A.ptr, _shared_stride(a_A, M * N, batch, "A"),
-                                float(sigma), float(L), int(nit), px, mem), "jstsp_vamp_c32")
+    px, fx = _out(mem == DEVICE, batch, N, 1, cdt, dev)
+    fn = c._lib.jstsp_vamp_c64 if f64 else c._lib.jstsp_vamp_c32
+    check(fn(c.handle, M, N, batch, a_y.ptr, a_A.ptr, _shared_stride(a_A, M * N, batch, "A"),
+             float(sigma), float(L), int(nit), px, mem), "jstsp_vamp_c64" if f64 else "jstsp_vamp_c32")
     return fx(single)[..., 0]
 
 
 def vamp_kron(Y, Af, Gb, sigma, L, *, nit=100, ctx=None):
     """``vamp(vec(Y), kron(Gb.', Af), sigma, L)`` without forming the dictionary — the call of
-    plot_errorVSsnr.m:79-80,100 with ``Gb = B*B'``, ``Y = Y_hbf*B'``.  Returns X (Gr x G2), x = vec(X)."""
-    a_Y, a_A, a_G = _Arg(Y, np.complex64, "Y"), _Arg(Af, np.complex64, "Af"), _Arg(Gb, np.complex64, "Gb")
+    plot_errorVSsnr.m:79-80,100 with ``Gb = B*B'``, ``Y = Y_hbf*B'``.  Returns X (Gr x G2), x = vec(X).
+    complex128 inputs (all three) take the float64 path ``jstsp_vamp_kron_c64`` (see ``vamp``)."""
+    f64 = _is_c128(Y) and _is_c128(Af) and _is_c128(Gb)
+    cdt = np.complex128 if f64 else np.complex64
+    a_Y, a_A, a_G = _Arg(Y, cdt, "Y"), _Arg(Af, cdt, "Af"), _Arg(Gb, cdt, "Gb")
     batch, Na, G2, Gr = a_Y.batch, a_Y.R, a_Y.C, a_A.C
     if a_A.R != Na or (a_G.R, a_G.C) != (G2, G2):
         raise ValueError("shape mismatch")
     c, mem, dev = _ctx_for([a_Y, a_A, a_G], ctx)
-    px, fx = _out(mem == DEVICE, batch, Gr, G2, np.complex64, dev)
-    check(c._lib.jstsp_vamp_kron_c32(c.handle, Na, Gr, G2, batch, a_Y.ptr, a_A.ptr,
-                                     _shared_stride(a_A, Na * Gr, batch, "Af"), a_G.ptr,
-                                     _shared_stride(a_G, G2 * G2, batch, "Gb"), float(sigma), float(L), int(nit), px,
-                                     mem), "jstsp_vamp_kron_c32")
+    px, fx = _out(mem == DEVICE, batch, Gr, G2, cdt, dev)
+    fn = c._lib.jstsp_vamp_kron_c64 if f64 else c._lib.jstsp_vamp_kron_c32
+    check(fn(c.handle, Na, Gr, G2, batch, a_Y.ptr, a_A.ptr, _shared_stride(a_A, Na * Gr, batch, "Af"), a_G.ptr,
+             _shared_stride(a_G, G2 * G2, batch, "Gb"), float(sigma), float(L), int(nit), px, mem),
+          "jstsp_vamp_kron_c64" if f64 else "jstsp_vamp_kron_c32")
     return fx(not a_Y.batched)

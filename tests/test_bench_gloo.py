@@ -68,3 +68,35 @@ def test_sweep_mode_two_ranks_equals_one_rank():
     np.testing.assert_allclose(two["mean_nmse_angles"], one["mean_nmse_angles"], rtol=0, atol=1e-6)
     assert len(set(two["mean_nmse_proposed"])) > 3             # the points differ: the stub scored real, per-key inputs
     assert abs(two["value"] - 2 * 11 * 3 / (two["ms_per_step"] * 1e-3)) / two["value"] < 1e-2
+
+
+@pytest.mark.timeout(900)
+def test_sweep_mode_eight_ranks_5005_items_uneven_blocks_equal_one_rank():
+    """The driver's 8-GPU command line (BASELINE configs[3]: plot_errorVSsnr.m:48-51,170 sharded over 8 ranks) under gloo: 11 points x
+    455 realisations = 5005 (point, trial) items (the reference-native shape: the CPU builder of the stub makes real inputs per key,
+    full-size ones would take 20 minutes here) over 8 ranks = blocks of 626 / 625 items, walked in calls of at most 48 trials - the
+    last call of a rank is ragged, and a rank's block straddles sweep points.  Per-point means identical to the 1-rank run."""
+    args = ["--sweep", "--small", "--sweep-trials", "455", "--batch", "48"]
+    eight = _run(8, args)
+    one = _run(1, args)
+    assert eight["n_gpus"] == 8 and one["n_gpus"] == 1 and eight["scaling"] == "strong" and eight["data"] == "stub"
+    assert eight["config"]["parallelism"].endswith("dp8")
+    assert len(eight["snr_db"]) == 11 and eight["snr_db"] == one["snr_db"]
+    np.testing.assert_allclose(eight["mean_nmse_proposed"], one["mean_nmse_proposed"], rtol=0, atol=1e-6)   # (6 decimals in the line)
+    np.testing.assert_allclose(eight["mean_nmse_angles"], one["mean_nmse_angles"], rtol=0, atol=1e-6)
+    assert abs(eight["value"] - 2 * 11 * 455 / (eight["ms_per_step"] * 1e-3)) / eight["value"] < 1e-2
+
+
+def test_eight_gpus_requested_on_a_smaller_node_exits_2_before_touching_the_gpu():
+    """`python bench.py --gpus 8` without a launcher on a node with fewer GPUs (here: none): exit code 2, a message on stderr, no
+    JSON line - decided from torch.cuda.device_count(), which does not initialise the GPU (bench.py: launch_ranks)."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "JSTSP_BENCH_HOOKS"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this node has 8 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--sweep"], env=env, capture_output=True, text=True,
+                       timeout=300, cwd=ROOT)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "--gpus 8 requested" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
