@@ -44,11 +44,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Translation units compiled WITH packed fp32 (round 6, tools/probe/pk_jacobi_race.py): none by default; JSTSP_PK_FP32_FILES=a.hip,b.hip
+# for the experiment
+PK_FP32_FILES = set(f for f in os.environ.get("JSTSP_PK_FP32_FILES", "").split(",") if f)
+
+
 def _compile(src):
     obj = os.path.join(CSRC, src[:-4] + ("_xp.o" if XP else ".o"))
     path = os.path.join(CSRC, src)
-    if _stale(obj, [path] + _headers()):
-        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", path, "-o", obj]
+    flags = [f for f in FLAGS if f not in ("-Xclang", "-target-feature", "-packed-fp32-ops")] if src in PK_FP32_FILES else FLAGS
+    if _stale(obj, [path] + _headers()) or src in PK_FP32_FILES:
+        cmd = [HIPCC] + flags + ["-x", "hip", "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

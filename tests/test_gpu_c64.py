@@ -180,14 +180,12 @@ def test_benchmark_algorithms_c64():
     xo = np.empty(batch * Nv, complex)
     _lib.check(lib.jstsp_vamp_c64(ctx.handle, Mv, Nv, batch, _p(np.ascontiguousarray(yv)), _p(_f(Av)), 0, 1.0, 4.0, 5, _p(xo), HOST))
     for t in range(batch):
-        assert rel_err(xo.reshape(batch, Nv)[t], V.vamp_literal(yv[t], Av, 1.0, 4.0, nit=5)) < 2e-4
-    # float-representable doubles: the _c32 result, widened
-    yr, Ar = yv.astype(np.complex64), Av.astype(np.complex64)
-    _lib.check(lib.jstsp_vamp_c64(ctx.handle, Mv, Nv, batch, _p(np.ascontiguousarray(yr.astype(complex))), _p(_f(Ar.astype(complex))), 0,
-                                  1.0, 4.0, 100, _p(xo), HOST))
-    x32 = np.empty(batch * Nv, np.complex64)
-    _lib.check(lib.jstsp_vamp_c32(ctx.handle, Mv, Nv, batch, _p(np.ascontiguousarray(yr)), _p(_f(Ar)), 0, 1.0, 4.0, 100, _p(x32), HOST))
-    assert np.array_equal(xo, x32.astype(complex))
+        assert rel_err(xo.reshape(batch, Nv)[t], V.vamp_literal(yv[t], Av, 1.0, 4.0, nit=5)) < 1e-10      # (float64 on the device since round 6)
+    # the reference's operating point, nit = 100: the _c64 entry computes in float64 (csrc/vamp64.hip) and follows the literal
+    # float64 restatement per trial; the _c32 entry on the same (float-representable) inputs agrees statistically only
+    _lib.check(lib.jstsp_vamp_c64(ctx.handle, Mv, Nv, batch, _p(np.ascontiguousarray(yv)), _p(_f(Av)), 0, 1.0, 4.0, 100, _p(xo), HOST))
+    for t in range(batch):
+        assert rel_err(xo.reshape(batch, Nv)[t], V.vamp_literal(yv[t], Av, 1.0, 4.0, nit=100)) < 1e-5
 
 
 def test_c64_device_memory_stays_asynchronous_and_matches_host():
