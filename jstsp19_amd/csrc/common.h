@@ -94,6 +94,7 @@ struct Tuning {
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     JSTSP_XP gram_refine = 1;    // (experiments build) JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
     int bj_mask = 1;        // JSTSP_BJ_MASK: 0 the block Jacobi above order 128 without compute-unit masks (its sub-problems then compete with the panel products for units)
+    JSTSP_XP lz_defer = 1;       // (experiments build) JSTSP_LZ_DEFER: 0 the lambda_max runs of convergence_error inside the iteration loop (rounds 2-5)
     JSTSP_XP bj_trace = 0;       // (experiments build) JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
 };
 const Tuning &tune();       // the calling thread's setting, as parsed by the API call in progress
@@ -258,7 +259,7 @@ struct jstsp_ctx {
     // ev[] themselves - an SVT of order > 128 on a side stream of proposed_algorithm - and must not re-record their events)
     hipStream_t bj_stream[3] = {nullptr, nullptr, nullptr};
     hipEvent_t bj_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace jstsp {
@@ -367,7 +368,8 @@ int hermitian_fill_lower(jstsp_ctx *ctx, float2 *G, long long sGt, int n, int co
 // skip_prm != nullptr: problems with prm[t].tauY_rho <= 2^-27 amax[t] are skipped (see jacobi2_kernel)
 int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int cols, int count, int nsplit,
                  const uint32_t *amax, float2 *Gpart, const TrialParams *skip_prm = nullptr, const float2 *Z2 = nullptr,
-                 const TrialParams *zprm = nullptr);     // Z2: Gram of Z - zprm[t].irho * Z2 (same layout as Z)
+                 const TrialParams *zprm = nullptr,      // Z2: Gram of Z - zprm[t].irho * Z2 (same layout as Z)
+                 bool norm_only = false);                // the Gram's only use is its lambda_max in convergence_error: high f16 plane only
 // G_x = X X^H, G_v = V1 V1^H, G_z = (X - V1/rho)(X - V1/rho)^H in one pass over X and V1 (rows <= 64)
 int launch_hgram3(jstsp_ctx *ctx, const float2 *X, const float2 *V1, long long sZt, int rows, int cols, int count, int nsplit,
                   const uint32_t *xmax, const uint32_t *vmax, const uint32_t *zmax, const TrialParams *prm, float2 *Gz,

@@ -47,6 +47,7 @@ void load_tuning()
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     t.rv_comp = env_int("JSTSP_RV_COMP", t.rv_comp);
+    t.lz_defer = env_int("JSTSP_LZ_DEFER", t.lz_defer);
 #endif
     g_tune = t;
 }
@@ -248,12 +249,12 @@ int gram_partials(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZ
 }
 
 int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long long sZt, int t0, int count,
-                        const uint32_t *amax, const TrialParams *skip_prm, const float2 *Z2, const TrialParams *zprm)
+                        const uint32_t *amax, const TrialParams *skip_prm, const float2 *Z2, const TrialParams *zprm, bool norm_only)
 {
     if (amax && w.left && w.n <= 64)       // split-f16 path: amax[t0 + i] bounds problem t0 + i
         return launch_hgram(ctx, Z + (long long)t0 * sZt, sZt, w.rows, w.cols, count, w.nsplit, amax + t0,
                             w.Gpart + (long long)t0 * w.n * w.n * w.nsplit, skip_prm ? skip_prm + t0 : nullptr,
-                            Z2 ? Z2 + (long long)t0 * sZt : nullptr, zprm ? zprm + t0 : nullptr);
+                            Z2 ? Z2 + (long long)t0 * sZt : nullptr, zprm ? zprm + t0 : nullptr, norm_only);
     JSTSP_REQUIRE(!Z2, JSTSP_E_ARG, "gram_partials_range: on-the-fly Z needs the split-f16 Gram path");
     const Mat Zm{Z + (long long)t0 * sZt, sZt, w.rows};
     const long long sG = (long long)w.n * w.n;
@@ -358,7 +359,7 @@ int ensure_side_streams(jstsp_ctx *ctx)
     //  svt chain no better - rounds 2 and 3; the switch for it is gone)
     for (int i = 0; i < 2; ++i)
         if (!ctx->side[i]) JSTSP_HIP(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 10; ++i)
         if (!ctx->ev[i]) JSTSP_HIP(hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming));
     return 0;
 }
@@ -538,7 +539,7 @@ int jstsp_destroy(jstsp_ctx *ctx)
     for (int i = 0; i < 3; ++i) if (ctx->bj_stream[i]) { (void)hipStreamSynchronize(ctx->bj_stream[i]); (void)hipStreamDestroy(ctx->bj_stream[i]); }
     for (int i = 0; i < 6; ++i) if (ctx->bj_ev[i]) (void)hipEventDestroy(ctx->bj_ev[i]);
     for (int i = 0; i < 4; ++i) if (ctx->cu_stream[i]) { (void)hipStreamSynchronize(ctx->cu_stream[i]); (void)hipStreamDestroy(ctx->cu_stream[i]); }
-    for (int i = 0; i < 8; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 10; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->diag) (void)hipFree(ctx->diag);
     if (ctx->lz_mismatch) (void)hipFree(ctx->lz_mismatch);

@@ -185,7 +185,7 @@ def test_benchmark_algorithms_c64():
     # float64 restatement per trial; the _c32 entry on the same (float-representable) inputs agrees statistically only
     _lib.check(lib.jstsp_vamp_c64(ctx.handle, Mv, Nv, batch, _p(np.ascontiguousarray(yv)), _p(_f(Av)), 0, 1.0, 4.0, 100, _p(xo), HOST))
     for t in range(batch):
-        assert rel_err(xo.reshape(batch, Nv)[t], V.vamp_literal(yv[t], Av, 1.0, 4.0, nit=100)) < 1e-5
+        assert rel_err(xo.reshape(batch, Nv)[t], V.vamp_literal(yv[t], Av, 1.0, 4.0, nit=100)) < 1e-8      # (this small system is not chaotic)
 
 
 def test_c64_device_memory_stays_asynchronous_and_matches_host():
