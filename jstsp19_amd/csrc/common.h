@@ -94,7 +94,6 @@ struct Tuning {
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     JSTSP_XP gram_refine = 1;    // (experiments build) JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
     int bj_mask = 1;        // JSTSP_BJ_MASK: 0 the block Jacobi above order 128 without compute-unit masks (its sub-problems then compete with the panel products for units)
-    JSTSP_XP lz_defer = 1;       // (experiments build) JSTSP_LZ_DEFER: 0 the lambda_max runs of convergence_error inside the iteration loop (rounds 2-5)
     JSTSP_XP bj_trace = 0;       // (experiments build) JSTSP_BJ_TRACE: 1 print the block Jacobi's convergence per sweep (stderr)
 };
 const Tuning &tune();       // the calling thread's setting, as parsed by the API call in progress

@@ -631,16 +631,15 @@ __device__ __forceinline__ float lz_twisted(const float *sd, const float *se, in
     return nrm;
 }
 
-// (the body of one lambda_max call of a workgroup: lanczos_lmax_kernel runs it once, lanczos_chain_kernel once per step of a
-//  sequence - every `return` below is uniform over the workgroup)
-template <int NE, int NW>
-__device__ __forceinline__ void lanczos_lmax_body(char *smem_raw, int n, const float2 *Gpart, long long sGt, int nsplit,
-                                                  long long sGs, float *lam_out, float2 *wx, int *wst,
-                                                  unsigned *wmis, int call, int vperiod, float tol)
+template <int NE, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void lanczos_lmax_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
+                                                           long long sGs, float *lam_out, float2 *wx, int *wst,
+                                                           unsigned *wmis, int call, int vperiod, float tol)
 {
     constexpr int R = NE / 64;              // components per lane
     constexpr int KW = NE / NW;             // columns of G per wave
     constexpr int NT = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     // LDS: the exchange of the partial products, the tridiagonal matrix, and (warm start) the first LZ_KMAX Lanczos vectors
     // (round 3: the matrix itself is no longer staged here - 33 KiB per workgroup for the kernel's whole life kept
     // eigen-decomposition workgroups, 101 KiB, off the CU)
@@ -937,37 +936,6 @@ __device__ __forceinline__ void lanczos_lmax_body(char *smem_raw, int n, const f
     }
 }
 
-template <int NE, int NW, int OCC>
-__global__ __launch_bounds__(64 * NW, OCC) void lanczos_lmax_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
-                                                           long long sGs, float *lam_out, float2 *wx, int *wst,
-                                                           unsigned *wmis, int call, int vperiod, float tol)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    lanczos_lmax_body<NE, NW>(smem_raw, n, Gpart, sGt, nsplit, sGs, lam_out, wx, wst, wmis, call, vperiod, tol);
-}
-
-// Round 6: the lambda_max of `steps` CONSECUTIVE calls of one matrix sequence in one launch - matrix t of step s is warm-started from
-// matrix t of step s - 1 exactly as `steps` launches of lanczos_lmax_kernel would be (same body, same order: the same bits), but the
-// chain of a workgroup runs without kernel boundaries and the solver's iteration loop is rid of two launches per iteration
-// (proposed.hip: the norms of convergence_error are not on the critical path of an iteration, only their Grams are).
-// Gpart / lam_out of step s sit sGstep / sLstep elements after those of step s - 1; the call number of step s is call0 + s.
-template <int NE, int NW, int OCC>
-__global__ __launch_bounds__(64 * NW, OCC) void lanczos_chain_kernel(int n, const float2 *Gpart, long long sGt, int nsplit,
-                                                            long long sGs, float *lam_out, float2 *wx, int *wst, unsigned *wmis,
-                                                            int call0, int vperiod, float tol, int steps, long long sGstep,
-                                                            long long sLstep)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    for (int s = 0; s < steps; ++s) {
-        if (s > 0) {                        // the Ritz vector / state words wave 0 stored are read by every wave of the next step
-            __threadfence_block();
-            __syncthreads();
-        }
-        lanczos_lmax_body<NE, NW>(smem_raw, n, Gpart + (long long)s * sGstep, sGt, nsplit, sGs, lam_out + (long long)s * sLstep, wx, wst,
-                                  wmis, call0 + s, vperiod, tol);
-    }
-}
-
 
 template <int NE> static size_t jacobi2_smem()
 {
@@ -1047,31 +1015,6 @@ static int launch_lanczos_t(jstsp_ctx *ctx, int n, int batch, const float2 *Gpar
 }
 
 int lanczos_ne(int n) { return n <= 64 ? 64 : 128; }
-
-// lambda_max of `steps` consecutive calls (n <= 64, warm-started Lanczos): see lanczos_chain_kernel.  Any other configuration: the
-// calls one by one.
-int launch_lmax_chain(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs, float *lam_out,
-                      const LanczosWarm *lw, int first, int steps, long long sGstep, long long sLstep, int call0)
-{
-    const bool warm = lw && lw->x && lw->ne == 64 && tune().lanczos_warm != 0;
-    if (n > 64 || !tune().lanczos || !warm) {
-        for (int s = 0; s < steps; ++s) {
-            LanczosWarm l2;
-            if (lw) { l2 = *lw; l2.call = call0 + s; }
-            JSTSP_TRY(launch_lmax(ctx, n, batch, Gpart + (long long)s * sGstep, sGt, nsplit, sGs, lam_out + (long long)s * sLstep, true,
-                                  lw ? &l2 : nullptr, first));
-        }
-        return 0;
-    }
-    constexpr int NE = 64, NW = 4;
-    const size_t sh = (size_t)2 * NW * NE * sizeof(float2) + 16 + (size_t)2 * NE * sizeof(float) + 12 * sizeof(int) +
-                      (size_t)3 * NE * sizeof(float) + 16 + (size_t)LzKmax<NE>::value * NE * sizeof(float2);
-    JSTSP_HIP(hipFuncSetAttribute((const void *)lanczos_chain_kernel<NE, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh));
-    hipLaunchKernelGGL((lanczos_chain_kernel<NE, NW, 1>), dim3(batch), dim3(64 * NW), sh, ctx->stream, n, Gpart, sGt, nsplit, sGs, lam_out,
-                       lw->x + (size_t)first * NE, lw->state + first, lw->mismatch, call0, tune().lanczos_verify, 1e-5f, steps, sGstep, sLstep);
-    JSTSP_HIP(hipGetLastError());
-    return 0;
-}
 
 // lam_out[t] = lambda_max of the n x n Hermitian matrix sum_s Gpart[t][s]; n <= 128.
 // lanczos: the four-wave Lanczos kernel (1e-6 relative; the ADMM loops' convergence_error) instead of Householder + Sturm;

@@ -116,9 +116,14 @@ int host_toeplitz_stage(jstsp_ctx *ctx, const T *Bh, int G2, int M, int nB, floa
         }
     };
     {
+        // (thread creation can throw - std::system_error at a thread / pid limit of the cgroup - and this is below an extern "C"
+        //  entry: the stripes whose thread did not start are worked off here, nothing propagates)
         std::vector<std::thread> th;
-        for (int k = 1; k < nth; ++k) th.emplace_back(work, k);
-        work(0);
+        std::vector<int> mine{0};
+        for (int k = 1; k < nth; ++k) {
+            try { th.emplace_back(work, k); } catch (...) { mine.push_back(k); }
+        }
+        for (int k : mine) work(k);
         for (auto &x : th) x.join();
     }
     if (stop.load()) return 0;                                // one dictionary without the structure: the plain upload

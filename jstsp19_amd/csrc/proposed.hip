@@ -40,8 +40,6 @@ struct ProposedWS {
     int32_t *rank;
     double *ce;
     float *lam;            // 3 * batch
-    float2 *lzG = nullptr; // deferred norms (round 6): Gram partials of [X | V1 | V2] of 2 x LZ_CHUNK iterations
-    float *lzLam = nullptr;    // lambda_max of one chunk: [LZ_CHUNK][3 * batch]
     GramWS gz, gn;         // SVT of Z; spectral norms of V1, V2, X
     // split-f16 path (hgemm.hip): B packed once per solve in both orientations, per-problem operand maxima
     bool h2 = false;
@@ -53,11 +51,6 @@ struct ProposedWS {
     HPack Wp;              // the synthesis' a operand A S, re-packed every iteration (64 j-tiles would each split it)
     uint32_t *pmax = nullptr;
 };
-
-// Deferred norms of convergence_error(:,1:2) (round 6): iterations per chained lambda_max launch, and the shapes that use it (the
-// one-pass iteration with the three-Gram pass; decided again per call where the path is chosen)
-constexpr int LZ_CHUNK = 10;
-static bool lz_defer_shape(int N, int M, int G2) { return fused_shape_ok(N, M, G2, 1); }
 
 // k-split of the fused three-Gram pass (hgram3_kernel: G_x, G_v1 and G_z from one read of X and V1): chunks of at most
 // 1024 columns; 0 = that pass is not used for this shape (then every Gram workspace picks its own split)
@@ -87,8 +80,6 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     const int ns3 = gram3_nsplit(N, M, G2, want_ce);
     b += GramWS::bytes(N, M, batch, true, ns3);
     if (want_ce) b += GramWS::bytes(N, M, 3 * batch, false, ns3);
-    if (want_ce && lz_defer_shape(N, M, G2))
-        b += rnd256(2 * (size_t)LZ_CHUNK * 3 * batch * std::max(ns3, 1) * (size_t)N * N * sizeof(float2)) + rnd256((size_t)LZ_CHUNK * 3 * batch * sizeof(float)) + 512;
     if (use_hgemm(N, G2, M))
         b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(8 * batch * sizeof(uint32_t)) +
              hgemm_pack_bytes(G2, N, batch);
@@ -124,14 +115,6 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
     const int ns3 = gram3_nsplit(N, M, G2, want_ce);
     JSTSP_TRY(w.gz.alloc(a, N, M, batch, true, ns3));
     if (want_ce) JSTSP_TRY(w.gn.alloc(a, N, M, 3 * batch, false, ns3));
-    // Round 6: the norms of convergence_error(:,1:2) leave the iteration loop on the one-pass path - their three Grams are kept for
-    // LZ_CHUNK iterations (two buffers) and lambda_max of a whole chunk is ONE chained launch (eig2.hip: lanczos_chain_kernel)
-    w.lzG = nullptr; w.lzLam = nullptr;
-    if (want_ce && lz_defer_shape(N, M, G2)) {
-        w.lzG = a.get<float2>(2 * (size_t)LZ_CHUNK * 3 * batch * w.gn.nsplit * (size_t)w.gn.n * w.gn.n);
-        w.lzLam = a.get<float>((size_t)LZ_CHUNK * 3 * batch);
-        JSTSP_REQUIRE(w.lzG && w.lzLam, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
-    }
     w.h2 = use_hgemm(N, G2, M);
     if (w.h2) {
         // operand maxima of one iteration, one block zeroed once per iteration: kmax | X | V1 | V2 | Znext | wmax | pmax x2.
@@ -503,15 +486,6 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     // norm partials, the whole side chain behind the step's head, other gate positions, stream priorities) are gone from
     // the code; their numbers are in DESIGN.md.
     hipEvent_t ev_q1 = ctx->ev[7];
-    // Round 6: on the one-pass path the lambda_max runs of convergence_error(:,1:2) leave the loop.  Only the Grams must be taken
-    // while X, V1, V2 of an iteration exist; their partial sums are kept per iteration (slot it % (2 LZ_CHUNK)) and every
-    // LZ_CHUNK iterations ONE chained launch on the side stream s2 runs the warm-started Lanczos of the whole chunk (matrix t of
-    // iteration i from matrix t of iteration i - 1, as before: the same values), followed by the ratios.  Two launches per
-    // iteration (82 us each alone, 183 co-running) become one per ten iterations.
-    const bool lzdefer = fusedp && zfly && want_ce && w.lzG && w.gn.n <= 64 && tn.lanczos != 0 && tn.lanczos_warm != 0 && tn.lz_defer != 0;
-    const size_t lz_slot = (size_t)3 * batch * w.gn.nsplit * (size_t)w.gn.n * w.gn.n;      // Gram partials of one iteration
-    auto gn_at = [&](int it_) { GramWS g2 = w.gn; if (lzdefer) g2.Gpart = w.lzG + (size_t)(it_ % (2 * LZ_CHUNK)) * lz_slot; return g2; };
-    hipEvent_t ev_chain[2] = {ctx->ev[8], ctx->ev[9]};
     // convergence_error(:,1:2): lambda_max of three Grams per trial and iteration, each warm-started from its own Ritz vector
     // of the previous iteration (eig2.hip); the record starts empty
     if (want_ce) JSTSP_TRY(lanczos_warm_reset(ctx, w.gn));
@@ -564,18 +538,15 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             if (zfly) {
               if (stage != 2) {
                 // (the spectral norms of X, V1 of the previous iteration read the G_x, G_v1 partials this pass overwrites)
-                if (fusedp && it > 0 && !lzdefer) JSTSP_HIP(hipStreamWaitEvent(s1, ev_lxv, 0));
-                // (deferred norms: this iteration's slot was last read by the chained launch two chunks ago)
-                if (lzdefer && it % LZ_CHUNK == 0 && it >= 2 * LZ_CHUNK) JSTSP_HIP(hipStreamWaitEvent(s1, ev_chain[(it / LZ_CHUNK) & 1], 0));
+                if (fusedp && it > 0) JSTSP_HIP(hipStreamWaitEvent(s1, ev_lxv, 0));
                 // (Until the library was compiled without packed-fp32 instructions - see build.py - this pass also had to
                 // wait for the previous iteration's lambda_max kernels: the Lanczos kernel, whose complex arithmetic hipcc had
                 // turned into v_pk_fma_f32 chains, returned different Ritz values when MFMA-heavy waves shared its SIMDs.)
                 // one pass over X and V1: G_x, G_v1 (convergence_error) and G_z of Z = X - V1/rho (next svt)
-                const GramWS gnx = gn_at(it);          // (X, V1 of iteration it: convergence_error(it, 1:2))
                 JSTSP_TRY(launch_hgram3(ctx, w.X, w.V1, snm, N, M, batch, w.gz.nsplit, w.nmax, w.nmax + batch, w.zmax,
-                                        w.prm, w.gz.Gpart, gnx.Gpart, gnx.Gpart + (size_t)batch * N * N * w.gn.nsplit));
+                                        w.prm, w.gz.Gpart, w.gn.Gpart, w.gn.Gpart + (size_t)batch * N * N * w.gn.nsplit));
                 JSTSP_HIP(hipEventRecord(ev_gxv, s1));
-                if (fusedp && !lzdefer) {       // lambda_max of G_x, G_v1 now (beside the pass), not after it with G_v2: the next Gram
+                if (fusedp) {       // lambda_max of G_x, G_v1 now (beside the pass), not after it with G_v2: the next Gram
                                     // pass then never waits for them
                     JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));
                     StreamScope sc2(ctx, s2);
@@ -601,7 +572,7 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         if (want_ce && !(zfly && it + 1 < Imax)) {              // s2: Gram of [X | V1]
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_x, 0));
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, gn_at(it), w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr, nullptr, nullptr, nullptr, true));
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 0, 2 * batch, hmax ? w.nmax : nullptr, nullptr, nullptr, nullptr, true));      // (norms only: high f16 plane)
             JSTSP_HIP(hipEventRecord(ev_gxv, s2));
         }
         // -- sub 3: res = K2'*k - R*v                                                        (:47)
@@ -764,26 +735,11 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             JSTSP_HIP(hipStreamWaitEvent(s2, ev_c, 0));
             if (zfly) JSTSP_HIP(hipStreamWaitEvent(s2, ev_gxv, 0));      // G_x, G_v1 came from the side stream s1
             StreamScope sc(ctx, s2);
-            JSTSP_TRY(gram_partials_range(ctx, gn_at(it), w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr, nullptr, nullptr, nullptr, true));
+            JSTSP_TRY(gram_partials_range(ctx, w.gn, w.X, snm, 2 * batch, batch, hmax ? w.nmax : nullptr, nullptr, nullptr, nullptr, true));
             JSTSP_HIP(hipEventRecord(ev_gv2, s2));
-            if (lzdefer) {
-                // the chunk [c0, it] is complete: one chained launch for the lambda_max of its 3 x batch matrix sequences, then the ratios
-                if ((it + 1) % LZ_CHUNK == 0 || it + 1 == Imax) {
-                    const int c0 = (it / LZ_CHUNK) * LZ_CHUNK, steps = it - c0 + 1;
-                    const long long sGm = (long long)w.gn.n * w.gn.n;
-                    JSTSP_TRY(launch_lmax_chain(ctx, w.gn.n, 3 * batch, w.lzG + (size_t)(c0 % (2 * LZ_CHUNK)) * lz_slot, sGm * w.gn.nsplit, w.gn.nsplit,
-                                                sGm, w.lzLam, &w.gn.lz, 0, steps, (long long)lz_slot, 3ll * batch, c0));
-                    JSTSP_HIP(hipEventRecord(ev_chain[(c0 / LZ_CHUNK) & 1], s2));
-                    for (int k = 0; k < steps; ++k) {
-                        const float *lm = w.lzLam + (size_t)k * 3 * batch;
-                        JSTSP_TRY(launch_ce_ratio(ctx, batch, lm + batch, lm + 2 * batch, lm, w.ce, Imax, c0 + k));
-                    }
-                }
-            } else {
             if (fusedp && zfly && it + 1 < Imax) JSTSP_TRY(lmax_from_partials_range(ctx, w.gn, 2 * batch, batch, w.lam, true));
             else JSTSP_TRY(lmax_from_partials(ctx, w.gn, w.lam, true));
             JSTSP_TRY(launch_ce_ratio(ctx, batch, w.lam + batch, w.lam + 2 * batch, w.lam, w.ce, Imax, it));
-            }
             JSTSP_HIP(hipEventRecord(ev_ce, s2));
         }
     }

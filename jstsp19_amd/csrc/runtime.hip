@@ -47,7 +47,6 @@ void load_tuning()
     t.grad_head = env_int("JSTSP_GRAD_HEAD", t.grad_head);
     t.rv_always = env_int("JSTSP_RV_ALWAYS", t.rv_always);
     t.rv_comp = env_int("JSTSP_RV_COMP", t.rv_comp);
-    t.lz_defer = env_int("JSTSP_LZ_DEFER", t.lz_defer);
 #endif
     g_tune = t;
 }

@@ -79,8 +79,6 @@ int gram_partials_range(jstsp_ctx *ctx, const GramWS &w, const float2 *Z, long l
 // lam[t] = lambda_max of the Gram partials already in the workspace, all w.batch problems
 // The warm-start record of a norm workspace: all vectors invalid, the context's mismatch counter zeroed (on ctx->stream;
 // once per solve, before the first lambda_max of its loop).  `call` of the record is set by the loop's owner.
-int launch_lmax_chain(jstsp_ctx *ctx, int n, int batch, const float2 *Gpart, long long sGt, int nsplit, long long sGs, float *lam_out,
-                      const LanczosWarm *lw, int first, int steps, long long sGstep, long long sLstep, int call0);
 int lanczos_warm_reset(jstsp_ctx *ctx, const GramWS &w);
 int lmax_from_partials(jstsp_ctx *ctx, const GramWS &w, float *lam, bool lanczos = false);
 int lmax_from_partials_range(jstsp_ctx *ctx, const GramWS &w, int first, int count, float *lam, bool lanczos);   // matrices [first, first + count)

@@ -5,6 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import jstsp19_amd as J
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+Imax = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 N, M, Gr, G2 = 64, 65536, 64, 4096
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(5)
@@ -28,8 +29,9 @@ fro2 = (subY.abs() ** 2).sum(dim=(1, 2)).double().cpu().numpy()
 tY = 1.0 / fro2; tS = np.full(batch, 1e-3); rho = np.full(batch, 0.2)
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    S, Y, ce = J.proposed_algorithm_angles(cm(subY), cm(Om), indx, A, Bt, 20, tY, tS, rho, "approximate", None)
+    S, Y, ce = J.proposed_algorithm_angles(cm(subY), cm(Om), indx, A, Bt, Imax, tY, tS, rho, "approximate", None)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("angles, block-Toeplitz pilots (block %d), batch %d, 20 iterations: %.3f s" % (J.default_context(0).last_dictionary_block(), batch, dt), flush=True)
+    print("angles, block-Toeplitz pilots (block %d), batch %d, %d iterations: %.3f s = %.2f channel-estimates/s per GPU" % (
+        J.default_context(0).last_dictionary_block(), batch, Imax, dt, batch / dt), flush=True)
 import hashlib
 print("sha1 S %s  Y %s" % (hashlib.sha1(S.cpu().numpy().tobytes()).hexdigest()[:16], hashlib.sha1(Y.cpu().numpy().tobytes()).hexdigest()[:16]))
