@@ -9,6 +9,10 @@ inputs are built by the library's own counter-based generator, the float64 side 
     python tools/parity_tail.py --seed 20260105 --trials 256 --bench-trials 0 --angles-trials 128 \
            --angles-snrs=-15,-12,-9,-6,-3,0,3,6,9,12 --variants default,two_output --out gpurun_out/parity_heldout
     python tests/golden/make_fullsize_port_fixture.py gpurun_out/parity_heldout heldout
+    # the second held-out fixture (round 6; seed 20261003, generated ONCE after the numerics of the round were frozen, same recipe)
+    python tools/parity_tail.py --seed 20261003 --trials 256 --bench-trials 0 --angles-trials 128 \
+           --angles-snrs=-15,-12,-9,-6,-3,0,3,6,9,12 --variants default,two_output --out gpurun_out/parity_heldout2
+    python tests/golden/make_fullsize_port_fixture.py gpurun_out/parity_heldout2 heldout2
 
 Per group (bench_proposed: the 256 trials of the bench workload, 5 dB, sweep index 0; sweep_proposed: 10 SNR points x 256
 trials of the BASELINE configs[3] sweep; sweep_angles: proposed_algorithm_angles - 64 trials at -15 / 0 / 12 dB in the first
@@ -27,7 +31,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def main(src, name=""):
     z = np.load(os.path.join(src, "fixture.npz"))
     out = {}
-    heldout = name == "heldout"
+    heldout = name.startswith("heldout")
     for g in ("bench_proposed", "sweep_proposed", "sweep_angles"):
         if g + "/nmse_port" not in z.files:
             continue

@@ -144,3 +144,42 @@ def test_heldout_two_output_calls_64_trials_per_point_both_solvers():
         nmse, _ = solve_group(fx, group, rows, want_ce=False, angles=angles, chunk=64)
         d = np.abs(nmse - fx[group + "/nmse_port"][rows])
         assert d.max() < TOL, (group, float(d.max()), int(rows[np.argmax(d)]))
+
+
+# ---- the SECOND held-out fixture (round 6): generator seed 20261003, 10 x 256 proposed_algorithm + 10 x 128 proposed_algorithm_angles
+#      trials, float64 side by oracle/cpu_port.cpp on a GPU box's host (tools/parity_tail.py, recipe in
+#      tests/golden/make_fullsize_port_fixture.py).  Generated ONCE, after the last change of the round that touches S (the round's
+#      later changes - norm Grams on the high f16 plane - touch convergence_error(:,1:2) only); no default was chosen or re-chosen
+#      after looking at it.  The contract is stated as a maximum AND as distribution figures (rms, 99th percentile).
+HELDOUT2 = "fullsize_port_heldout2"
+
+
+def _heldout2():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", HELDOUT2 + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("second held-out fixture not generated")
+    fx = fixture(HELDOUT2)
+    assert int(fx["sweep_proposed/seed"][0]) not in (20190913, 20260105)
+    return fx
+
+
+@pytest.mark.parametrize("want_ce", [True, False], ids=["three_outputs", "two_outputs"])
+def test_heldout2_all_trials_both_call_forms_both_solvers(want_ce):
+    """Every trial of the second held-out set, both call forms (the drivers make the two-output one, plot_errorVSsnr.m:137): 2560
+    proposed_algorithm + 1280 proposed_algorithm_angles solves against float64.  max < 1e-6 (the statement), rms < 2e-7 and the 99th
+    percentile < 6e-7 (the distribution: measured 1.4e-7 / 4.5e-7 on the earlier sets)."""
+    from conftest import check_below
+    fx = _heldout2()
+    for group, angles, nmin in (("sweep_proposed", False, 2560), ("sweep_angles", True, 1280)):
+        n = len(fx[group + "/nmse_port"])
+        assert n >= nmin
+        nmse, ces = solve_group(fx, group, np.arange(n), want_ce=want_ce, angles=angles)
+        d = nmse - fx[group + "/nmse_port"]
+        tag = "heldout2.%s.%s" % (group, "ce" if want_ce else "noce")
+        check_below(tag + ".max", np.abs(d).max(), TOL)
+        check_below(tag + ".rms", np.sqrt(np.mean(d ** 2)), 2e-7)
+        check_below(tag + ".p99", np.quantile(np.abs(d), 0.99), 6e-7)
+        if want_ce:
+            assert check_ce(fx, group, np.arange(n), ces) >= 300
+    import jstsp19_amd as J
+    assert J.default_context(0).last_lanczos_mismatches() == 0

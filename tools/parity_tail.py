@@ -32,7 +32,8 @@ VARIANTS = {                     # name -> (environment, want_ce)
     "two_output": ({}, False),
     "toeplitz1": ({"JSTSP_TOEPLITZ": "1"}, True),        # old pass kernel on the compact image
     "toeplitz0": ({"JSTSP_TOEPLITZ": "0"}, True),        # unstructured path (full tile image)
-    "rv_refresh1": ({"JSTSP_RV_REFRESH": "1"}, True),    # R v recomputed every iteration
+    "rv_refresh1": ({"JSTSP_RV_REFRESH": "1"}, True),    # R v recomputed every iteration (experiments build only since round 6:
+                                                         # JSTSP_EXPERIMENTS_LIB=1, else this variant IS the default)
     "unfused": ({"JSTSP_FUSED": "0"}, True),             # three-kernel iteration
     "fp32_mfma": ({"JSTSP_H2": "0"}, True),              # strict complex-fp32 MFMA path
 }
