@@ -39,7 +39,8 @@ __device__ __forceinline__ f32x16 mma(u32x4 a, u32x4 b, f32x16 c)
 }
 __device__ __forceinline__ u32x4 negu(u32x4 u) { return u ^ 0x80008000u; }
 
-// MODE 0: both phases; 1: phase A only; 2: phase B only
+// MODE 0: both phases; 1: phase A only; 2: phase B only; 3: phase A without its global loads ((A S) fragments loaded once);
+// 4: phase A without its LDS reads (window fragments read once); 5: both phases, (A S) fragments loaded once
 template <int MODE>
 __global__ __launch_bounds__(256) void pass4_products(const u32x4 *__restrict__ E, const u32x4 *__restrict__ AS, float *__restrict__ out, int tiles)
 {
@@ -83,7 +84,10 @@ __global__ __launch_bounds__(256) void pass4_products(const u32x4 *__restrict__ 
     store_window(0, wreg);
     __syncthreads();
 
-    const u32x4 *ast = AS + (size_t)(wg >> 2 & 63) * (32 * 2 * 4 * 64);     // (A S) fragments of "trial" wg / 4: [ks 32][nb2 2][plane 4][lane 64]
+    // the pass's workgroup -> (trial, column range) map: the four column ranges of a trial run on ONE XCD, so that its (A S) fragments
+    // (256 KiB) stay in that XCD's L2 - 8 trials per XCD at a time
+    const int trial = ((wg >> 3) / 4) * 8 + (wg & 7);
+    const u32x4 *ast = AS + (size_t)(trial & 63) * (32 * 2 * 4 * 64);      // [ks 32][nb2 2][plane 4][lane 64]
     auto *lbase = (__attribute__((address_space(3))) unsigned char *)lds;
 
     for (int i = 0; i < tiles; ++i) {
@@ -94,31 +98,42 @@ __global__ __launch_bounds__(256) void pass4_products(const u32x4 *__restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ar[r] = 0.f; ai[r] = 0.f; }
         if (MODE != 2) {
-            u32x4 wf[2][4];
+            constexpr bool NOG = MODE == 3 || MODE == 5, NOL = MODE == 4;
+            constexpr int WD = 3;               // (A S) fragments requested WD - 1 k-steps ahead: one wave per SIMD has nobody to hide an L2 round trip
+            u32x4 wf[WD][4];
             // ONE running byte offset, advanced opaquely per k-step (constant offsets make hipcc materialise - and spill - an address
             // per (k-step, plane) outside the tile loop: fused.hip)
             uint32_t ao = 16u * (uint32_t)(((16 * h) * 2 + nb2) * 256 + l);
             asm volatile("" : "+v"(ao));
 #pragma unroll
-            for (int p = 0; p < 4; ++p) wf[0][p] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(ast) + ao + p * 1024);
+            for (int q = 0; q < WD - 1; ++q) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) wf[q][p] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(ast) + ao + p * 1024);
+                ao += 8192;
+                asm volatile("" : "+v"(ao));
+            }
             int cK = m32 + 7 - 4 * h;
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if (ks + 1 < 16) {
-                    ao += 8192;
-                    asm volatile("" : "+v"(ao));
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) wf[(ks + 1) & 1][p] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(ast) + ao + p * 1024);
-                }
+            u32x4 bfb[2][4];
+            auto rdA = [&](int ks, u32x4 *dst) {
                 // rows g = 256 h + 16 ks + 8 kg ..: delay block ld = 4 h + (ks >> 2), octet 2 (ks & 3) + kg of block 0, column m - ld
                 if ((ks & 3) == 0) { if (ks > 0) cK -= 1; asm volatile("" : "+v"(cK)); }
                 const int oc = (2 * (ks & 3) + kg) ^ sw4(cK);
                 const unsigned char *arow = ebuf + cK * 128 + 16 * oc;
-                u32x4 bf[4];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) bf[p] = *reinterpret_cast<const u32x4 *>(arow + p * EPL);
+                for (int p = 0; p < 4; ++p) dst[p] = *reinterpret_cast<const u32x4 *>(arow + p * EPL);
+            };
+            rdA(0, bfb[0]);
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if (ks + WD - 1 < 16 && !(NOG && i > 0)) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) wf[(ks + WD - 1) % WD][p] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(ast) + ao + p * 1024);
+                    ao += 8192;
+                    asm volatile("" : "+v"(ao));
+                }
+                if (ks + 1 < 16 && !(NOL && i > 0)) rdA(ks + 1, bfb[(ks + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                const u32x4 *wk = wf[ks & 1];
+                const u32x4 *wk = wf[ks % WD], *bf = bfb[ks & 1];
                 const u32x4 nwi_h = negu(wk[2]), nwi_l = negu(wk[3]);
                 ar = mma(bf[0], wk[0], ar); ai = mma(bf[0], wk[2], ai);
                 ar = mma(bf[0], wk[1], ar); ai = mma(bf[0], wk[3], ai);
@@ -132,45 +147,52 @@ __global__ __launch_bounds__(256) void pass4_products(const u32x4 *__restrict__ 
         pr[0] += ar; pi[0] += ai;
         __syncthreads();
         // ================= phase B: P^T (32 g x 32 n blocks: this wave n-half nb2, blocks 8 h .. 8 h + 7) += conj(B)(g, tile) k^T
-        if (MODE != 1) {
+        if (MODE != 1 && MODE != 3 && MODE != 4) {
+            u32x4 kf[2][6];
 #pragma unroll
-            for (int gb = 0; gb < 8; ++gb) {
+            for (int s = 0; s < 2; ++s) {
+                const unsigned char *kp = xch + (((nb2 * 2 + s) * 6) * 64 + l) * 16;
+#pragma unroll
+                for (int p = 0; p < 6; ++p) kf[s][p] = *reinterpret_cast<const u32x4 *>(kp + p * 1024);
+            }
+            const int G = l >> 4, i16 = l & 15;
+            u32x4 bfb[2][4];
+            auto rdB = [&](int st, u32x4 *dst) {
+                const int gb = st >> 1, s = st & 1;
                 const int blk = 8 * h + gb, ld = blk >> 1;                 // 32 rows g: delay ld, rows 32 (blk & 1) .. of block 0
+                // k-index 8 kg + j of k-step s <-> column m = 16 s + 4 kg + (j & 3) + 8 (j >> 2): two transposing reads; lane l, 16-lane
+                // group G: rows g = 32 (blk & 1) + 16 (G & 1) + (l & 15); supplies the address of the four halves g = .. + 4 (l & 3) of
+                // row m = 16 s + 4 kg + ((l & 15) >> 2)
+                const int gl = 32 * (blk & 1) + 16 * (G & 1) + 4 * (i16 & 3);
+                int cB = 4 * kg + (i16 >> 2) + 7 + 16 * s - ld;           // (opaque: no address per (block, step) kept across the tile loop)
+                asm volatile("" : "+v"(cB));
+                unsigned o2[2];
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    // k-index 8 kg + j of k-step s <-> column m = 16 s + 4 kg + (j & 3) + 8 (j >> 2): two transposing reads
-                    // lane l: 16-lane group G = l >> 4: rows g = 32 (blk & 1) + 16 (G & 1) + (l & 15); supplies the address of the four
-                    // halves g = .. + 4 (l & 3) of row m = 16 s + 4 kg + ((l & 15) >> 2)
-                    const int G = l >> 4, i16 = l & 15;
-                    const int gl = 32 * (blk & 1) + 16 * (G & 1) + 4 * (i16 & 3);
-                    int cB = 4 * kg + (i16 >> 2) + 7 + 16 * s - ld;      // (opaque: no address per (block, step) kept across the tile loop)
-                    asm volatile("" : "+v"(cB));
-                    u32x4 bf[4];
-                    unsigned o2[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int cc = cB + 8 * u;
-                        o2[u] = (unsigned)((i & 1) * EBUF + cc * 128 + 16 * ((gl >> 3) ^ sw4(cc)) + 2 * (gl & 7));
-                    }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o2[0] + p * EPL)));
-                        const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o2[1] + p * EPL)));
-                        bf[p] = u32x4{p0.x, p0.y, p1.x, p1.y};
-                    }
-                    const unsigned char *kp = xch + (((nb2 * 2 + s) * 6) * 64 + l) * 16;
-                    const u32x4 k0 = *reinterpret_cast<const u32x4 *>(kp), k1 = *reinterpret_cast<const u32x4 *>(kp + 1024),
-                                k2 = *reinterpret_cast<const u32x4 *>(kp + 2048), k3 = *reinterpret_cast<const u32x4 *>(kp + 3072),
-                                n0 = *reinterpret_cast<const u32x4 *>(kp + 4096), n1 = *reinterpret_cast<const u32x4 *>(kp + 5120);
-                    // re += Br kr + Bi ki ; im += Br ki - Bi kr
-                    pr[gb] = mma(bf[0], k0, pr[gb]); pi[gb] = mma(bf[0], k2, pi[gb]);
-                    pr[gb] = mma(bf[0], k1, pr[gb]); pi[gb] = mma(bf[0], k3, pi[gb]);
-                    pr[gb] = mma(bf[1], k0, pr[gb]); pi[gb] = mma(bf[1], k2, pi[gb]);
-                    pr[gb] = mma(bf[2], k2, pr[gb]); pi[gb] = mma(bf[2], n0, pi[gb]);
-                    pr[gb] = mma(bf[2], k3, pr[gb]); pi[gb] = mma(bf[2], n1, pi[gb]);
-                    pr[gb] = mma(bf[3], k2, pr[gb]); pi[gb] = mma(bf[3], n0, pi[gb]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < 2; ++u) {
+                    const int cc = cB + 8 * u;
+                    o2[u] = (unsigned)((i & 1) * EBUF + cc * 128 + 16 * ((gl >> 3) ^ sw4(cc)) + 2 * (gl & 7));
                 }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const u32x2 p0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o2[0] + p * EPL)));
+                    const u32x2 p1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(lbase + o2[1] + p * EPL)));
+                    dst[p] = u32x4{p0.x, p0.y, p1.x, p1.y};
+                }
+            };
+            rdB(0, bfb[0]);
+#pragma unroll
+            for (int st = 0; st < 16; ++st) {
+                const int gb = st >> 1, s = st & 1;
+                if (st + 1 < 16) rdB(st + 1, bfb[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 *bf = bfb[st & 1], *k = kf[s];
+                // re += Br kr + Bi ki ; im += Br ki - Bi kr
+                pr[gb] = mma(bf[0], k[0], pr[gb]); pi[gb] = mma(bf[0], k[2], pi[gb]);
+                pr[gb] = mma(bf[0], k[1], pr[gb]); pi[gb] = mma(bf[0], k[3], pi[gb]);
+                pr[gb] = mma(bf[1], k[0], pr[gb]); pi[gb] = mma(bf[1], k[2], pi[gb]);
+                pr[gb] = mma(bf[2], k[2], pr[gb]); pi[gb] = mma(bf[2], k[4], pi[gb]);
+                pr[gb] = mma(bf[2], k[3], pr[gb]); pi[gb] = mma(bf[2], k[5], pi[gb]);
+                pr[gb] = mma(bf[3], k[2], pr[gb]); pi[gb] = mma(bf[3], k[4], pi[gb]);
             }
         }
         if (i + 1 < tiles) store_window((i + 1) & 1, wreg);
@@ -218,5 +240,8 @@ int main()
     run(pass4_products<0>, "4-wave products, both phases", 384);
     run(pass4_products<1>, "4-wave products, (A S) B only", 192);
     run(pass4_products<2>, "4-wave products, K B^H only", 192);
+    run(pass4_products<3>, "(A S) B only, no global loads", 192);
+    run(pass4_products<4>, "(A S) B only, no LDS reads", 192);
+    run(pass4_products<5>, "both phases, no global loads", 384);
     return 0;
 }
