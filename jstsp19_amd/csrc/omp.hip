@@ -567,10 +567,14 @@ static bool omp_reg_step()
 }
 
 // basis columns omp_step_reg_kernel keeps in LDS: what 160 KiB leave beside its static arrays (inner products 16 KiB, w 8 EPT KiB)
+// (-1: the opt-in to that much dynamic LDS was refused - the caller then takes omp_step_kernel<1024>, which needs none)
 static int omp_reg_qcols(int meas, int m)
 {
-    (void)hipFuncSetAttribute((const void *)omp_step_reg_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 138240);
-    (void)hipFuncSetAttribute((const void *)omp_step_reg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 130048);
+    if (hipFuncSetAttribute((const void *)omp_step_reg_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 138240) != hipSuccess ||
+        hipFuncSetAttribute((const void *)omp_step_reg_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 130048) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
     const int budget = meas <= 1024 ? 138240 : 130048;
     const int qc = budget / (meas * (int)sizeof(float2));
     return qc < m ? qc : m;
@@ -852,8 +856,9 @@ int jstsp_omp_c32(jstsp_ctx *ctx, int meas, int size_d, int batch, const jstsp_c
     JSTSP_HIP(hipMemcpyAsync(s.r, v, (size_t)batch * meas * sizeof(float2), hipMemcpyDeviceToDevice, st));   // r = v (:10)
     JSTSP_HIP(hipMemsetAsync(s.nu, 0, batch * sizeof(int), st));
     JSTSP_HIP(hipMemsetAsync(s.Rm, 0, (size_t)batch * m * m * sizeof(float2), st));
-    const bool reg_step = batch <= 64 && meas <= 2048 && omp_reg_step();
-    const int qc = reg_step ? omp_reg_qcols(meas, m) : 0;
+    bool reg_step = batch <= 64 && meas <= 2048 && omp_reg_step();
+    int qc = reg_step ? omp_reg_qcols(meas, m) : 0;
+    if (qc < 0) { reg_step = false; qc = 0; }
     for (int it = 0; it < m; ++it) {                                                             // :16
         // A'*r (:17).  Few right-hand sides per dictionary: the matrix-vector kernel above.  Shared dictionary and many problems:
         // one GEMM with the residuals of all problems as columns.
@@ -995,8 +1000,9 @@ int jstsp_omp_kron_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, 
         rmax = ctx->arena.get<uint32_t>(batch);
         JSTSP_REQUIRE(rmax, JSTSP_E_NOMEM, "omp_kron: workspace exhausted");
     }
-    const bool reg_step = batch <= 64 && meas <= 2048 && omp_reg_step();
-    const int qc = reg_step ? omp_reg_qcols(meas, m) : 0;
+    bool reg_step = batch <= 64 && meas <= 2048 && omp_reg_step();
+    int qc = reg_step ? omp_reg_qcols(meas, m) : 0;
+    if (qc < 0) { reg_step = false; qc = 0; }
     for (int it = 0; it < m; ++it) {
         // Phi'*r = vec(Af^H R Bf^H) with R = reshape(r, N, M): the correlation kernel of the hot path
         if (h2) {
