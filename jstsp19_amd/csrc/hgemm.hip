@@ -653,6 +653,8 @@ __device__ __forceinline__ void herm_symmetrize(f32x16 &re, f32x16 &im, float2 *
 //        re G(i,j) = sum ar_i ar_j + ai_i ai_j,   im G(i,j) = sum ai_i ar_j - ar_i ai_j.
 //      Z2 != nullptr: the matrix is Z - zprm[t].irho * Z2, formed on the fly (the svt argument X - V1/rho of
 //      proposed_algorithm.m:35 without ever storing it: X and V1 were written by the preceding kernel).
+constexpr int GRAM_HONLY_MIN_COLS = 1024;     // norm-only Grams take the high f16 plane alone from this many columns on
+
 // HONLY (round 6): the high f16 plane only, G = H H^H - for the Grams whose ONLY use is lambda_max in convergence_error(:,1:2)
 // (proposed_algorithm.m:67,69): an 11-bit operand perturbs lambda_max = sum_m |u^H x_m|^2 by independent relative errors of 2^-12 per
 // entry, i.e. by about 2^-12 / sqrt(#terms) ~ 1e-5 relative at 64 x 4096 - a tenth of what the test tolerance of the error curve
@@ -803,7 +805,8 @@ __global__ __launch_bounds__(256, 2) void hgram_kernel(const float2 *Z, long lon
 //      and the svt argument of the next iteration (:35), which is therefore never stored.  Wave (wi, wj) computes block
 //      (wi, wj) of all three Grams with one fp32 accumulator per real sum; k chunks of at most 1024 terms per workgroup
 //      (no second-level sums: these Grams feed an eigensolver and a norm ratio, not the gradient).
-template <bool EVEN>
+// NH (round 6): G_x and G_v1 on the high f16 plane only (see hgram_kernel HONLY) - chosen by the launcher for cols >= 1024
+template <bool EVEN, bool NH>
 __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const float2 *V1, long long sZt, int rows, int cols,
                                                         int nsplit, const uint32_t *xmax, const uint32_t *vmax,
                                                         const uint32_t *zmax, const TrialParams *prm, float2 *Gz,
@@ -877,8 +880,8 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
 #pragma unroll
         for (int u = 0; u < 8; ++u)                                                                            // (:35)
             z[u] = make_float2(fmaf(-ir, R.v[u].x, R.x[u].x) - irl * R.v[u].x, fmaf(-ir, R.v[u].y, R.x[u].y) - irl * R.v[u].y);
-        put_h(smem, R.x, sx);
-        put_h(smem + 1024, R.v, sv);
+        if constexpr (NH) { put_h(smem, R.x, sx); put_h(smem + 1024, R.v, sv); }
+        else { put(smem, R.x, sx); put(smem + 1024, R.v, sv); }
         put(smem + 2048, z, sz);
     };
     f32x16 re[3], im[3];
@@ -903,7 +906,7 @@ __global__ __launch_bounds__(256, 2) void hgram3_kernel(const float2 *X, const f
                 im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_h, ii_h, im[g], 0, 0, 0);
                 re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_h, ii_h, re[g], 0, 0, 0);
                 im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(nji_h, ir_h, im[g], 0, 0, 0);
-                if (g < 2) continue;        // G_x, G_v1: H H^H (the low planes of their panels are not written)
+                if (NH && g < 2) continue;  // G_x, G_v1: H H^H (the low planes of their panels are not written)
                 re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ir_h, re[g], 0, 0, 0);
                 im[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(jr_l, ii_h, im[g], 0, 0, 0);
                 re[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ji_l, ii_h, re[g], 0, 0, 0);
@@ -1033,7 +1036,7 @@ int launch_hgram(jstsp_ctx *ctx, const float2 *Z, long long sZt, int rows, int c
     prof_begin(ctx, "gram");
     JSTSP_REQUIRE(!Z2 || zprm, JSTSP_E_NULL, "hgram: Z2 without per-problem scalars");
     // norm_only: the Gram is used for its lambda_max in convergence_error alone - high f16 plane only (hgram_kernel, HONLY)
-    if (norm_only && !Z2 && !skip_prm) {
+    if (norm_only && !Z2 && !skip_prm && cols >= GRAM_HONLY_MIN_COLS) {
         if (cols % (nsplit * 2 * HBK) == 0)
             hgram_kernel<true, true><<<(unsigned)grid, 256, 0, ctx->stream>>>(Z, sZt, rows, cols, nsplit, amax, Gpart, count, skip_prm, Z2, zprm);
         else
@@ -1057,12 +1060,16 @@ int launch_hgram3(jstsp_ctx *ctx, const float2 *X, const float2 *V1, long long s
     const long long grid = (long long)count * nsplit;
     JSTSP_REQUIRE(grid < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgram3 grid too large");
     prof_begin(ctx, "gram");
-    if (cols % (nsplit * 2 * HBK) == 0)
-        hgram3_kernel<true><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx,
-                                                                      Gv, count);
-    else
-        hgram3_kernel<false><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx,
-                                                                       Gv, count);
+    // G_x, G_v1 feed lambda_max of convergence_error(:,1:2) only: one f16 plane perturbs it by ~2^-12 / sqrt(cols) relative - taken from
+    // 1024 columns on (measured 1e-4 at 4096 columns beside the Lanczos tolerance; at 10 columns it would be 4.5e-4 of the 5e-4 asserted)
+    const bool nh = cols >= GRAM_HONLY_MIN_COLS;
+    if (cols % (nsplit * 2 * HBK) == 0) {
+        if (nh) hgram3_kernel<true, true><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx, Gv, count);
+        else hgram3_kernel<true, false><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx, Gv, count);
+    } else {
+        if (nh) hgram3_kernel<false, true><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx, Gv, count);
+        else hgram3_kernel<false, false><<<(unsigned)grid, 256, 0, ctx->stream>>>(X, V1, sZt, rows, cols, nsplit, xmax, vmax, zmax, prm, Gz, Gx, Gv, count);
+    }
     prof_end(ctx, "gram");
     JSTSP_HIP(hipGetLastError());
     return 0;
