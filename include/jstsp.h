@@ -362,6 +362,21 @@ int jstsp_vamp_kron_c32(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
                         const jstsp_c32 *Af, long long strideA, const jstsp_c32 *Gb, long long strideG,
                         double sigma, double L, int nit, jstsp_c32 *X_out, int memspace);
 
+/* The two scalar estimators VAMP is built from, stand-alone (they run inside every VAMP iteration as
+ * device functions of csrc/vamp_kernels.h - these entries call exactly those functions on arrays, so that they can be tested and used
+ * by themselves).  float64 in and out, n real coordinates (the reference real-stacks the complex system, vamp.m:3-4).
+ *   jstsp_sparse_sca_estim_f64:  [xhat, xvar] = SparseScaEstim(CAwgnEstimIn(0, var0), p1).estim(rhat, rvar)
+ *     MPbased_solvers/main/SparseScaEstim.m:76-166 around main/CAwgnEstimIn.m:94-102,181-184: the Bernoulli-Gaussian posterior mean and
+ *     variance with the COMPLEX log-likelihood branch of :100-103 (what vamp.m's r1init = eps*1i selects on real-stacked data), the
+ *     activity exponent clipped at +-500 (:108-109), rvar floored at eps (:96).  rvar: one value for all coordinates.
+ *   jstsp_cawgn_estim_out_f64:  [zhat, zvar] = CAwgnEstimOut(y, wvar).estim(phat, pvar), scale = 1
+ *     MPbased_solvers/main/CAwgnEstimOut.m:97-108: gain = pvar / (pvar + wvar), zhat = gain (y - phat) + phat, zvar = wvar gain
+ *     (zvar is one value, returned through *zvar on the host). */
+int jstsp_sparse_sca_estim_f64(jstsp_ctx *ctx, long long n, const double *rhat, double rvar, double var0, double p1, double *xhat,
+                               double *xvar, int memspace);
+int jstsp_cawgn_estim_out_f64(jstsp_ctx *ctx, long long n, const double *y, const double *phat, double pvar, double wvar, double *zhat,
+                              double *zvar, int memspace);
+
 /* nmse[t] = min(1, norm(S - Zbar)^2 / norm(Zbar)^2) with spectral norms
  *   plot_errorVSsnr.m:138-141.   S, Zbar: R x C x batch; nmse: batch doubles (same memspace). */
 int jstsp_nmse_spectral_c32(jstsp_ctx *ctx, int R, int C, int batch, const jstsp_c32 *S,

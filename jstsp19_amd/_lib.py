@@ -87,6 +87,8 @@ SIGNATURES = {
                                c_void_p, c_int]),
     "jstsp_vamp_kron_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_ll, c_void_p, c_ll,
                                     C.c_double, C.c_double, c_int, c_void_p, c_int]),
+    "jstsp_sparse_sca_estim_f64": (c_int, [c_void_p, c_ll, c_void_p, C.c_double, C.c_double, C.c_double, c_void_p, c_void_p, c_int]),
+    "jstsp_cawgn_estim_out_f64": (c_int, [c_void_p, c_ll, c_void_p, c_void_p, C.c_double, C.c_double, c_void_p, c_dp, c_int]),
     "jstsp_lambda_max_sequence_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
     "jstsp_nmse_spectral_c32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "jstsp_build_trials_c32": (c_int, [c_void_p, C.POINTER(Model), C.c_uint64, c_int, c_ll, c_int, C.POINTER(Trials),

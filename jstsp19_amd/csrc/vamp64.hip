@@ -329,6 +329,21 @@ int vamp_run64(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const double2 
     return 0;
 }
 
+__global__ __launch_bounds__(256) void sca_estim_kernel(long long n, const double *rhat, double rvar, double var0, double p1, double *xhat, double *xvar)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        double xh, xv;
+        bg_denoise(rhat[i], rvar, var0, p1, xh, xv);
+        xhat[i] = xh; xvar[i] = xv;
+    }
+}
+__global__ __launch_bounds__(256) void awgn_out_kernel(long long n, const double *y, const double *phat, double pvar, double wvar, double *zhat)
+{
+    const double gain = pvar / (pvar + wvar);                                    // CAwgnEstimOut.m:106
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        zhat[i] = gain * (y[i] - phat[i]) + phat[i];                             // :107
+}
+
 // a caller array in device memory: itself (JSTSP_DEVICE) or a stream-ordered copy (JSTSP_HOST)
 const double2 *stage64(Scratch &sc, const jstsp_c64 *src, size_t n, int memspace)
 {
@@ -368,6 +383,65 @@ int jstsp_vamp_kron_c64(jstsp_ctx *ctx, int Na, int Gr, int G2, int batch, const
     JSTSP_TRY(vamp_run64(ctx, Na, Gr, G2, batch, Y, Af, strideA, Gb, strideG, sigma, Lnz, nit, 0.85, X));      // damp: vamp.m:11
     if (memspace == JSTSP_HOST) {
         JSTSP_HIP(hipMemcpyAsync(X_out, X, bN * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+        JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+// SparseScaEstim(CAwgnEstimIn(0, var0), p1).estim(rhat, rvar) and CAwgnEstimOut(y, wvar).estim(phat, pvar) on arrays: the device
+// functions of the VAMP iteration, stand-alone (include/jstsp.h)
+int jstsp_sparse_sca_estim_f64(jstsp_ctx *ctx, long long n, const double *rhat_, double rvar, double var0, double p1, double *xhat_, double *xvar_,
+                               int memspace)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_REQUIRE(rhat_ && xhat_ && xvar_, JSTSP_E_NULL, "sparse_sca_estim: NULL array argument");
+    JSTSP_REQUIRE(n > 0, JSTSP_E_SHAPE, "sparse_sca_estim: n = %lld", n);
+    JSTSP_REQUIRE(rvar >= 0 && var0 > 0 && p1 > 0 && p1 < 1, JSTSP_E_ARG, "sparse_sca_estim: need rvar >= 0, var0 > 0, 0 < p1 < 1");
+    JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
+    JSTSP_ENTER(ctx);
+    Scratch sc(ctx->stream);
+    const double *rhat = rhat_;
+    double *xhat = xhat_, *xvar = xvar_;
+    if (memspace == JSTSP_HOST) {
+        double *d = sc.get<double>((size_t)3 * n);
+        JSTSP_TRY(sc.rc);
+        JSTSP_HIP(hipMemcpyAsync(d, rhat_, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        rhat = d; xhat = d + n; xvar = d + 2 * n;
+    }
+    hipLaunchKernelGGL(sca_estim_kernel, gsz(n), dim3(256), 0, ctx->stream, n, rhat, rvar, var0, p1, xhat, xvar);
+    JSTSP_HIP(hipGetLastError());
+    if (memspace == JSTSP_HOST) {
+        JSTSP_HIP(hipMemcpyAsync(xhat_, xhat, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        JSTSP_HIP(hipMemcpyAsync(xvar_, xvar, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        JSTSP_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
+}
+
+int jstsp_cawgn_estim_out_f64(jstsp_ctx *ctx, long long n, const double *y_, const double *phat_, double pvar, double wvar, double *zhat_,
+                              double *zvar, int memspace)
+{
+    JSTSP_REQUIRE(ctx, JSTSP_E_NULL, "ctx is NULL");
+    JSTSP_REQUIRE(y_ && phat_ && zhat_ && zvar, JSTSP_E_NULL, "cawgn_estim_out: NULL argument");
+    JSTSP_REQUIRE(n > 0, JSTSP_E_SHAPE, "cawgn_estim_out: n = %lld", n);
+    JSTSP_REQUIRE(pvar >= 0 && wvar > 0, JSTSP_E_ARG, "cawgn_estim_out: need pvar >= 0, wvar > 0");
+    JSTSP_REQUIRE(memspace == JSTSP_HOST || memspace == JSTSP_DEVICE, JSTSP_E_ARG, "bad memspace %d", memspace);
+    JSTSP_ENTER(ctx);
+    Scratch sc(ctx->stream);
+    const double *y = y_, *phat = phat_;
+    double *zhat = zhat_;
+    if (memspace == JSTSP_HOST) {
+        double *d = sc.get<double>((size_t)3 * n);
+        JSTSP_TRY(sc.rc);
+        JSTSP_HIP(hipMemcpyAsync(d, y_, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        JSTSP_HIP(hipMemcpyAsync(d + n, phat_, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        y = d; phat = d + n; zhat = d + 2 * n;
+    }
+    hipLaunchKernelGGL(awgn_out_kernel, gsz(n), dim3(256), 0, ctx->stream, n, y, phat, pvar, wvar, zhat);
+    JSTSP_HIP(hipGetLastError());
+    *zvar = wvar * (pvar / (pvar + wvar));                                       // CAwgnEstimOut.m:108 (scale = 1)
+    if (memspace == JSTSP_HOST) {
+        JSTSP_HIP(hipMemcpyAsync(zhat_, zhat, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         JSTSP_HIP(hipStreamSynchronize(ctx->stream));
     }
     return 0;

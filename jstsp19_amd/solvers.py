@@ -27,7 +27,7 @@ from . import _lib
 from ._lib import DEVICE, HOST, JstspError, check
 
 __all__ = ["proposed_algorithm", "proposed_algorithm_angles", "svt", "mc_svt", "mc_admm", "OMP", "omp_kron",
-           "sparse_admm", "vamp", "vamp_kron", "ls_estimate", "pinv", "mmv_omp", "tssr", "rate", "correlate", "synthesize", "gradient_head", "nmse_spectral", "colmajor",
+           "sparse_admm", "vamp", "vamp_kron", "sparse_sca_estim", "cawgn_estim_out", "ls_estimate", "pinv", "mmv_omp", "tssr", "rate", "correlate", "synthesize", "gradient_head", "nmse_spectral", "colmajor",
            "empty_colmajor"]
 
 
@@ -571,3 +571,30 @@ def vamp_kron(Y, Af, Gb, sigma, L, *, nit=100, ctx=None):
              _shared_stride(a_G, G2 * G2, batch, "Gb"), float(sigma), float(L), int(nit), px, mem),
           "jstsp_vamp_kron_c64" if f64 else "jstsp_vamp_kron_c32")
     return fx(not a_Y.batched)
+
+
+def sparse_sca_estim(rhat, rvar, var0, p1, *, ctx=None):
+    """``[xhat, xvar] = SparseScaEstim(CAwgnEstimIn(0, var0), p1).estim(rhat, rvar)`` on real coordinates with the complex
+    log-likelihood branch (MPbased_solvers/main/SparseScaEstim.m:76-166, CAwgnEstimIn.m:94-102,181-184) - the denoiser of every
+    VAMP iteration (vamp.m:23-25), stand-alone.  ``rhat``: 1-D float64 numpy array (host path); returns two float64 arrays."""
+    r = np.ascontiguousarray(np.asarray(rhat, dtype=np.float64).reshape(-1))
+    c = ctx or _lib.default_context(0)
+    xh, xv = np.empty_like(r), np.empty_like(r)
+    check(c._lib.jstsp_sparse_sca_estim_f64(c.handle, r.size, r.ctypes.data, float(rvar), float(var0), float(p1), xh.ctypes.data, xv.ctypes.data,
+                                            HOST), "jstsp_sparse_sca_estim_f64")
+    return xh.reshape(np.shape(rhat)), xv.reshape(np.shape(rhat))
+
+
+def cawgn_estim_out(y, phat, pvar, wvar, *, ctx=None):
+    """``[zhat, zvar] = CAwgnEstimOut(y, wvar).estim(phat, pvar)`` with scale = 1 (MPbased_solvers/main/CAwgnEstimOut.m:97-108) on real
+    coordinates - the likelihood of every VAMP iteration (vamp.m:30), stand-alone.  Returns (zhat array, zvar scalar)."""
+    yy = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+    pp = np.ascontiguousarray(np.asarray(phat, dtype=np.float64).reshape(-1))
+    if yy.size != pp.size:
+        raise ValueError("y and phat must have the same number of entries")
+    c = ctx or _lib.default_context(0)
+    zh = np.empty_like(yy)
+    zv = C.c_double(0.0)
+    check(c._lib.jstsp_cawgn_estim_out_f64(c.handle, yy.size, yy.ctypes.data, pp.ctypes.data, float(pvar), float(wvar), zh.ctypes.data,
+                                           C.byref(zv), HOST), "jstsp_cawgn_estim_out_f64")
+    return zh.reshape(np.shape(y)), float(zv.value)

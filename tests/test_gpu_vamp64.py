@@ -115,3 +115,31 @@ def test_vamp_float64_tall_system_and_few_iterations_match_tightly():
         out = np.asarray(J.vamp_kron(g["Y"].astype(np.complex128), g["A"].astype(np.complex128), g["Gb"].astype(np.complex128), float(g["sigma"]),
                                      float(g["L"]), nit=nit))
         assert rel_err(out, ref) < 1e-10, (nit, rel_err(out, ref))
+
+
+def test_standalone_denoiser_and_likelihood_against_the_oracle():
+    """SURVEY section 8 rows a8-a10 by themselves: SparseScaEstim(CAwgnEstimIn(0, var0), p1).estim (SparseScaEstim.m:76-166,
+    CAwgnEstimIn.m:94-102,181-184) and CAwgnEstimOut.estim (CAwgnEstimOut.m:97-108) through jstsp_sparse_sca_estim_f64 /
+    jstsp_cawgn_estim_out_f64 - the device functions every VAMP iteration calls - against oracle.vamp._bg_denoise / _awgn_like:
+    1e-13, over the regimes of the iteration (rvar from 1e8 = 1 / gam1x at the start down to the eps floor of :96, the +-500 clip
+    of the activity exponent of :108-109) and the known values (r = 0 -> xhat = 0; a huge |r| is active: xhat -> gain r)."""
+    import jstsp19_amd as J
+    from oracle import vamp as V
+    rng = np.random.default_rng(12)
+    r = np.concatenate([rng.standard_normal(500) * 3.0, [0.0, 30.0, -45.0, 1e-3, 1e3]])
+    for rvar, var0, p1 in ((1e8, 5.12, 0.1953), (1.0, 5.12, 0.1953), (0.03, 5.12, 0.1953), (1e-40, 4.0, 0.1), (2.0, 0.5, 0.9)):
+        xh, xv = J.sparse_sca_estim(r, rvar, var0, p1)
+        xo, vo = V._bg_denoise(r.astype(complex), np.full(r.shape, rvar), var0, p1)
+        assert np.all(np.isfinite(xh)) and np.all(np.isfinite(xv))
+        check_below("denoiser.xhat", np.max(np.abs(xh - xo.real)) / max(np.max(np.abs(xo)), 1e-300), 1e-13)
+        check_below("denoiser.xvar", np.max(np.abs(xv - vo)) / np.max(np.abs(vo)), 1e-12)
+    xh, xv = J.sparse_sca_estim(np.array([0.0, 30.0]), 1.0, 4.0, 0.1)
+    assert xh[0] == 0.0 and abs(xh[1] - 0.8 * 30) < 1e-6 and np.all(xv > 0)
+    y, ph = rng.standard_normal(300), rng.standard_normal(300)
+    for pvar, wvar in ((1e8, 1.0), (0.7, 1.0), (1e-9, 0.3)):
+        zh, zv = J.cawgn_estim_out(y, ph, pvar, wvar)
+        zo, vo = V._awgn_like(ph, pvar, y, wvar)
+        check_below("likelihood.zhat", np.max(np.abs(zh - zo)) / np.max(np.abs(zo)), 1e-14)
+        assert abs(zv - vo) <= 1e-15 * abs(vo)
+    with pytest.raises(J.JstspError):
+        J.sparse_sca_estim(r, 1.0, 4.0, 1.5)                # p1 outside (0, 1)
