@@ -453,7 +453,12 @@ def main():
                 roofline = {"bound": "hbm", "kernel": kname, **hbm, "mfma": mfma}
             roofline.update({"traffic": traffic_of("fused_pass64"), "avg_launch_ms": round(avg_f, 4), "launches": n_f,
                              "bytes_per_launch": bytes_pass, "dictionary_block": gt,
-                             "algorithmic_tflops": round(2 * flops_per_launch / (avg_f * 1e-3) / 1e12, 1),
+                             "algorithmic_tflops": round((2 * flops_per_launch + 8.0 * N * N * M * a.batch) / (avg_f * 1e-3) / 1e12, 1),
+                             "algorithmic_frac_of_f16_peak": round((2 * flops_per_launch + 8.0 * N * N * M * a.batch) / (avg_f * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                             "algorithmic_note": "8 real flops per complex MAC of (A S) B, K B^H and Y = (I - Q) Z, counted ONCE - `frac` above counts the three f16 "
+                                                 "products each fp32-equivalent product is executed as (split-f16); against the 157.3-TFLOP/s fp32 matrix roof "
+                                                 "that the same contractions would otherwise run on, the algorithmic rate is %.2f x that roof" % (
+                                                     (2 * flops_per_launch + 8.0 * N * N * M * a.batch) / (avg_f * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS),
                              "full_dictionary_equivalent": {"bytes_per_launch": bytes_full, "achieved": round(full, 1), "unit": "GB/s",
                                                             "frac": round(full / HBM_PEAK_GBS, 4),
                                                             "note": "the bytes an unstructured dictionary needs (fused_pass_kernel, the figure "

@@ -89,7 +89,7 @@ struct Tuning {
     JSTSP_XP rv_comp = 0;        // (experiments build) JSTSP_RV_COMP: 1 v and R v carried as two floats each (compensated accumulation of alpha res / alpha R res)
     JSTSP_XP rv_always = 0;      // (experiments build) JSTSP_RV_ALWAYS: R v recomputed from v in each of the first n iterations (then every JSTSP_RV_REFRESH-th)
     JSTSP_XP inv_two_float = 1;  // (experiments build) JSTSP_INV2: 0 the pass reads 1 / (Omega + 2 rho) as one rounded float per entry (rounds 1-4)
-    JSTSP_XP pass_acc = 1;       // (experiments build) JSTSP_PASS_ACC: 0 products of K B^H straight into the window pass's running sums (rounds 2-4), 1 per-tile block sums first (fused.hip)
+    JSTSP_XP pass_acc = 1;       // (experiments build; applies to the window pass fused_pass64_kernel only - fused_pass_kernel always sums per tile first) JSTSP_PASS_ACC: 0 products of K B^H straight into the window pass's running sums (rounds 2-4), 1 per-tile block sums first (fused.hip)
     int host_compact = 1;   // JSTSP_HOST_COMPACT: 0 a JSTSP_HOST dictionary is uploaded whole (no host-side block-Toeplitz test / compaction)
     int host_pipeline = 1;  // JSTSP_HOST_PIPELINE: 0 a JSTSP_HOST solve as ONE staged call (no overlap of the copies with the solve)
     JSTSP_XP gram_refine = 1;    // (experiments build) JSTSP_GRAM_REFINE: 0 the dictionary Grams G_A, G_B as plain fp32 products, no low-order parts in R*v
