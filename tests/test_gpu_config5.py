@@ -27,7 +27,7 @@ def _np(x, t, dt=np.complex128):
 
 def test_cfg5_small_frame_proposed_and_angles_against_the_oracle():
     """N=64, M=256, Gr=64, G2=4096: inputs from the library's own builder, 12 iterations, 2 trials against the float64
-    oracle (S to 2e-5 of max|S|, |dNMSE| <= 1e-6), convergence_error to 5e-4, support of _angles inside indx_S."""
+    oracle (S to 1e-5 of max|S|, |dNMSE| <= 1e-6), convergence_error to 5e-4, support of _angles inside indx_S."""
     import torch
     import jstsp19_amd as J
     from jstsp19_amd.system_model import build_trials

@@ -1,7 +1,7 @@
 """HIP path vs the float64 oracle / golden fixtures — proposed_algorithm(_angles).
 
 Tolerances (fp32 device arithmetic vs float64 reference restatement):
-  S, Y   : max|d| / max|ref| <= 2e-5   (conftest.TOL_S: about 4x the largest error measured, round 6)
+  S, Y   : max|d| / max|ref| <= 1e-5   (conftest.TOL_S: 5x the largest error measured, round 6)
   NMSE   : |d| <= 1e-6 (BASELINE.json north_star), every fixture
   ce     : relative 5e-4 on every finite entry of convergence_error (conftest.TOL_CE)
 """

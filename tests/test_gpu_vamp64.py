@@ -30,7 +30,7 @@ def _hbf_trials(db, nt, seed):
 
 
 def test_vamp_kron_float64_follows_the_oracle_as_far_as_float64_can_three_snr_points():
-    """6 trials at each of -6, 3 and 12 dB through jstsp_vamp_kron_c64 (host arrays, one batched call per point and iteration count)
+    """6 trials at each of -6 and 12 dB through jstsp_vamp_kron_c64 (host arrays, one batched call per point and iteration count)
     against oracle.vamp.vamp_kron on the same inputs, numOfnz = 100 (plot_errorVSsnr.m:26,100), after 12, 50 and 100 iterations.
 
     What can be asserted.  The reference's configuration (sigma = 1, no stopping rule) is chaotic: at this size a rounding
@@ -46,7 +46,7 @@ def test_vamp_kron_float64_follows_the_oracle_as_far_as_float64_can_three_snr_po
     from oracle import vamp as V
     nt = 6              # (the literal restatement takes 5 s per run at this size: 54 runs; 16 trials per point were run once for
                         #  profiles/r06_measured_tolerances.json)
-    for db in (-6.0, 3.0, 12.0):
+    for db in (-6.0, 12.0):
         A, Gb, Ym, Zb = _hbf_trials(db, nt, seed=616)
         for nit in NITS:
             X = np.asarray(J.vamp_kron(Ym, A, Gb, 1.0, 100, nit=nit))
