@@ -492,7 +492,9 @@ int jstsp_mc_admm_c64(jstsp_ctx *ctx, int Mr, int Mt, int batch, const jstsp_c64
  * which narrows to the fp32 path.  Reason: at the reference's only operating point (nit = 100, sigma = 1, no stopping rule:
  * vamp.m:9,38,45, VampGlmEst.m:505-511) the iteration amplifies rounding differences ~1e9-fold, so only float64 reproduces the
  * reference's output per trial (tests/test_gpu_vamp64.py: x within 1e-5, NMSE within 1e-6 of oracle/vamp.py at nit = 100); the
- * _c32 entries keep the fp32-storage path (per-iteration parity for ~12 iterations, statistical parity at 100). */
+ * _c32 entries keep the fp32-storage path (per-iteration parity for ~12 iterations, statistical parity at 100).  Unlike the other
+ * JSTSP_DEVICE calls these two synchronise the context's stream (the convergence test of the float64 Jacobi reads its
+ * off-diagonal norm on the host once per sweep). */
 int jstsp_vamp_c64(jstsp_ctx *ctx, int M, int N, int batch, const jstsp_c64 *y, const jstsp_c64 *A,
                    long long strideA, double sigma, double L, int nit, jstsp_c64 *x_out, int memspace);
 

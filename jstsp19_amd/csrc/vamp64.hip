@@ -193,6 +193,12 @@ __global__ __launch_bounds__(256) void jacobi64_out_kernel(int n, int n0, const 
     }
 }
 
+__global__ __launch_bounds__(256) void eig64_order1_kernel(int nmat, const double2 *G, long long sG, double2 *U, double *lam)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nmat) { U[t] = make_double2(1.0, 0.0); lam[t] = G[(long long)t * sG].x; }
+}
+
 struct Scratch {            // stream-ordered temporaries of one call
     hipStream_t st;
     std::vector<void *> held;
@@ -213,17 +219,9 @@ struct Scratch {            // stream-ordered temporaries of one call
 // Hermitian eigen-decomposition of nmat matrices of order n0 (G: column-major, ld = n0, stride sG): U (n0 x n0 each), lam (n0 each)
 int eig64(hipStream_t st, Scratch &sc, int n0, int nmat, const double2 *G, long long sG, double2 *U, double *lam)
 {
-    if (n0 == 1) {
-        // (the Kronecker factor of a dense dictionary: Gb = 1)
-        std::vector<double2> one(nmat, make_double2(1.0, 0.0));
-        std::vector<double2> g(nmat);
-        for (int t = 0; t < nmat; ++t) JSTSP_HIP(hipMemcpyAsync(&g[t], G + (long long)t * sG, sizeof(double2), hipMemcpyDeviceToHost, st));
-        JSTSP_HIP(hipStreamSynchronize(st));
-        std::vector<double> l(nmat);
-        for (int t = 0; t < nmat; ++t) l[t] = g[t].x;
-        JSTSP_HIP(hipMemcpyAsync(U, one.data(), nmat * sizeof(double2), hipMemcpyHostToDevice, st));
-        JSTSP_HIP(hipMemcpyAsync(lam, l.data(), nmat * sizeof(double), hipMemcpyHostToDevice, st));
-        JSTSP_HIP(hipStreamSynchronize(st));
+    if (n0 == 1) {          // (the Kronecker factor of a dense dictionary, Gb = 1: U = 1, lambda = the entry)
+        hipLaunchKernelGGL(eig64_order1_kernel, dim3((nmat + 255) / 256), dim3(256), 0, st, nmat, G, sG, U, lam);
+        JSTSP_HIP(hipGetLastError());
         return 0;
     }
     const int n = (n0 + 1) & ~1, h2 = n / 2;
