@@ -11,7 +11,7 @@ timeout 900 bash tools/pmc_bench.sh r06 | tail -3
 timeout 300 python3 bench.py --steps 10 --warmup 2 --no-ce --no-cpu-baseline --no-host-path --no-strict-fp32 > gpurun_out/r06_bench_two_outputs.json 2>/dev/null
 timeout 600 python3 bench.py --sweep > gpurun_out/r06_bench_sweep_config3.json 2>/dev/null
 timeout 600 python3 tools/bench_cfg3.py 1024 > gpurun_out/r06_cfg3_shapes.txt 2>&1; tail -6 gpurun_out/r06_cfg3_shapes.txt
-timeout 2400 python3 -m pytest tests -m gpu -q --timeout 1500 > gpurun_out/r06_gpu_tests.txt 2>&1; tail -4 gpurun_out/r06_gpu_tests.txt
+timeout 2400 python3 -m pytest tests -m gpu -q --timeout 1500 --durations=12 > gpurun_out/r06_gpu_tests.txt 2>&1; tail -22 gpurun_out/r06_gpu_tests.txt
 python3 - <<'PY'
 import json
 for n in ("r06_bench_default", "r06_bench_two_outputs", "r06_bench_sweep_config3"):
