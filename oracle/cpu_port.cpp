@@ -317,6 +317,7 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
     if (rm & 16384u) jitter(GA, rj, jst);
     if (rm & 32768u) jitter(GB, rj, jst);
     if (rm & 128u) { round32(GA); round32(GB); }
+    if (rm & 67108864u) round32(GB);                                       // G_B alone in fp32 (the device: G_A as two floats, G_B as one)
     std::vector<double> inv_d(nm), omega_s(indx_S ? g : 0, 0.0), lam;
     for (size_t i = 0; i < nm; ++i) inv_d[i] = 1.0 / (Omega[i] + 2.0 * rho);     // iK1                        (:14-20)
     std::fill(ce, ce + (size_t)3 * Imax, 0.0);
@@ -361,6 +362,13 @@ void solve_one(int N, int M, int Gr, int G2, const double *subY_, const double *
             }
             Planar Uh; conj_transpose(U, Uh);
             gemm(Uf, Uh, Q);
+            if (rm & 134217728u) {
+                // the device's svt operator I - Q as the pass holds it: every entry times 2^13 split into two f16 (11 + 11 significant
+                // bits, fused.hip pack_wq_kernel) - a rounding that stays the same for as long as Q does
+                auto r11 = [](double x) { if (x == 0.0) return 0.0; int e; const double m = std::frexp(x, &e); return std::ldexp(std::nearbyint(std::ldexp(m, 11)), e - 11); };
+                auto sp = [&](double x) { const double h = r11(x * 8192.0), l = r11(x * 8192.0 - h); return (h + l) / 8192.0; };
+                for (size_t i = 0; i < Q.re.size(); ++i) { Q.re[i] = sp(Q.re[i]); Q.im[i] = sp(Q.im[i]); }
+            }
             gemm(Q, Z, Y);
         }
         if (rm & 256u) round32(Y);

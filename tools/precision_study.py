@@ -26,6 +26,7 @@ NAMES = {1: "X,K stored fp32", 2: "V1,V2 stored fp32", 4: "V,S stored fp32", 8: 
          65536: "B to 22 bits in K B^H and (A S) B, G_B from exact B", 131072: "B to 22 bits everywhere (consistent)",
          262144: "G_B to 22 bits", 1048576: "rho, 1/rho, rho/(rho+1), tau/rho each rounded to fp32 on its own (TrialParams)", 4194304: "1/(Omega + 2 rho) stored fp32",
          8388608: "tau_S/rho, tau_Y/rho rounded to fp32", 16777216: "1/rho rounded to fp32", 33554432: "rho/(rho+1) rounded to fp32",
+         67108864: "G_B alone stored fp32 (G_A float64)", 134217728: "svt operator I - Q as two f16 per entry (the pass's fragments)",
          2097152: "rho rounded to fp32, everything derived from it in float64 (a consistent problem with another rho)"}
 
 
