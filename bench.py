@@ -303,7 +303,7 @@ def main():
         return
 
     import jstsp19_amd as J
-    ctx = J.default_context(local)
+    ctx = J.default_context(device.index)           # (= LOCAL_RANK; tests/bench_stub.py's one-GPU hooks put every rank on device 0)
     extra = {}
     # ---- the metric as SURVEY section 8(d) / BASELINE.md section 3 item 4 define it: solves / wall time of the WHOLE Monte-Carlo
     # step - fresh trials built on the device every step (plot_errorVSsnr.m:57-136: channel, pilots, measurement, hyper-

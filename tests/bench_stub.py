@@ -60,4 +60,31 @@ class StubHooks:
         return {"solve_fn": _sweep_solve, "builder": builder}
 
 
+
+def _one_gpu_hooks():
+    """GPU tier, 1-GPU box: the REAL library behind bench.py's hooks, every rank on device 0 and gloo instead of RCCL (RCCL wants
+    one device per rank).  What that run adds to the stub runs above: the library's per-process contexts, the device input builder
+    keyed by the rank's GLOBAL trial ids and the device NMSE behind bench.py's partition and all-reduces - with real solves, so
+    the reduced NMSE can be compared with a one-rank run over the same trials (tests/test_gpu_bench_contract.py)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import bench
+
+    class OneGpuHooks(bench.HipHooks):
+        backend = "gloo"
+
+        @staticmethod
+        def device(local):
+            torch.cuda.set_device(0)
+            return torch.device("cuda", 0)
+
+    return OneGpuHooks
+
+
+def __getattr__(name):              # (bench.py is imported only when these hooks are asked for)
+    if name == "ONE_GPU_HOOKS":
+        return _one_gpu_hooks()
+    raise AttributeError(name)
+
+
 HOOKS = StubHooks

@@ -100,3 +100,39 @@ def test_bench_two_ranks_over_rccl_when_the_box_has_two_gpus():
     assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
     assert j2["mean_nmse_proposed"] == pytest.approx(j1["mean_nmse_proposed"], abs=2e-6)
     assert j2["mean_nmse_angles"] == pytest.approx(j1["mean_nmse_angles"], abs=2e-6)
+
+
+def test_bench_two_ranks_real_library_on_one_gpu_over_gloo():
+    """N = 2 with the REAL library on the one GPU a test box has: both ranks on device 0, gloo instead of RCCL
+    (tests/bench_stub.py ONE_GPU_HOOKS; everything else is bench.py as the driver launches it).  Rank r solves global trials
+    [8 r, 8 r + 8): the reduced mean NMSE must be the one-rank run's over trials [0, 16) - a trial's result does not depend on
+    the batch it is solved in, so the two differ by the summation order of float64 partial sums only - and the sweep's
+    per-point means must be the one-rank sweep's.  What is left for the first 8-GPU run to exercise is RCCL itself."""
+    import socket
+    env = dict(os.environ, JSTSP_BENCH_HOOKS="tests.bench_stub:ONE_GPU_HOOKS", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(world, extra):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--small"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    head = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-host-path"]
+    two = run(2, head + ["--batch", "8"])
+    one = run(1, head + ["--batch", "16"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["data"] == "synthetic" and one["n_gpus"] == 1
+    assert abs(two["value"] - 2 * 8 / (two["ms_per_step"] * 1e-3)) / two["value"] < 1e-3       # whole-job: both ranks' trials
+    assert 0 < two["mean_nmse"] < 1 and abs(two["mean_nmse"] - one["mean_nmse"]) < 1e-12, (two["mean_nmse"], one["mean_nmse"])
+    assert two["end_to_end"]["value"] > 0 and two["cpu_baseline"] is None     # (the CPU leg is rank 0 at N = 1 only)
+    sw = ["--sweep", "--sweep-trials", "12", "--batch", "8"]
+    s2, s1 = run(2, sw), run(1, sw)
+    assert s2["n_gpus"] == 2 and s2["scaling"] == "strong" and s1["n_gpus"] == 1
+    assert s2["mean_nmse_proposed"] == pytest.approx(s1["mean_nmse_proposed"], abs=2e-6)
+    assert s2["mean_nmse_angles"] == pytest.approx(s1["mean_nmse_angles"], abs=2e-6)
