@@ -192,6 +192,23 @@ static float mc_eig_stop()
     return e ? (float)atof(e) : 1e-4f;
 }
 
+// One packed b operand for the batch and a shape hgemm_pair_kernel takes: the a operand (rows x Kd per problem, column-major, leading
+// dimension `rows`) in fragment order as well - the two-trials-per-workgroup kernel reads packed operands only (hgemm.hip)
+static size_t pair_apack_bytes(int Kd, int batch) { return rnd256((size_t)batch * 2 * (4 * ((Kd + 63) / 64)) * 256 * sizeof(uint4)); }
+static int pair_apack(jstsp_ctx *ctx, const float2 *Aop, long long sAt, int rows, int Kd, int batch, const uint32_t *amax, const HPack &bp,
+                      HGemmDesc &hd)
+{
+    HPack ap;
+    ap.KS = 4 * ((Kd + 63) / 64); ap.JT = 2; ap.count = batch;
+    ap.st = (long long)ap.JT * ap.KS * 256;
+    if (ap.KS != bp.KS) return 0;
+    ap.data = ctx->arena.get<uint4>((size_t)batch * ap.st);
+    JSTSP_REQUIRE(ap.data, JSTSP_E_NOMEM, "workspace exhausted (packed a operand)");
+    JSTSP_TRY(hgemm_repack(ctx, ap, Aop, sAt, rows, 1, 0, Kd, rows, amax));
+    hd.Ap = ap.data; hd.sApt = ap.st; hd.aKS = ap.KS;
+    return 0;
+}
+
 extern "C" {
 
 int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch, const jstsp_c32 *K_,
@@ -211,6 +228,8 @@ int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
     if (h2) need += hgemm_pack_bytes(M, G2, nB) + rnd256(batch * sizeof(uint32_t)) + rnd256(batch * nm * sizeof(float2)) +
                     rnd256((size_t)nB * G2 * M * sizeof(float2)) + rnd256((size_t)batch * N * sizeof(int32_t)) +
                     rnd256((size_t)nB * G2 * sizeof(int32_t));
+    const bool pair = h2 && !strideB && hgemm_pair_shape(N, G2, batch);
+    if (pair) need += pair_apack_bytes(M, batch);
     if (memspace == JSTSP_HOST)
         need += rnd256(batch * nm * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -241,6 +260,7 @@ int jstsp_correlate_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch,
         JSTSP_TRY(hgemm_absmax(ctx, Ks, (long long)nm, (long long)nm, batch, amax));
         HGemmDesc hd{Ks, (long long)nm, N, amax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS, pk.JT,
                      Tc, (long long)ng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
+        if (pair) JSTSP_TRY(pair_apack(ctx, Ks, (long long)nm, N, M, batch, amax, pk, hd));
         JSTSP_TRY(launch_hgemm(ctx, hd, "correlate"));
         JSTSP_TRY(scale2(ctx, N, G2, batch, Tc, (long long)ng, Tc, (long long)ng, eK, N, eB, strideB ? G2 : 0, +1));
     } else
@@ -269,6 +289,8 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
     const int nB = strideB ? batch : 1;
     if (h2) need += hgemm_pack_bytes(G2, M, nB) + rnd256(batch * sizeof(uint32_t)) + rnd256((size_t)nB * G2 * M * sizeof(float2)) +
                     rnd256((size_t)batch * N * sizeof(int32_t)) + rnd256((size_t)nB * M * sizeof(int32_t));
+    const bool pair = h2 && !strideB && hgemm_pair_shape(N, M, batch);
+    if (pair) need += pair_apack_bytes(G2, batch);
     if (memspace == JSTSP_HOST)
         need += rnd256(batch * g * sizeof(float2)) + rnd256(szA * sizeof(float2)) + rnd256(szB * sizeof(float2));
     JSTSP_TRY(ctx->arena.reserve(need));
@@ -300,6 +322,7 @@ int jstsp_synthesize_c32(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
         JSTSP_TRY(hgemm_absmax(ctx, W, (long long)ng, (long long)ng, batch, amax));
         HGemmDesc hd{W, (long long)ng, N, amax, pk.data, strideB ? pk.st : 0, pk.bmax, strideB ? 1 : 0, pk.KS, pk.JT,
                      O, (long long)nm, N, N, M, G2, batch, EPI_NONE, nullptr, nullptr, nullptr};
+        if (pair) JSTSP_TRY(pair_apack(ctx, W, (long long)ng, N, G2, batch, amax, pk, hd));
         JSTSP_TRY(launch_hgemm(ctx, hd, "synthesize"));
         JSTSP_TRY(scale2(ctx, N, M, batch, O, (long long)nm, O, (long long)nm, eW, N, eB, strideB ? M : 0, +1));
     } else

@@ -374,6 +374,8 @@ int launch_hgram3(jstsp_ctx *ctx, const float2 *X, const float2 *V1, long long s
                   const uint32_t *xmax, const uint32_t *vmax, const uint32_t *zmax, const TrialParams *prm, float2 *Gz,
                   float2 *Gx, float2 *Gv);
 size_t hgemm_pack_bytes(int Kd, int J, int count);
+// true when launch_hgemm gives a product with ONE packed b operand for the batch to the two-trials-per-workgroup kernel (hgemm.hip)
+bool hgemm_pair_shape(int m, int n, int batch);
 // amax[t] = max(|re|, |im|) over n contiguous elements of X[t*sXt ...]
 int hgemm_absmax(jstsp_ctx *ctx, const float2 *X, long long n, long long sXt, int count, uint32_t *amax);
 // b(kk, j) = B[t*sBt + kk*sBk + j*sBj] (conjugated if conj), kk < Kd, j < J; each B[t] spans n_contig contiguous elements

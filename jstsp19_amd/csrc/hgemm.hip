@@ -345,6 +345,107 @@ __global__ __launch_bounds__(128 * WJ, WJ == 2 ? 2 : 2) void hgemm_kernel(HGemmD
     }
 }
 
+// ---- epilogue of the 64-row kernels below: C(i, j), i = it 32 + (lane & 31), j = jw0 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5);
+//      re / im: the two 32 x 32 blocks (it = 0, 1) of one wave.
+//      16-byte accesses: accumulator registers r, r+1 are two adjacent columns of one row; lanes 2q and 2q+1 (adjacent
+//      rows) swap one of them (DPP quad_perm [1,0,3,2]), after which the even lane owns rows (i, i+1) of column j_r and the
+//      odd lane rows (i-1, i) of column j_r+1: every lane reads X / V2 and writes V2 / Xs as ONE float4 per register pair.
+//      (Measured at configs[1] by switching parts of the kernel off: dictionary + A S reads alone 0.75 ms = 5.45 TB/s;
+//      + the Xs store 0.97 ms; + X / V2 reads and the V2 store 1.29 ms - 1.39 ms with 8-byte accesses; the MFMAs are
+//      free, 0.03 ms.  What keeps the kernel from the read-stream rate is its read-modify-write tail.)
+template <int EPI>
+__device__ __forceinline__ void rows64_epilogue(const HGemmDesc &d, int t, int jw0, const f32x16 *re, const f32x16 *im, float alpha, int lane)
+{
+    float2 *Cp = d.C + (long long)t * d.sCt;
+    float vmax = 0.f;
+    const bool vec4 = ((d.m & 1) == 0) && ((d.ldc & 1) == 0) && ((d.sCt & 1) == 0) && (((uintptr_t)d.C & 15) == 0) &&
+                      (EPI != EPI_UPDATE_C || ((((uintptr_t)d.e_r0 | (uintptr_t)d.e_rw0) & 15) == 0));
+    const TrialParams prm = (EPI == EPI_UPDATE_C) ? d.prm[t] : TrialParams();
+    auto swap1 = [](float x) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+    };
+    if (vec4) {
+        // All X / V2 loads of a row block (eight register pairs: 16 requests per lane) are issued BEFORE the first use,
+        // from addresses that are always valid (out-of-range pairs read the tile's first element and are masked at the
+        // store): with a bounds `continue` in front of the loads hipcc waited for each pair's loads (vmcnt(0)) before
+        // issuing the next pair's — sixteen serialized HBM round trips per lane.
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int gi = it * 32 + (lane & 31);
+            const int gi2 = gi & ~1;
+            float4 xs[8];
+            long long ixs[8];
+            bool ok[8];
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                const int r0 = 2 * rp, r1 = r0 + 1;
+                const float2 o0 = make_float2(re[it][r0] * alpha, im[it][r0] * alpha);
+                const float2 o1 = make_float2(re[it][r1] * alpha, im[it][r1] * alpha);
+                const float2 snd = odd ? o0 : o1;
+                const float2 rcv = make_float2(swap1(snd.x), swap1(snd.y));
+                xs[rp] = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
+                const int gj = jw0 + (r0 & 3) + 8 * (r0 >> 2) + 4 * (lane >> 5) + (odd ? 1 : 0);
+                ok[rp] = gi2 < d.m && gj < d.n;
+                ixs[rp] = (long long)t * d.sCt + (ok[rp] ? gi2 + (long long)gj * d.ldc : 0);
+            }
+            if (EPI == EPI_UPDATE_C) {
+                float4 x[8], v2[8];
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    x[rp] = *reinterpret_cast<const float4 *>(d.e_r0 + ixs[rp]);
+                    v2[rp] = *reinterpret_cast<const float4 *>(d.e_rw0 + ixs[rp]);
+                }
+                asm volatile("" ::: "memory");      // keep the sixteen requests together, ahead of every store
+#pragma unroll
+                for (int rp = 0; rp < 8; ++rp) {
+                    // Xs in xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
+                    float4 v = v2[rp];
+                    v.x = admm_v2(prm, v.x, x[rp].x, xs[rp].x);
+                    v.y = admm_v2(prm, v.y, x[rp].y, xs[rp].y);
+                    v.z = admm_v2(prm, v.z, x[rp].z, xs[rp].z);
+                    v.w = admm_v2(prm, v.w, x[rp].w, xs[rp].w);
+                    if (ok[rp]) {
+                        *reinterpret_cast<float4 *>(d.e_rw0 + ixs[rp]) = v;
+                        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                    }
+                }
+            }
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp)
+                if (ok[rp]) *reinterpret_cast<float4 *>(d.C + ixs[rp]) = xs[rp];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int gi = it * 32 + (lane & 31);
+            if (gi >= d.m) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gj = jw0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (gj >= d.n) continue;
+                const float vr = re[it][r], vi = im[it][r];
+                const float2 o = make_float2(vr * alpha, vi * alpha);
+                const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
+                if (EPI == EPI_UPDATE_C) {
+                    const float2 x = d.e_r0[ix];
+                    float2 v2 = d.e_rw0[ix];
+                    v2.x = admm_v2(prm, v2.x, x.x, o.x);
+                    v2.y = admm_v2(prm, v2.y, x.y, o.y);
+                    d.e_rw0[ix] = v2;
+                    vmax = fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y)));
+                }
+                Cp[gi + (long long)gj * d.ldc] = o;
+            }
+        }
+    }
+    if (EPI == EPI_UPDATE_C && d.amax_v2) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0) atomicMax(&d.amax_v2[t], __float_as_uint(vmax));
+    }
+}
+
 // ---- v2 of the streaming contraction for m <= 64 (one row tile): every wave owns 32 output columns x all 64 rows
 //      (two 32 x 32 MFMA blocks).  Its b fragments are needed by nobody else, so they go straight from HBM to
 //      registers (1 KiB lane-linear blocks, 16 B per lane) with PD stages in flight per wave — no LDS round trip, no
@@ -492,7 +593,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
         im[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(br_h, a1i_l, im[1], 0, 0, 0);
     };
     const float alpha = ldexpf(1.f, -(ea + eb));
-    float2 *Cp = d.C + (long long)t * d.sCt;
     // Every load below is UNCONDITIONAL (past the end the stage index is clamped and the data ignored): a branch
     // around a load makes hipcc forget how many requests are outstanding and drain the queue (vmcnt(0)) at the top of
     // the loop.  The packs pad k to a multiple of 64, so the stage count is a multiple of PD = 2.
@@ -527,100 +627,227 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
         for (int p = 0; p < PD; ++p) stage(s + p, RB[p], RAr[p]);
     }
 
-    // ---- epilogue: C(i, j), i = it 32 + (lane & 31), j = j0 + wave 32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-    // 16-byte accesses: accumulator registers r, r+1 are two adjacent columns of one row; lanes 2q and 2q+1 (adjacent
-    // rows) swap one of them (DPP quad_perm [1,0,3,2]), after which the even lane owns rows (i, i+1) of column j_r and the
-    // odd lane rows (i-1, i) of column j_r+1: every lane reads X / V2 and writes V2 / Xs as ONE float4 per register pair.
-    // (Measured at configs[1] by switching parts of the kernel off: dictionary + A S reads alone 0.75 ms = 5.45 TB/s;
-    // + the Xs store 0.97 ms; + X / V2 reads and the V2 store 1.29 ms — 1.39 ms with 8-byte accesses; the MFMAs are
-    // free, 0.03 ms.  What keeps the kernel from the read-stream rate is its read-modify-write tail.)
-    float vmax = 0.f;
-    const bool vec4 = ((d.m & 1) == 0) && ((d.ldc & 1) == 0) && ((d.sCt & 1) == 0) && (((uintptr_t)d.C & 15) == 0) &&
-                      (EPI != EPI_UPDATE_C || ((((uintptr_t)d.e_r0 | (uintptr_t)d.e_rw0) & 15) == 0));
-    const TrialParams prm = (EPI == EPI_UPDATE_C) ? d.prm[t] : TrialParams();
-    auto swap1 = [](float x) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+    rows64_epilogue<EPI>(d, t, j0 + wave * 32, re, im, alpha, lane);
+}
+
+// ---- v3 of the streaming contraction: ONE dictionary shared by the trials (sPt == 0), m = 64 - BASELINE configs[4], where the
+//      two contractions are a (batch 64) x 4096 x 65536 complex GEMM and PMC shows what bounds the per-trial kernels above: the
+//      synthesis misses L2 on 70 % of its requests (77 GB per launch through the fabric at batch 32: the 64 workgroups an XCD holds
+//      stream 3 MiB per 32-k stage through a 4-MiB L2, so a panel fetched for one trial is gone before the next trial asks), and
+//      K B^H spends its LDS on 1.5 MFMAs per fragment read.  Here a workgroup of four waves takes TWO trials x 128 columns: each
+//      wave owns 32 columns of b (fragments straight to registers, as in v2) against the 128 rows of both trials' a panels (LDS) -
+//      48 MFMAs per k-step and wave on 16 a-fragment + 4 b-fragment reads (2.4 per read), 32 KiB of operands per 1536 MFMA cycles
+//      and CU instead of 48.  One wave per SIMD (accumulators 128 + second-level sums 128 + staging registers), one workgroup
+//      per CU.  The a operand arrives packed (d.Ap): split on the fly in a kernel with ONE wave per SIMD the conversions are not
+//      hidden behind anybody's MFMAs (measured: 16.6 ms against 12.1 ms for K B^H at configs[4]); the callers pack K once per
+//      iteration (0.37 ms).  TWOLVL: second-level sums every FLUSH2 stages, one accumulator per real sum (all three product streams
+//      have the same weight, see LO_SCALE).  The fold is 128 accumulator reads + adds per wave that nothing overlaps (one wave per
+//      SIMD): at 512 k per chain it costs 8 %; the rounding noise of a 65 536-term sum is within 1.4 x of hgemm_kernel's
+//      (first level 192 accumulations of partial sums up to sqrt(512) sigma, second level 128 additions: both ~1e-6 relative).
+constexpr int FLUSH2 = 16;
+template <int EPI, bool TWOLVL>
+__global__ __launch_bounds__(256, 1) void hgemm_pair_kernel(HGemmDesc d, int tiles_j, int npairs)
+{
+    constexpr int PD = 2;
+    extern __shared__ uint4 smem[];               // a panels, THREE stages (96 KiB): blocks [trial 2][it 2][ks 2][plane 4], 1 KiB each;
+                                                  // TWOLVL: + 64 KiB of second-level sums
+
+    // block -> (pair of trials, tile): the 32 workgroups an XCD holds are map_tb pairs x map_tt tiles
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int per = d.map_tb * d.map_tt, nbt = (npairs + d.map_tb - 1) / d.map_tb;
+    const int blk = (slot / per) * 8 + xcd, wq = slot % per;
+    const int tp = (blk % nbt) * d.map_tb + wq % d.map_tb;
+    const int tj = (blk / nbt) * d.map_tt + wq / d.map_tb;
+    if (tp >= npairs || tj >= tiles_j) return;
+    const int tr0 = 2 * tp, tr1 = min(2 * tp + 1, d.batch - 1);       // (odd batch: the last pair computes its trial twice)
+    const bool two = 2 * tp + 1 < d.batch;
+    const int j0 = tj * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const int eb = scale_exp(d.bmax[0]);
+    const int ea0 = scale_exp(d.amax[tr0]), ea1 = scale_exp(d.amax[tr1]);
+    const int nst = d.KS / 2;
+
+    // ---- a (packed like b, d.Ap): wave -> (trial, it) = (wave >> 1, wave & 1), its 8 blocks [ks 2][plane 4] of the stage
+    const uint4 *paw = d.Ap + (long long)((wave >> 1) ? tr1 : tr0) * d.sApt + lane + ((long long)(wave & 1) * d.KS) * 256;
+    struct AStg { u32x4 q[8]; };
+    auto load_a = [&](int s, AStg &R) {
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(paw + (long long)(2 * s) * 256);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) R.q[r] = g[r * 64];
     };
-    if (vec4) {
-        // All X / V2 loads of a row block (eight register pairs: 16 requests per lane) are issued BEFORE the first use,
-        // from addresses that are always valid (out-of-range pairs read the tile's first element and are masked at the
-        // store): with a bounds `continue` in front of the loads hipcc waited for each pair's loads (vmcnt(0)) before
-        // issuing the next pair's — sixteen serialized HBM round trips per lane.
-        const bool odd = lane & 1;
+    auto store_a = [&](const AStg &R, uint4 *buf) {
+        u32x4 *q = reinterpret_cast<u32x4 *>(buf + wave * 512 + lane);
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int gi = it * 32 + (lane & 31);
-            const int gi2 = gi & ~1;
-            float4 xs[8];
-            long long ixs[8];
-            bool ok[8];
+        for (int r = 0; r < 8; ++r) q[r * 64] = R.q[r];
+    };
+
+    // ---- b: this wave's 32 columns, straight to registers (as in hgemm2_kernel)
+    const uint4 *pbw = d.Bp + ((long long)(tj * 4 + wave) * d.KS) * 256 + lane;
+    struct BStg { u32x4 q[8]; };            // [ks 2][plane 4]
+    auto load_b_half = [&](int s, int ks, BStg &R) {
+        const u32x4 *g = reinterpret_cast<const u32x4 *>(pbw + (long long)(s < nst ? 2 * s + ks : 0) * 256);
 #pragma unroll
-            for (int rp = 0; rp < 8; ++rp) {
-                const int r0 = 2 * rp, r1 = r0 + 1;
-                const float2 o0 = make_float2(re[it][r0] * alpha, im[it][r0] * alpha);
-                const float2 o1 = make_float2(re[it][r1] * alpha, im[it][r1] * alpha);
-                const float2 snd = odd ? o0 : o1;
-                const float2 rcv = make_float2(swap1(snd.x), swap1(snd.y));
-                xs[rp] = odd ? make_float4(rcv.x, rcv.y, o1.x, o1.y) : make_float4(o0.x, o0.y, rcv.x, rcv.y);
-                const int gj = j0 + wave * 32 + (r0 & 3) + 8 * (r0 >> 2) + 4 * (lane >> 5) + (odd ? 1 : 0);
-                ok[rp] = gi2 < d.m && gj < d.n;
-                ixs[rp] = (long long)t * d.sCt + (ok[rp] ? gi2 + (long long)gj * d.ldc : 0);
-            }
-            if (EPI == EPI_UPDATE_C) {
-                float4 x[8], v2[8];
+        for (int p = 0; p < 4; ++p) R.q[ks * 4 + p] = g[p * 64];       // (NOT non-temporal: the other pairs of the XCD's block ask for the same lines)
+    };
+
+    // Second-level sums (TWOLVL): of trial 0 in registers (64), of trial 1 in LDS (the 64 KiB behind the three stage buffers: float4
+    // slot q of wave w at ((w 16 + q) 64 + lane): with all 128 in registers hipcc kept 44 of them in scratch and a fold became 22
+    // serialized scratch round trips - 12.1 ms instead of 10.4 for K B^H at configs[4])
+    f32x16 re[4], im[4], Lre[TWOLVL ? 2 : 1], Lim[TWOLVL ? 2 : 1];
+    float4 *Lsm = reinterpret_cast<float4 *>(smem + 3 * 2048) + wave * 1024 + lane;
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    x[rp] = *reinterpret_cast<const float4 *>(d.e_r0 + ixs[rp]);
-                    v2[rp] = *reinterpret_cast<const float4 *>(d.e_rw0 + ixs[rp]);
-                }
-                asm volatile("" ::: "memory");      // keep the sixteen requests together, ahead of every store
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    // Xs in xs;  V2 <- (1 - cc)(V2 - rho (X - Xs))   (proposed_algorithm.m:61 + :65 with C == -V2)
-                    float4 v = v2[rp];
-                    v.x = admm_v2(prm, v.x, x[rp].x, xs[rp].x);
-                    v.y = admm_v2(prm, v.y, x[rp].y, xs[rp].y);
-                    v.z = admm_v2(prm, v.z, x[rp].z, xs[rp].z);
-                    v.w = admm_v2(prm, v.w, x[rp].w, xs[rp].w);
-                    if (ok[rp]) {
-                        *reinterpret_cast<float4 *>(d.e_rw0 + ixs[rp]) = v;
-                        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-                    }
-                }
-            }
-#pragma unroll
-            for (int rp = 0; rp < 8; ++rp)
-                if (ok[rp]) *reinterpret_cast<float4 *>(d.C + ixs[rp]) = xs[rp];
+        for (int r = 0; r < 16; ++r) {
+            re[b][r] = 0.f; im[b][r] = 0.f;
+            if (TWOLVL && b < 2) { Lre[b][r] = 0.f; Lim[b][r] = 0.f; }
         }
-    } else {
+    if constexpr (TWOLVL) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int gi = it * 32 + (lane & 31);
-            if (gi >= d.m) continue;
+        for (int q = 0; q < 16; ++q) Lsm[q * 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto fold = [&]() {
+        if constexpr (TWOLVL) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gj = j0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (gj >= d.n) continue;
-                const float vr = re[it][r], vi = im[it][r];
-                const float2 o = make_float2(vr * alpha, vi * alpha);
-                const long long ix = (long long)t * d.sCt + gi + (long long)gj * d.ldc;
-                if (EPI == EPI_UPDATE_C) {
-                    const float2 x = d.e_r0[ix];
-                    float2 v2 = d.e_rw0[ix];
-                    v2.x = admm_v2(prm, v2.x, x.x, o.x);
-                    v2.y = admm_v2(prm, v2.y, x.y, o.y);
-                    d.e_rw0[ix] = v2;
-                    vmax = fmaxf(vmax, fmaxf(fabsf(v2.x), fabsf(v2.y)));
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    Lre[b][r] += re[b][r]; Lim[b][r] += im[b][r];
+                    re[b][r] = 0.f; im[b][r] = 0.f;
                 }
-                Cp[gi + (long long)gj * d.ldc] = o;
-            }
+#pragma unroll
+            for (int b = 2; b < 4; ++b)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 vr = Lsm[((b - 2) * 8 + q) * 64], vi = Lsm[((b - 2) * 8 + 4 + q) * 64];
+                    vr.x += re[b][4 * q]; vr.y += re[b][4 * q + 1]; vr.z += re[b][4 * q + 2]; vr.w += re[b][4 * q + 3];
+                    vi.x += im[b][4 * q]; vi.y += im[b][4 * q + 1]; vi.z += im[b][4 * q + 2]; vi.w += im[b][4 * q + 3];
+                    Lsm[((b - 2) * 8 + q) * 64] = vr; Lsm[((b - 2) * 8 + 4 + q) * 64] = vi;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { re[b][4 * q + c] = 0.f; im[b][4 * q + c] = 0.f; }
+                }
+        }
+    };
+    auto h8 = [](u32x4 u) { return *reinterpret_cast<half8 *>(&u); };
+    auto nh8 = [](u32x4 u) { u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+                             return *reinterpret_cast<half8 *>(&u); };
+    // Fragments of one trial, one k-step: [it 2][plane 4].  The reads of the NEXT (trial, k-step) are issued in front of the 24 MFMAs
+    // of the current one and spread between them (sched_group_barrier): with one wave per SIMD nobody else covers an LDS round
+    // trip (the compiler's own schedule read each block just in time: `ds_read, s_waitcnt lgkmcnt(0), v_mfma` all over the loop).
+    struct Frag { u32x4 f[8]; };
+    auto ldfrag = [&](const uint4 *pan, int ks, Frag &F) {
+        const u32x4 *fa0 = reinterpret_cast<const u32x4 *>(pan + ((0 * 2 + ks) * 4) * 64 + lane);
+        const u32x4 *fa1 = reinterpret_cast<const u32x4 *>(pan + ((1 * 2 + ks) * 4) * 64 + lane);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { F.f[p] = fa0[p * 64]; F.f[4 + p] = fa1[p * 64]; }
+    };
+    struct BFrag { half8 r_h, r_l, i_h, i_l, ni_h, ni_l; };
+    // re = ar br - ai bi with the sign on the b side: two negated planes per k-step and WAVE, not per row block
+    auto bfrag = [&](const BStg &R, int ks) {
+        BFrag b;
+        b.r_h = h8(R.q[ks * 4 + 0]); b.r_l = h8(R.q[ks * 4 + 1]); b.i_h = h8(R.q[ks * 4 + 2]); b.i_l = h8(R.q[ks * 4 + 3]);
+        b.ni_h = nh8(R.q[ks * 4 + 2]); b.ni_l = nh8(R.q[ks * 4 + 3]);
+        return b;
+    };
+    // 24 MFMAs: the two row blocks of one trial, four accumulators in rotation
+    auto mm = [&](const Frag &F, const BFrag &b, f32x16 &re0, f32x16 &im0, f32x16 &re1, f32x16 &im1) {
+        const half8 a0r_h = h8(F.f[0]), a0r_l = h8(F.f[1]), a0i_h = h8(F.f[2]), a0i_l = h8(F.f[3]);
+        const half8 a1r_h = h8(F.f[4]), a1r_l = h8(F.f[5]), a1i_h = h8(F.f[6]), a1i_l = h8(F.f[7]);
+        re0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a0r_h, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.i_h, a0r_h, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a1r_h, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.i_h, a1r_h, im1, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.ni_h, a0i_h, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a0i_h, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.ni_h, a1i_h, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a1i_h, im1, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_l, a0r_h, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.i_l, a0r_h, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_l, a1r_h, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.i_l, a1r_h, im1, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a0r_l, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.i_h, a0r_l, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a1r_l, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.i_h, a1r_l, im1, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.ni_l, a0i_h, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_l, a0i_h, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.ni_l, a1i_h, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_l, a1i_h, im1, 0, 0, 0);
+        re0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.ni_h, a0i_l, re0, 0, 0, 0);
+        im0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a0i_l, im0, 0, 0, 0);
+        re1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.ni_h, a1i_l, re1, 0, 0, 0);
+        im1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.r_h, a1i_l, im1, 0, 0, 0);
+    };
+    // Every load is UNCONDITIONAL (past the end the stage index is clamped and the data ignored), see hgemm2_kernel.
+    // Three LDS buffers: stage s reads buffer s % 3 and stores a(s + 2), so the first fragments of stage s + 1 (stored in stage
+    // s - 1, behind that stage's barrier) are read behind the last products of stage s - a stage starts with its operands in
+    // registers, and between two stages' MFMAs lie the eight LDS stores and the barrier only.
+    Frag F0;
+    auto stage = [&](int s, int cb, BStg &R, AStg &RAnext) {
+        const uint4 *cur = smem + cb * 2048;
+        const int nb1 = cb == 2 ? 0 : cb + 1, nb2 = cb == 0 ? 2 : cb - 1;      // (s + 1) % 3, (s + 2) % 3
+        Frag F1;
+        const BFrag b0 = bfrag(R, 0);
+        ldfrag(cur + 1024, 0, F1); mm(F0, b0, re[0], im[0], re[1], im[1]);
+        ldfrag(cur, 1, F0);        mm(F1, b0, re[2], im[2], re[3], im[3]);
+        load_b_half(s + PD, 0, R);
+        const BFrag b1 = bfrag(R, 1);
+        ldfrag(cur + 1024, 1, F1); mm(F0, b1, re[0], im[0], re[1], im[1]);
+        ldfrag(smem + nb1 * 2048, 0, F0); mm(F1, b1, re[2], im[2], re[3], im[3]);
+        load_b_half(s + PD, 1, R);
+        // the order of the stage's LDS reads and MFMAs, spelled out: four times (8 reads among 24 MFMAs)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        store_a(RAnext, smem + nb2 * 2048);                                // a(s+2): requested PD stages ago
+        load_a(min(s + 2 + PD, nst - 1), RAnext);
+        if (TWOLVL && ((s + 1) % FLUSH2) == 0) fold();
+        __syncthreads();
+    };
+
+    BStg RB[PD];
+    AStg RAr[PD];
+    {
+        AStg RA0, RA1;
+        load_a(0, RA0); load_a(min(1, nst - 1), RA1);
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            load_b_half(min(p, nst - 1), 0, RB[p]); load_b_half(min(p, nst - 1), 1, RB[p]);
+            load_a(min(p + 2, nst - 1), RAr[p]);
+        }
+        store_a(RA0, smem); store_a(RA1, smem + 2048);
+    }
+    __syncthreads();
+    ldfrag(smem, 0, F0);
+    int cb = 0;
+    for (int s = 0; s < nst; s += PD) {
+#pragma unroll
+        for (int p = 0; p < PD; ++p) {
+            stage(s + p, cb, RB[p], RAr[p]);
+            cb = cb == 2 ? 0 : cb + 1;
         }
     }
-    if (EPI == EPI_UPDATE_C && d.amax_v2) {
+    if constexpr (TWOLVL) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if (lane == 0) atomicMax(&d.amax_v2[t], __float_as_uint(vmax));
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { re[b][r] += Lre[b][r]; im[b][r] += Lim[b][r]; }
+#pragma unroll
+        for (int b = 2; b < 4; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 vr = Lsm[((b - 2) * 8 + q) * 64], vi = Lsm[((b - 2) * 8 + 4 + q) * 64];
+                re[b][4 * q] += vr.x; re[b][4 * q + 1] += vr.y; re[b][4 * q + 2] += vr.z; re[b][4 * q + 3] += vr.w;
+                im[b][4 * q] += vi.x; im[b][4 * q + 1] += vi.y; im[b][4 * q + 2] += vi.z; im[b][4 * q + 3] += vi.w;
+            }
     }
+    rows64_epilogue<EPI>(d, tr0, j0 + wave * 32, re, im, ldexpf(1.f, -(ea0 + eb)), lane);
+    if (two) rows64_epilogue<EPI>(d, tr1, j0 + wave * 32, re + 2, im + 2, ldexpf(1.f, -(ea1 + eb)), lane);
 }
 
 // ---- A Gram Z Z^H is Hermitian: with Z = h + l (f16 planes), G = HH + T + T^H, T(i,j) = sum h_i conj(l_j), so the product
@@ -1121,6 +1348,14 @@ static long long hgemm_grid(HGemmDesc &d, long long tiles, int conc)
     return (long long)((d.batch + 7) / 8) * 8 * tiles;
 }
 
+// the shapes hgemm_pair_kernel takes (given ONE dictionary for the batch): 64 rows per trial, at least one workgroup per CU
+bool hgemm_pair_shape(int m, int n, int batch)
+{
+    const char *pair_env = xp_getenv("JSTSP_HGEMM_PAIR");     // (experiments build: 0 = the per-trial kernels)
+    if (pair_env && atoi(pair_env) == 0) return false;
+    return m == 64 && batch >= 2 && (long long)((batch + 1) / 2) * ((n + 127) / 128) >= 256;
+}
+
 int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d_in, const char *prof_name)
 {
     HGemmDesc d = d_in;
@@ -1132,6 +1367,30 @@ int launch_hgemm(jstsp_ctx *ctx, const HGemmDesc &d_in, const char *prof_name)
     const int tiles_i = (d.m + 63) / 64, tiles_j = wide ? (d.n + 127) / 128 : (d.n + 63) / 64;
     const bool wide_even = wide && (d.k % 32) == 0 && ((d.KS / 2) % 2) == 0 && d.KS == 2 * (d.k / 32);
     JSTSP_REQUIRE((long long)((d.batch + 7) / 8) * 8 * tiles_i * tiles_j < (1ll << 30), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
+    // v3 (hgemm_pair_kernel): one dictionary for all trials, the a operand packed, m = 64, at least one workgroup per CU
+    if (d.Ap && d.aKS == d.KS && d.sPt == 0 && d.sbmax == 0 && !d.herm_upper && (d.KS % 4) == 0 &&
+        hgemm_pair_shape(d.m, d.n, d.batch) && d.JT * 32 >= ((d.n + 127) / 128) * 128) {
+        const int npairs = (d.batch + 1) / 2, tj3 = (d.n + 127) / 128;
+        d.map_tb = npairs < 4 ? npairs : 4;
+        d.map_tt = 32 / d.map_tb < tj3 ? 32 / d.map_tb : tj3;
+        const long long nb = (long long)((npairs + d.map_tb - 1) / d.map_tb) * ((tj3 + d.map_tt - 1) / d.map_tt);
+        const long long grid3 = ((nb + 7) / 8) * 8 * d.map_tb * d.map_tt;
+        JSTSP_REQUIRE(grid3 < (1ll << 31), JSTSP_E_UNSUPPORTED, "hgemm grid too large");
+        if (prof_name) prof_begin(ctx, prof_name);
+        // (second-level sums for a contraction of more than 1024 terms that has no epilogue: K B^H)
+        constexpr int PAIR_LDS = 3 * 2048 * (int)sizeof(uint4);      // (beyond 64 KiB: opted into per launch, the attribute is per device)
+        auto go = [&](auto kern, int lds) -> int {
+            JSTSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid3), dim3(256), lds, ctx->stream, d, tj3, npairs);
+            return 0;
+        };
+        if (d.epi == EPI_UPDATE_C) JSTSP_TRY(go(hgemm_pair_kernel<EPI_UPDATE_C, false>, PAIR_LDS));
+        else if (d.k > 1024) JSTSP_TRY(go(hgemm_pair_kernel<EPI_NONE, true>, PAIR_LDS + 65536));
+        else JSTSP_TRY(go(hgemm_pair_kernel<EPI_NONE, false>, PAIR_LDS));
+        if (prof_name) prof_end(ctx, prof_name);
+        JSTSP_HIP(hipGetLastError());
+        return 0;
+    }
     // v2 (hgemm2_kernel): one row tile, b fragments straight to registers.  Bit 0: packed-a products (the synthesis); bit 1:
     // fp32-a products of up to 1024 terms (the G_B applies: 185 -> 135 us each, but their single-level 512-term sums feed the
     // cancellation Res = A^H Tc - G_A V G_B and triple the rounding noise in S, 1.9e-6 -> 5.9e-6 relative: not used)

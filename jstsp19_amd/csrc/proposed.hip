@@ -49,6 +49,7 @@ struct ProposedWS {
     bool h2g = false;      // the two (G_A V) G_B applies of the gradient step on the same path
     HPack GBp;             // b(k, j) = G_B[k + G2 j]
     HPack Wp;              // the synthesis' a operand A S, re-packed every iteration (64 j-tiles would each split it)
+    HPack Kp;              // K of K B^H in fragment order (one dictionary for the batch: hgemm_pair_kernel reads it for two trials at a time)
     uint32_t *pmax = nullptr;
 };
 
@@ -83,6 +84,8 @@ static size_t proposed_bytes(int N, int M, int Gr, int G2, int batch, int nA, in
     if (use_hgemm(N, G2, M))
         b += hgemm_pack_bytes(M, G2, nB) + hgemm_pack_bytes(G2, M, nB) + 2 * rnd256(8 * batch * sizeof(uint32_t)) +
              hgemm_pack_bytes(G2, N, batch);
+    if (use_hgemm(N, G2, M) && nB == 1 && hgemm_pair_shape(N, G2, batch))
+        b += rnd256((size_t)batch * 2 * (4 * ((M + 63) / 64)) * 256 * sizeof(uint4));
     if (use_hgemm(Gr, G2, G2)) b += hgemm_pack_bytes(G2, G2, nB) + rnd256(2 * batch * sizeof(uint32_t));
     return b;
 }
@@ -130,6 +133,12 @@ static int proposed_alloc(Arena &a, ProposedWS &w, int N, int M, int Gr, int G2,
         w.Wp.data = a.get<uint4>((size_t)batch * w.Wp.st);
         w.Wp.bmax = w.wmax;
         JSTSP_REQUIRE(w.Wp.data, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
+        if (nB == 1 && hgemm_pair_shape(N, G2, batch)) {
+            w.Kp.KS = 4 * ((M + 63) / 64); w.Kp.JT = 2; w.Kp.count = batch;
+            w.Kp.st = (long long)w.Kp.JT * w.Kp.KS * 256;
+            w.Kp.data = a.get<uint4>((size_t)batch * w.Kp.st);
+            JSTSP_REQUIRE(w.Kp.data, JSTSP_E_NOMEM, "proposed_algorithm: workspace exhausted");
+        }
     }
     w.h2g = use_hgemm(Gr, G2, G2);
     if (w.h2g && !w.pmax) {
@@ -590,6 +599,13 @@ static int proposed_impl(jstsp_ctx *ctx, int N, int M, int Gr, int G2, int batch
             if (!fz) JSTSP_TRY(hgemm_absmax(ctx, w.ZK, snm, snm, batch, w.kmax));
             HGemmDesc hc{w.ZK, snm, N, w.kmax, w.Bc.data, strideB ? w.Bc.st : 0, w.Bc.bmax, strideB ? 1 : 0, w.Bc.KS,
                          w.Bc.JT, w.Tc, sng, N, N, G2, M, batch, EPI_NONE, nullptr, nullptr, nullptr};
+            if (w.Kp.data && !strideB && w.Kp.KS == w.Bc.KS) {
+                // one dictionary for the batch: k(n, m) in fragment order once (1 GiB read + written at configs[4] against 96 GiB
+                // that the 1024 workgroups of the per-trial kernel split themselves), then two trials per workgroup
+                w.Kp.bmax = w.kmax;
+                JSTSP_TRY(hgemm_repack(ctx, w.Kp, w.ZK, snm, N, 1, 0, M, N, w.kmax));
+                hc.Ap = w.Kp.data; hc.sApt = w.Kp.st; hc.aKS = w.Kp.KS;
+            }
             JSTSP_TRY(launch_hgemm(ctx, hc, "correlate"));
         } else
         JSTSP_TRY(gemm(ctx, 'N', 'C', N, G2, M, batch, Mat{w.ZK, snm, N}, Bm, w.Tc, sng, N, 1.f, nullptr, 0, 0,

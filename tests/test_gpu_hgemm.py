@@ -157,6 +157,65 @@ def test_proposed_ragged_and_two_row_tiles_through_split_f16(force_h2, N, M, Gr,
     check_below("hgemm_shapes.ce", ce_rel(ce, ceo), TOL_CE)
 
 
+@pytest.mark.parametrize("M,G2,batch", [(2048, 2048, 32), (4096, 4096, 17), (16384, 256, 4)])
+def test_shared_dictionary_pairs_of_trials_match_numpy(force_h2, M, G2, batch):
+    """hgemm_pair_kernel (one dictionary for the batch, N = 64, at least 256 workgroups: BASELINE configs[4]'s form of the two
+    contractions - two trials per workgroup against the same dictionary fragments): even and ODD batch (the last pair holds one
+    trial), the second-level sums of a 4096-term contraction, trials of very different scale in one pair, against float64 numpy -
+    and each trial bit-identical to the same trial in another batch position (pair partner and half of the pair changed)."""
+    import jstsp19_amd as J
+    rng = np.random.default_rng(M + batch)
+    N = Gr = 64
+    K, S = _rand(rng, batch, N, M), _rand(rng, batch, Gr, G2)
+    K[1] *= 1e-6; S[1] *= 1e5; K[2] *= 3e4                    # (scales are per trial: a pair shares nothing but the dictionary)
+    A, B = _rand(rng, N, Gr) / 8, _rand(rng, G2, M)
+    Cg, Xg = J.correlate(K, A, B), J.synthesize(S, A, B)
+    for t in range(batch):
+        ref_c = np.conj(A.T) @ K[t] @ np.conj(B.T)
+        ref_s = A @ S[t] @ B
+        check_below("hgemm_pair.correlate", rel_err(Cg[t], ref_c), 5e-6)
+        check_below("hgemm_pair.synthesize", rel_err(Xg[t], ref_s), 5e-6)
+    if batch >= 4:
+        perm = np.roll(np.arange(batch), 1)                     # trial t moves to position t + 1: other partner, other half
+        Cp, Xp = J.correlate(K[perm], A, B), J.synthesize(S[perm], A, B)
+        assert np.array_equal(Cp, Cg[perm]) and np.array_equal(Xp, Xg[perm])
+
+
+def test_proposed_shared_pilots_three_kernel_iteration_through_the_pair_kernel(force_h2):
+    """The solver's own use of the pair kernel: (A S) B with the packed a operand and the V2 update in its epilogue
+    (proposed_algorithm.m:58,61,65), three-kernel iteration (JSTSP_FUSED=0), N = 64, one pilot set for 8 trials, M = 8192
+    (4 pairs x 64 column tiles) - against the float64 oracle trial by trial, and batched == single (the single solve takes the
+    per-trial kernel)."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(58)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    N, M, Gr, G2, b, Imax = 64, 8192, 64, 128, 8, 8
+    A, B = r(N, Gr) / np.sqrt(N), r(G2, M) / np.sqrt(G2)
+    Om = (rng.random((b, N, M)) < 0.25).astype(float)
+    S0 = np.zeros((b, Gr, G2), complex)
+    for t in range(b):
+        S0[t, rng.integers(0, Gr, 5), rng.integers(0, G2, 5)] = r(5)
+    subY = Om * (A @ S0 @ B + 0.05 * r(b, N, M))
+    fro2 = (np.abs(subY) ** 2).sum((1, 2))
+    tY, tZ, rho = 1.0 / fro2, np.full(b, 1e-2), np.full(b, 0.25)
+    old = os.environ.get("JSTSP_FUSED")
+    os.environ["JSTSP_FUSED"] = "0"
+    try:
+        S, Y, ce = J.proposed_algorithm(subY, Om, A, B, Imax, tY, tZ, rho, "approximate")
+        S1, Y1, _ = J.proposed_algorithm(subY[5:6], Om[5:6], A, B, Imax, tY[5:6], tZ[5:6], rho[5:6], "approximate")
+    finally:
+        if old is None:
+            os.environ.pop("JSTSP_FUSED", None)
+        else:
+            os.environ["JSTSP_FUSED"] = old
+    for t in (0, 5, 7):
+        So, Yo, ceo = O.proposed_algorithm(subY[t], Om[t], A, B, Imax, float(tY[t]), float(tZ[t]), float(rho[t]), "approximate")
+        check_below("hgemm_pair.S", rel_err(S[t], So), TOL_S); check_below("hgemm_pair.Y", rel_err(Y[t], Yo), TOL_S)
+        check_below("hgemm_pair.ce", ce_rel(ce[t], ceo), TOL_CE)
+    check_below("hgemm_pair.batched_vs_single.S", rel_err(S1[0], S[5]), TOL_S)
+
+
 def test_side_stream_overlap_is_bit_identical_through_the_split_f16_grams(force_h2):
     """JSTSP_OVERLAP=1 runs the next SVT preparation and the norm chain on side streams.  Same kernels, same
     arithmetic: the results must be bit-identical to the single-stream run, also when the side-stream Grams (which
