@@ -119,7 +119,7 @@ size_t jstsp_workspace_bytes(const jstsp_ctx *ctx);
  * libjstsp_mi355x_xp.so (loaded by the Python binding under JSTSP_EXPERIMENTS_LIB=1; tools/ only, never a reported number), in
  * which they are read again; HISTORY.md has what each one measured:
  *   JSTSP_GRAM_REFINE JSTSP_RV_REFRESH JSTSP_RV_ALWAYS JSTSP_RV_COMP JSTSP_GRAD_HEAD JSTSP_SVT_SKIP JSTSP_PASS_ACC JSTSP_INV2
- *   JSTSP_HGEMM_MAP JSTSP_OMP_REG JSTSP_OMP_GRAM JSTSP_SADMM_FUSE JSTSP_SADMM_OVERLAP JSTSP_M3_MINK JSTSP_HOST_TRACE JSTSP_BJ_TRACE
+ *   JSTSP_HGEMM_MAP JSTSP_HGEMM_PAIR JSTSP_OMP_REG JSTSP_OMP_GRAM JSTSP_SADMM_FUSE JSTSP_SADMM_OVERLAP JSTSP_M3_MINK JSTSP_HOST_TRACE JSTSP_BJ_TRACE
  * (and JSTSP_FUSED_DBG in a -DJSTSP_FUSED_DBG_BUILD build of fused.hip: timing experiments, results wrong). */
 
 /* ---- kernel-level entry points (the north-star correlation / synthesis) ------------ */

@@ -216,6 +216,32 @@ def test_proposed_shared_pilots_three_kernel_iteration_through_the_pair_kernel(f
     check_below("hgemm_pair.batched_vs_single.S", rel_err(S1[0], S[5]), TOL_S)
 
 
+def test_proposed_shared_pilots_both_contractions_through_the_pair_kernel():
+    """K B^H (second-level sums, K packed once per iteration) AND (A S) B through hgemm_pair_kernel inside the solver, at a shape
+    the default switches give it to: N = 64, G2 = 2048 (no one-pass iteration beyond 512), M = 4096, 32 trials on one pilot set
+    (16 pairs x 16 / 32 column tiles) - K B^H feeds the cancellation Res = A^H Tc - R v (proposed_algorithm.m:47), which is where
+    accumulation noise would show.  Three trials against the float64 oracle after 10 iterations; the support-restricted variant too."""
+    import jstsp19_amd as J
+    from oracle import solvers as O
+    rng = np.random.default_rng(4747)
+    r = lambda *s: rng.standard_normal(s) + 1j * rng.standard_normal(s)
+    N, M, Gr, G2, b, Imax = 64, 4096, 64, 2048, 32, 10
+    A, B = r(N, Gr) / np.sqrt(N), r(G2, M) / np.sqrt(G2)
+    Om = (rng.random((b, N, M)) < 0.25).astype(float)
+    S0 = np.zeros((b, Gr, G2), complex)
+    for t in range(b):
+        S0[t, rng.integers(0, Gr, 6), rng.integers(0, G2, 6)] = r(6)
+    subY = Om * (A @ S0 @ B + 0.05 * r(b, N, M))
+    fro2 = (np.abs(subY) ** 2).sum((1, 2))
+    tY, tZ, rho = 1.0 / fro2, np.full(b, 1e-2), np.full(b, 0.25)
+    S, Y, ce = J.proposed_algorithm(subY, Om, A, B, Imax, tY, tZ, rho, "approximate")
+    for t in (0, 17, 31):
+        So, Yo, ceo = O.proposed_algorithm(subY[t], Om[t], A, B, Imax, float(tY[t]), float(tZ[t]), float(rho[t]), "approximate")
+        check_below("hgemm_pair.full.S", rel_err(S[t], So), TOL_S); check_below("hgemm_pair.full.Y", rel_err(Y[t], Yo), TOL_S)
+        check_below("hgemm_pair.full.ce", ce_rel(ce[t], ceo), TOL_CE)
+        check_below("hgemm_pair.full.nmse", abs(O.nmse_capped(S[t], S0[t]) - O.nmse_capped(So, S0[t])), TOL_NMSE)
+
+
 def test_side_stream_overlap_is_bit_identical_through_the_split_f16_grams(force_h2):
     """JSTSP_OVERLAP=1 runs the next SVT preparation and the norm chain on side streams.  Same kernels, same
     arithmetic: the results must be bit-identical to the single-stream run, also when the side-stream Grams (which
