@@ -150,3 +150,42 @@ def test_cfg5_full_frame_shared_pilots_properties():
                                            ty[1:2], tz[1:2], rho[1:2], "approximate", None, want_ce=False)
     torch.cuda.synchronize()
     assert float((S1[0] - S[1]).abs().max() / S[1].abs().max()) < 1e-5
+
+
+def test_cfg5_full_frame_against_the_float64_oracle():
+    """The full configs[4] frame (N=64, M=65 536, Gr=64, G2=4096, one pilot set) against the float64 numpy oracle - not only its
+    properties: 16 trials of proposed_algorithm_angles (the batch at which BOTH big contractions take the two-trials-per-workgroup
+    kernel: 8 pairs x 32 column tiles for K B^H, x 512 for (A S) B), 6 iterations, trials 0 and 9 (first and second of a pair)
+    compared: S and Y to 1e-5 of their maxima, |dNMSE| <= 1e-6.  The oracle's setup (B B^H: 8.8 TFLOP in float64) and six iterations
+    take about half a minute per trial on the box's cores; skipped when the host has less than 24 GiB free (B in complex128 and its
+    conjugate transpose are 8 GiB)."""
+    import psutil
+    import torch
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import build_trials
+    from oracle import solvers as O
+    from threadpoolctl import threadpool_limits
+    if psutil.virtual_memory().available < (24 << 30):
+        pytest.skip("needs 24 GiB of free host memory for the float64 oracle at this size")
+    p = _params()
+    assert p.solver_shape == (64, 65536, 64, 4096)
+    nb, Imax = 16, 6
+    inp = build_trials(p, 0, nb, seed=81, shared_pilots=True)
+    B = J.colmajor(inp["B"][0].clone())
+    del inp["B"]
+    torch.cuda.empty_cache()
+    ty, tz, rho = inp["tau_Y"].numpy(), inp["tau_Z"].numpy(), inp["rho"].numpy()
+    S, Y, _ = J.proposed_algorithm_angles(inp["subY"], inp["Omega"], inp["indx_S"], inp["A"], B, Imax, ty, tz, rho, "approximate", None,
+                                          want_ce=False)
+    torch.cuda.synchronize()
+    assert J.default_context(0).last_dictionary_block() == 256
+    A_h = inp["A"].cpu().numpy().astype(np.complex128)
+    B_h = B.cpu().numpy().astype(np.complex128)
+    with threadpool_limits(limits=min(32, psutil.cpu_count() or 1)):
+        for t in (0, 9):
+            So, Yo, _ = O.proposed_algorithm(_np(inp["subY"], t), _np(inp["Omega"], t, np.float64), A_h, B_h, Imax, float(ty[t]),
+                                             float(tz[t]), float(rho[t]), "approximate", indx_S=inp["indx_S"][t].cpu().numpy(), want_ce=False)
+            sg, zb = _np(S, t), _np(inp["Zbar"], t)
+            check_below("cfg5.full.S", np.max(np.abs(sg - So)) / np.max(np.abs(So)), TOL_S)
+            check_below("cfg5.full.Y", np.max(np.abs(_np(Y, t) - Yo)) / np.max(np.abs(Yo)), TOL_S)
+            check_below("cfg5.full.nmse", abs(O.nmse_capped(sg, zb) - O.nmse_capped(So, zb)), TOL_NMSE)
