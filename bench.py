@@ -68,6 +68,8 @@ def parse():
                     help="besides the bench batch (always checked against the committed float64 fixture), this many trials of the "
                          "configs[3] sweep (10 SNR points, up to 2560) against the same fixture: about 3.5 s per 100")
     ap.add_argument("--no-strict-fp32", action="store_true", help="skip the informational JSTSP_H2=0 (strict complex-fp32 MFMA) rate")
+    ap.add_argument("--no-configs4", action="store_true",
+                    help="skip the informational BASELINE configs[4] leg (proposed_algorithm_angles at N=64 M=65536 G2=4096, 32 trials, one call)")
     return ap.parse_args()
 
 
@@ -147,6 +149,37 @@ def make_inputs(p, trial_ids, device, shared_pilots=False):
         o["B"] = colmajor(o["B"][0].clone())                   # 2-D => shared dictionary (strideB = 0)
     return dict(subY=o["subY"], Omega=o["Omega"], A=o["A"], B=o["B"], Zbar=o["Zbar"], tau_Y=o["tau_Y"].numpy(),
                 tau_Z=o["tau_Z"].numpy(), rho=o["rho"].numpy())
+
+
+def configs4_leg(device, batch=32):
+    """BASELINE configs[4]'s proposed_algorithm_angles (proposed_algorithm_angles.m:36-75) at its full frame - Nt=256 Nr=64 K=256 L=16:
+    N=64, M=65 536, Gr=64, G2=4096, ONE pilot set for the batch (the 2-GiB dictionary), inputs built on the device - ONE timed call
+    of Imax iterations after a one-iteration priming call.  Informational (the line's metric is configs[1]'s); per GPU: configs[4]
+    shards its trials like configs[3]."""
+    import jstsp19_amd as J
+    from jstsp19_amd.system_model import SweepParams, build_trials
+    p4 = SweepParams(Nt=256, Nr=64, L=16, T=256, Mr=8, snr_db=5.0)
+    o = build_trials(p4, 0, batch, device=device, shared_pilots=True)
+    B = J.colmajor(o["B"][0].clone())
+    del o["B"]
+    torch.cuda.empty_cache()
+    ty, tz, rho = o["tau_Y"].numpy(), o["tau_Z"].numpy(), o["rho"].numpy()
+    call = lambda im: J.proposed_algorithm_angles(o["subY"], o["Omega"], o["indx_S"], o["A"], B, im, ty, tz, rho, "approximate", None)
+    call(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    S, _, _ = call(IMAX)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nm = J.nmse_spectral(S, J.colmajor(o["Zbar"].to(torch.complex64)))
+    out = {"value": round(batch / dt, 3), "unit": "channel-estimates/s per GPU", "trials": batch, "seconds": round(dt, 4), "Imax": IMAX,
+           "mean_nmse": float(nm.mean().item()), "dictionary_block": int(J.default_context(device.index).last_dictionary_block()),
+           "workload": "BASELINE configs[4]: proposed_algorithm_angles approximate, Nt=256 Nr=64 K=256 L=16 (N=64 M=65536 Gr=64 G2=4096), "
+                       "one pilot set per batch, three outputs",
+           "note": "informational; three-kernel iteration, both big contractions through hgemm_pair_kernel (DESIGN.md section 7)"}
+    del o, B, S
+    torch.cuda.empty_cache()
+    return out
 
 
 def emit(line, dist, rank):
@@ -643,6 +676,11 @@ def main():
                 "note": "jstsp_proposed_algorithm_c32 with memspace JSTSP_HOST: pageable numpy arrays in (subY, Omega, B per trial), "
                         "S, Y, convergence_error out - what a MEX call pays; never the headline value"}
         del hs
+
+    if rank == 0 and world == 1 and not a.small and not a.no_configs4:
+        del inp, out, S, Y, ce
+        torch.cuda.empty_cache()
+        extra["configs4"] = configs4_leg(device)
 
     if rank == 0:
         total = a.batch * world * a.steps

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   d="/tmp/pmc_${tag}_${c}"
   rm -rf "$d"
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$d" -o "$tag" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-strict-fp32 "$@" > /dev/null 2> "$R/gpurun_out/${tag}_pmc_${c}.err"
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$d" -o "$tag" -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-strict-fp32 --no-configs4 "$@" > /dev/null 2> "$R/gpurun_out/${tag}_pmc_${c}.err"
   f=$(find "$d" -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ] || [ ! -s "$f" ]; then echo "pmc_bench: no counter_collection.csv under $d (see ${tag}_pmc_${c}.err)" >&2; exit 1; fi
   : > "$R/gpurun_out/${tag}_pmc_${c}.txt"

@@ -6,7 +6,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 python3 bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.err; tail -c 600 gpurun_out/r04_bench_default.json
-bash tools/prof_bench.sh r04_bench --steps 3 --warmup 1 --no-cpu-baseline --no-host-path --no-strict-fp32 | tail -30
+bash tools/prof_bench.sh r04_bench --steps 3 --warmup 1 --no-cpu-baseline --no-host-path --no-strict-fp32 --no-configs4 | tail -30
 bash tools/pmc_bench.sh r04 | tail -3
 bash tools/prof_cmd.sh r04_cfg1_omp tools/bench_cfg1_omp.py | tail -25
 bash tools/prof_cmd.sh r04_cfg3 tools/bench_cfg3.py 1024 | tail -30
