@@ -157,11 +157,11 @@ def test_proposed_ragged_and_two_row_tiles_through_split_f16(force_h2, N, M, Gr,
     check_below("hgemm_shapes.ce", ce_rel(ce, ceo), TOL_CE)
 
 
-@pytest.mark.parametrize("M,G2,batch", [(2048, 2048, 32), (4096, 4096, 17), (16384, 256, 4)])
+@pytest.mark.parametrize("M,G2,batch", [(2048, 2048, 32), (4096, 4096, 17), (16384, 256, 4), (4160, 2050, 31)])
 def test_shared_dictionary_pairs_of_trials_match_numpy(force_h2, M, G2, batch):
     """hgemm_pair_kernel (one dictionary for the batch, N = 64, at least 256 workgroups: BASELINE configs[4]'s form of the two
     contractions - two trials per workgroup against the same dictionary fragments): even and ODD batch (the last pair holds one
-    trial), the second-level sums of a 4096-term contraction, trials of very different scale in one pair, against float64 numpy -
+    trial), column counts and contraction lengths that end inside a tile / a 64-term stage pair (4160, 2050), the second-level sums of a 4096-term contraction, trials of very different scale in one pair, against float64 numpy -
     and each trial bit-identical to the same trial in another batch position (pair partner and half of the pair changed)."""
     import jstsp19_amd as J
     rng = np.random.default_rng(M + batch)
