@@ -13,9 +13,11 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // VAR 0: 32x32x16, 4 accumulators (the wave tile of hgemm2_kernel); VAR 1: 16x16x32, 8 accumulators (the pass)
 template <int VAR>
-__global__ __launch_bounds__(256) void k(const half8 *ops, float *out, int iters)
+__global__ __launch_bounds__(256) void k(const half8 *ops, float *out, int iters, unsigned long long *clk)
 {
     const int tid = threadIdx.x;
+    // shader-clock cycles (s_memtime) against the constant 100-MHz counter (s_memrealtime): the clock the chip HOLDS under this load
+    const unsigned long long c0_ = clock64(), w0_ = wall_clock64();
     half8 a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a[i] = ops[(i * 256 + tid) % 2048]; b[i] = ops[((i + 4) * 256 + tid) % 2048]; }
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256) void k(const half8 *ops, float *out, int iters
         for (int q = 0; q < 8; ++q) s += c[q][0] + c[q][1] + c[q][2] + c[q][3];
     }
     out[blockIdx.x * 256 + tid] = s;
+    if (clk && blockIdx.x == 0 && tid == 0) { clk[0] = clock64() - c0_; clk[1] = wall_clock64() - w0_; }
 }
 
 // 16x16x32 with 16 accumulators (is the one-wave-per-SIMD rate of VAR 1 a dependency limit?)
@@ -75,16 +78,23 @@ template <int VAR> void run(const char *name, const half8 *ops, int blocks, doub
     const int iters = 20000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<VAR><<<blocks, 256>>>(ops, out, 100);
+    unsigned long long *clk, hclk[2];
+    hipMalloc(&clk, 16);
+    k<VAR><<<blocks, 256>>>(ops, out, 100, nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<VAR><<<blocks, 256>>>(ops, out, iters);
+    k<VAR><<<blocks, 256>>>(ops, out, iters, clk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    printf("  %-34s %d waves/SIMD  %8.3f ms  %7.1f TFLOP/s\n", name, blocks / 256, ms, (double)blocks * 4 * iters * flop_per_iter / ms / 1e9);
-    hipFree(out);
+    hipMemcpy(hclk, clk, 16, hipMemcpyDeviceToHost);
+    const double ghz = (double)hclk[0] / ((double)hclk[1] / 100e6) / 1e9;           // (s_memrealtime: 100 MHz)
+    const double tf = (double)blocks * 4 * iters * flop_per_iter / ms / 1e9;
+    // at the held clock the issue-rate peak is 2500 x clock / 2.4 TFLOP/s: how busy the pipe is at THAT clock
+    printf("  %-34s %d waves/SIMD  %8.3f ms  %7.1f TFLOP/s  clock %.2f GHz  (%.0f %% of the issue rate at that clock)\n", name, blocks / 256, ms, tf, ghz,
+           100.0 * tf / (2500.0 * ghz / 2.4));
+    hipFree(out); hipFree(clk);
 }
 
 int main()
