@@ -637,13 +637,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void hgemm2_kernel(HGemmD
 //      K B^H spends its LDS on 1.5 MFMAs per fragment read.  Here a workgroup of four waves takes TWO trials x 128 columns: each
 //      wave owns 32 columns of b (fragments straight to registers, as in v2) against the 128 rows of both trials' a panels (LDS) -
 //      48 MFMAs per k-step and wave on 16 a-fragment + 4 b-fragment reads (2.4 per read), 32 KiB of operands per 1536 MFMA cycles
-//      and CU instead of 48.  One wave per SIMD (accumulators 128 + second-level sums 128 + staging registers), one workgroup
-//      per CU.  The a operand arrives packed (d.Ap): split on the fly in a kernel with ONE wave per SIMD the conversions are not
+//      and CU instead of 48.  One wave per SIMD (accumulators 128 + second-level sums 64, the other 64 in LDS + 128 staging and fragment
+//      registers), one workgroup per CU.  The a operand arrives packed (d.Ap): split on the fly in a kernel with ONE wave per SIMD the conversions are not
 //      hidden behind anybody's MFMAs (measured: 16.6 ms against 12.1 ms for K B^H at configs[4]); the callers pack K once per
 //      iteration (0.37 ms).  TWOLVL: second-level sums every FLUSH2 stages, one accumulator per real sum (all three product streams
 //      have the same weight, see LO_SCALE).  The fold is 128 accumulator reads + adds per wave that nothing overlaps (one wave per
 //      SIMD): at 512 k per chain it costs 8 %; the rounding noise of a 65 536-term sum is within 1.4 x of hgemm_kernel's
-//      (first level 192 accumulations of partial sums up to sqrt(512) sigma, second level 128 additions: both ~1e-6 relative).
+//      (first level 192 accumulations of partial sums up to sqrt(512) sigma, second level 128 additions: both ~1e-6 relative;
+//      measured in S after 10 ADMM iterations: mean 2.8e-7 -> 3.5e-7, tools/probe/pair_noise.py).
 constexpr int FLUSH2 = 16;
 template <int EPI, bool TWOLVL>
 __global__ __launch_bounds__(256, 1) void hgemm_pair_kernel(HGemmDesc d, int tiles_j, int npairs)
