@@ -680,7 +680,10 @@ def main():
     if rank == 0 and world == 1 and not a.small and not a.no_configs4:
         del inp, out, S, Y, ce
         torch.cuda.empty_cache()
-        extra["configs4"] = configs4_leg(device)
+        try:                                    # (informational: whatever happens here, the line's own metric is printed)
+            extra["configs4"] = configs4_leg(device)
+        except Exception as e:                  # noqa: BLE001
+            extra["configs4"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         total = a.batch * world * a.steps
