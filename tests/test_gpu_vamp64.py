@@ -30,8 +30,9 @@ def _hbf_trials(db, nt, seed):
 
 
 def test_vamp_kron_float64_follows_the_oracle_as_far_as_float64_can_three_snr_points():
-    """6 trials at each of -6 and 12 dB through jstsp_vamp_kron_c64 (host arrays, one batched call per point and iteration count)
-    against oracle.vamp.vamp_kron on the same inputs, numOfnz = 100 (plot_errorVSsnr.m:26,100), after 12, 50 and 100 iterations.
+    """4 trials at each of -6 and 12 dB through jstsp_vamp_kron_c64 (host arrays, one batched call per point and iteration count)
+    against oracle.vamp.vamp_kron on the same inputs, numOfnz = 100 (plot_errorVSsnr.m:26,100), after 12, 50 and 100 iterations
+    (50 at the first point only: the suite's time).
 
     What can be asserted.  The reference's configuration (sigma = 1, no stopping rule) is chaotic: at this size a rounding
     difference grows ~1.4-fold per iteration, so TWO FLOAT64 RESTATEMENTS of the same recurrences (oracle.vamp.vamp_kron: factored;
@@ -44,11 +45,11 @@ def test_vamp_kron_float64_follows_the_oracle_as_far_as_float64_can_three_snr_po
     import jstsp19_amd as J
     from oracle import solvers as O
     from oracle import vamp as V
-    nt = 6              # (the literal restatement takes 5 s per run at this size: 54 runs; 16 trials per point were run once for
-                        #  profiles/r06_measured_tolerances.json)
+    nt = 4              # (the literal restatement takes 5 s per run at this size: 24 runs here; 16 trials per point at three SNR points and
+                        #  12 / 50 / 100 iterations were run once for profiles/r06_measured_tolerances_vamp64.json)
     for db in (-6.0, 12.0):
         A, Gb, Ym, Zb = _hbf_trials(db, nt, seed=616)
-        for nit in NITS:
+        for nit in (NITS if db < 0 else (12, 100)):
             X = np.asarray(J.vamp_kron(Ym, A, Gb, 1.0, 100, nit=nit))
             assert X.dtype == np.complex128 and X.shape == (nt,) + Zb.shape[1:]
             refs = [V.vamp_kron(Ym[t], A, Gb[t], 1.0, 100, nit=nit) for t in range(nt)]
@@ -75,11 +76,11 @@ def test_vamp_dense_float64_is_the_reference_call_at_the_drivers_size():
     import torch
     import jstsp19_amd as J
     from oracle import vamp as V
-    nt = 3
+    nt = 2
     A, Gb, Ym, Zb = _hbf_trials(6.0, nt, seed=99)
     Phi = np.stack([np.kron(Gb[t].T, A) for t in range(nt)])
     y = np.stack([Ym[t].reshape(-1, order="F") for t in range(nt)])
-    for nit in (12, 50, 100):
+    for nit in (12, 100):
         x = np.asarray(J.vamp(y, Phi, 1.0, 100, nit=nit))
         dev = spread = 0.0
         for t in range(nt):
