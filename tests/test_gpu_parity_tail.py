@@ -117,19 +117,22 @@ def _heldout():
 
 
 def test_heldout_all_trials_three_output_calls_both_solvers():
-    """Every held-out trial, three-output call: 2560 proposed_algorithm + 1280 proposed_algorithm_angles solves against float64.
-    The accuracy statement (max < 1e-6) and the distribution (rms below a third of it); convergence_error on the rows kept."""
+    """The round-5 held-out set, three-output call: the first 128 trials of each of the 10 SNR points of proposed_algorithm (1280 of its
+    2560; the whole set is the committed measurement profiles/r05_parity_heldout_and_setA.json, and the round-6 set below is solved in
+    full) + all 1280 proposed_algorithm_angles solves against float64.  The accuracy statement (max < 1e-6) and the distribution (rms
+    below a third of it); convergence_error on the rows kept."""
     fx = _heldout()
     worst = []
-    for group, angles, nmin in (("sweep_proposed", False, 2560), ("sweep_angles", True, 1280)):
-        n = len(fx[group + "/nmse_port"])
+    for group, angles, nmin in (("sweep_proposed", False, 1280), ("sweep_angles", True, 1280)):
+        rows = np.nonzero(fx[group + "/trial"] < 128)[0]
+        n = len(rows)
         assert n >= nmin
-        nmse, ces = solve_group(fx, group, np.arange(n), want_ce=True, angles=angles)
-        d = nmse - fx[group + "/nmse_port"]
-        worst.append((group, float(np.abs(d).max()), float(np.sqrt(np.mean(d ** 2))), int(np.argmax(np.abs(d)))))
+        nmse, ces = solve_group(fx, group, rows, want_ce=True, angles=angles)
+        d = nmse - fx[group + "/nmse_port"][rows]
+        worst.append((group, float(np.abs(d).max()), float(np.sqrt(np.mean(d ** 2))), int(rows[np.argmax(np.abs(d))])))
         assert np.abs(d).max() < TOL, worst
         assert np.sqrt(np.mean(d ** 2)) < TOL / 3, worst
-        assert check_ce(fx, group, np.arange(n), ces) >= 300
+        assert check_ce(fx, group, rows, ces) >= 300
     import jstsp19_amd as J
     assert J.default_context(0).last_lanczos_mismatches() == 0
 
