@@ -116,7 +116,7 @@ def _heldout():
     return fx
 
 
-def test_heldout_all_trials_three_output_calls_both_solvers():
+def test_heldout_three_output_calls_128_trials_per_point_both_solvers():
     """The round-5 held-out set, three-output call: the first 128 trials of each of the 10 SNR points of proposed_algorithm (1280 of its
     2560; the whole set is the committed measurement profiles/r05_parity_heldout_and_setA.json, and the round-6 set below is solved in
     full) + all 1280 proposed_algorithm_angles solves against float64.  The accuracy statement (max < 1e-6) and the distribution (rms
